@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- LCRC posterior path throughput on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (window assembly + window/DCT projection +
+band-L, band-R and merger MLPs, fused in one HIP kernel) over one batch of
+8192 frames of the PHN_CZ_SPDAT_LCRC_N1500 system, input log-mel frames already
+resident in HBM, output posteriors left in HBM.  N GPUs = N replicas, each on
+its own batch (utterances shard with no exchange; weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the fused kernel against the
+f32 MFMA peak with the ALGORITHMIC flop count (unpadded 2*MAC of the three MLPs,
+3.060 MFLOP per CZ frame) and HIP-event kernel times taken on the
+launch stream inside the timed region.  `cpu_baseline` times the reference's own
+code (oracle/_ref, built from /root/reference in the build container) on this
+box's host cores on a bounded sample, and reports the GPU-vs-CPU parity on it.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SYSTEM = "PHN_CZ_SPDAT_LCRC_N1500"
+BATCH = 8192
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+
+
+def algorithmic_flops_per_frame(dims):
+    """2*MAC of the three MLPs, unpadded."""
+    return sum(2 * (i * h + h * o) for (i, h, o) in dims)
+
+
+def model_directory(tmp):
+    from phnrec_amd import modelgen
+    real = os.path.join(ROOT, "tests", "golden", "models", SYSTEM)
+    if os.path.isdir(real):
+        return real, "shipped %s .nbin weights" % SYSTEM
+    d = os.path.join(tmp, SYSTEM)
+    modelgen.write_system(d, SYSTEM, seed=1234)
+    return d, "seeded random weights of the %s shape" % SYSTEM
+
+
+def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
+    """The reference CPU path on this host, bounded to ~budget_s seconds per variant."""
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import binding as ob
+    out = None
+    chunk = 512
+    for blas in (True, False):
+        if ob.ref_lib_path(blas) is None:
+            continue
+        try:
+            t = ob.RefTraps(mdir, nbanks, bunch=5, blas=blas)
+        except OSError:
+            continue
+        done, work, t0, worst = 0, 0, time.perf_counter(), 0.0
+        while time.perf_counter() - t0 < budget_s:
+            # chunk with a 15-frame halo on each side == rows of the whole utterance;
+            # wraps around the batch until the time budget is used
+            pos = done % (mel.shape[0] - chunk + 1)
+            a, b = max(0, pos - 15), min(mel.shape[0], pos + chunk + 15)
+            post = t.process_offline(mel[a:b])[pos - a:pos - a + chunk]
+            worst = max(worst, float(np.abs(post - gpu_post[pos:pos + chunk]).max()))
+            done += chunk
+            work += b - a          # halo frames are real work for the CPU too
+        dt = time.perf_counter() - t0
+        out = {"value": round(work / dt, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+               "variant": ("USE_BLAS (MKL cblas_sgemv, shipped bunch_size=5)" if blas
+                           else "naive loop (no BLAS), bunch_size=5"),
+               "sample": "%d frames of the bench batch (512-frame chunks + 15-frame halos), %.1f s" % (work, dt),
+               "parity_max_abs_vs_gpu": worst}
+        break
+    # this repo's port, single thread and all cores (frames split over threads)
+    o = ob.Oracle(mdir, nbanks)
+    n1 = min(mel.shape[0], 2048)
+    t0 = time.perf_counter()
+    p1 = o.posteriors(mel[:n1 + 15])[:n1]
+    dt1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    nall, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < min(budget_s, 5.0):
+        o.posteriors(mel, threads=cores)
+        nall += mel.shape[0]
+    dta = time.perf_counter() - t0
+    port = {"value": round(n1 / dt1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "first %d frames, %.1f s" % (n1, dt1),
+            "parity_max_abs_vs_gpu": float(np.abs(p1 - gpu_post[:n1]).max()),
+            "all_cores": {"value": round(nall / dta, 1), "cores": cores,
+                          "sample": "%d frames, %.1f s" % (nall, dta)}}
+    if out is None:
+        return port
+    out["port"] = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from phnrec_amd import capi, distrun, modelgen
+
+    ranks = distrun.Ranks(args.gpus)
+    if ranks.world != args.gpus and ranks.world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ranks.world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the LCRC path has no CPU fallback")
+    torch.cuda.set_device(ranks.local_rank)
+    dev = torch.device("cuda", ranks.local_rank)
+    ranks.init("nccl")
+
+    spec = modelgen.SYSTEMS[SYSTEM]
+    nb = spec["nbanks"]
+    with tempfile.TemporaryDirectory() as tmp:
+        mdir, weights_desc = model_directory(tmp)
+        ctx = capi.Lcrc(mdir, nb, device=ranks.local_rank)
+        dims = [ctx.net_dims(i) for i in range(3)]
+        flops_frame = algorithmic_flops_per_frame(dims)
+
+        # synthetic log-mel batch of this rank, resident in HBM
+        mel = modelgen.synth_mel(args.batch, nb, seed=1235 + ranks.rank, mean_norm=spec["sent_mean_norm"])
+        d_mel = torch.from_numpy(mel).to(dev)
+        d_post = torch.empty((args.batch, ctx.n_out), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        ctx.set_timing(False)       # per-step kernel times come from the events below
+
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        state = {"i": -args.warmup}
+
+        def step():
+            i = state["i"]
+            if i >= 0:
+                ev[i][0].record(stream)
+            ctx.posteriors_device(d_mel.data_ptr(), args.batch, d_post.data_ptr(),
+                                  stream=stream.cuda_stream)
+            if i >= 0:
+                ev[i][1].record(stream)
+            state["i"] = i + 1
+
+        def sync():
+            torch.cuda.synchronize(dev)
+
+        elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=dev)
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        kernel_ms = ranks.max_float(kernel_ms, device=dev)
+        total_frames = args.batch * args.steps * max(1, ranks.world)
+        fps = total_frames / elapsed
+
+        line = None
+        if ranks.rank == 0:
+            achieved = args.batch * flops_frame / (kernel_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    with open(pmc) as f:
+                        traffic = json.load(f).get("bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line = {
+                "metric": "frames/sec (LCRC posterior path)", "value": round(fps, 1), "unit": "frames/s",
+                "n_gpus": max(1, ranks.world), "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%s, batch=%d frames per GPU per step (BASELINE configs[2]), "
+                                       "log-mel frames resident in HBM, posteriors left in HBM"
+                                       % (SYSTEM, args.batch),
+                           "weights": weights_desc, "kernel": ctx.kernel_name,
+                           "sharding": "one replica per GPU, utterances never exchanged (no collective)"},
+                "frames_per_s_per_gpu": round(fps / max(1, ranks.world), 1),
+                "xrt": round(100.0 / (fps / max(1, ranks.world)), 8),
+                "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                             "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
+                             "flop_per_frame": flops_frame},
+            }
+            if ranks.world == 1 and not args.no_cpu:
+                gpu_post = d_post.cpu().numpy()
+                line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds)
+        ctx.close()
+    ranks.finish()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

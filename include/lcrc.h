@@ -1,0 +1,131 @@
+/*
+ * lcrc.h -- C ABI of the MI355X LCRC posterior estimator (libphnrec_lcrc.so).
+ *
+ * This is the drop-in boundary for ONE path of PhnRec: the LCRC
+ * split-temporal-context posterior estimator, i.e. everything class Traps
+ * (traps.h:21-76) does for posteriors/system=LCRC, including its three
+ * NeuralNet forward passes (nn.h:48-56).  The reference has no FFI; the seam is
+ * the public interface of Traps as SpeechRec drives it (srec.cpp:605-624 set-up;
+ * srec.cpp:1041,1048,1053,1059 offline; srec.cpp:815,856,898 online).  Each
+ * entry point below names the reference call it replaces.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no C++/torch types.
+ * Every function returns LCRC_OK (0) or a negative LCRC_E_* code; the message
+ * is available from lcrc_last_error().  All frame matrices are row-major
+ * float32: mel is [n][nbanks] (log mel-bank energies AFTER sentence
+ * normalisation, exactly what SpeechRec hands to Traps), post is
+ * [n][lcrc_num_outputs()].  A context is bound to one GPU and one HIP stream;
+ * calls on one context must be serialised by the caller (as with Traps, which
+ * is not re-entrant); different contexts are independent.
+ *
+ * There is NO CPU fallback behind this interface: if no gfx950 device is
+ * usable, lcrc_create fails with LCRC_E_DEVICE.
+ */
+#ifndef PHNREC_LCRC_H
+#define PHNREC_LCRC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCRC_ABI_VERSION 1
+
+enum {
+    LCRC_OK        = 0,
+    LCRC_E_ARG     = -1,   /* bad argument (NULL, negative size, wrong geometry)        */
+    LCRC_E_IO      = -2,   /* a model file is missing / unreadable (NN_NOWEIGHTS, nn.h) */
+    LCRC_E_MODEL   = -3,   /* a model file is malformed or nets are inconsistent       */
+    LCRC_E_DEVICE  = -4,   /* no usable HIP device / kernel launch or copy failed      */
+    LCRC_E_NOMEM   = -5,
+    LCRC_E_UNSUPPORTED = -6 /* posteriors/system other than LCRC, trap_len != 31, ...    */
+};
+
+typedef struct lcrc_ctx lcrc_ctx;
+
+/* ---- life cycle ---------------------------------------------------------- */
+
+/* Replaces the setter block + Traps::Init(dir) (srec.cpp:605-624,
+ * traps.cpp:88-171): loads DIR/weights/band{0,1}.{nbin|weights},
+ * DIR/norms/band{0,1}.norms, DIR/windows/band{0,1}.window,
+ * DIR/weights/merger.*, DIR/norms/merger.norms (path macros config.h:31-39;
+ * .nbin preferred, ASCII parsed otherwise, nn.cpp:594-621), re-packs the
+ * weights into MFMA fragment order and uploads them to GPU `device_id`.
+ * trap_len must be 31 and add_c0 non-zero (the only LCRC geometry the shipped
+ * systems and traps.cpp:285-343 define).  Unlike Traps::Init it returns an
+ * error instead of exit(1). */
+int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
+                int add_c0, int device_id);
+
+void lcrc_destroy(lcrc_ctx *ctx);
+
+/* Message of the last failing call on `ctx`; with ctx == NULL, of the last
+ * failing lcrc_create on this thread.  Never NULL. */
+const char *lcrc_last_error(const lcrc_ctx *ctx);
+
+int lcrc_abi_version(void);
+
+/* ---- geometry (Traps getters, traps.h:66-68) ------------------------------- */
+int lcrc_num_outputs(const lcrc_ctx *ctx);   /* Traps::GetNumOuts            */
+int lcrc_num_banks(const lcrc_ctx *ctx);
+int lcrc_trap_shift(const lcrc_ctx *ctx);    /* Traps::GetTrapShift == 15    */
+int lcrc_device(const lcrc_ctx *ctx);
+/* dims of net `which` (0,1 band classifiers, 2 merger): NeuralNet::Get*Size */
+int lcrc_net_dims(const lcrc_ctx *ctx, int which, int *n_inp, int *n_hid, int *n_out);
+
+/* ---- whole-utterance form ---------------------------------------------------
+ * Replaces the prime / main / flush sequence of SpeechRec::ProcessOffline
+ * (srec.cpp:1035-1059): post[r] = F(mel[clamp(r-15 .. r+15, 0, n-1)]).
+ * Host buffers; synchronous (H2D, kernel, D2H).  n == 0 is a no-op. */
+int lcrc_posteriors(lcrc_ctx *ctx, const float *mel, int n, float *post);
+
+/* Many utterances in one launch: utterance u occupies rows [off[u], off[u+1])
+ * of mel and post (off has n_utts+1 non-decreasing entries, off[0] == 0);
+ * contexts never cross an utterance boundary.  Empty utterances are allowed. */
+int lcrc_posteriors_batch(lcrc_ctx *ctx, const float *mel, const int *off, int n_utts,
+                          float *post);
+
+/* Same, on DEVICE pointers and asynchronous on `hip_stream` (a hipStream_t; NULL
+ * = HIP's default stream, as everywhere in HIP).  d_off may be NULL when
+ * n_utts == 1 (one utterance of n_rows frames).  Nothing is copied or
+ * synchronised; the caller orders the launch against its own work through the
+ * stream it passes. */
+int lcrc_posteriors_device(lcrc_ctx *ctx, const float *d_mel, const int *d_off, int n_utts,
+                           int n_rows, float *d_post, void *hip_stream);
+
+/* Test/diagnostic variant of lcrc_posteriors that also returns the stage
+ * outputs the reference keeps in Traps::band_input / band_output /
+ * merger_input (traps.h:27-29).  Any of the probe pointers may be NULL.
+ * in0,in1 [n][nbanks*11] (un-normalised projections), p0,p1 [n][nOut],
+ * g [n][2*nOut] (log band posteriors, merger input before its normalisation). */
+int lcrc_posteriors_probe(lcrc_ctx *ctx, const float *mel, int n, float *post,
+                          float *in0, float *in1, float *p0, float *p1, float *g);
+
+/* ---- streaming form (Traps semantics) -----------------------------------------
+ * lcrc_reset == Traps::Reset (traps.cpp:174-177).
+ * lcrc_push  == Traps::CalcFeaturesBunched(mel, post, n, needed)
+ * (traps.cpp:518-535): the first frame after a reset floods the 31-frame
+ * history; when `needed`, post row i is the estimate for the window ENDING at
+ * pushed frame i (i.e. centred 15 frames earlier); when !needed only the
+ * history advances and `post` is not touched (may be NULL).
+ * lcrc_delay == Traps::GetDelay (frames pushed since reset minus one, capped
+ * at 9999, traps.cpp:199,215-217). */
+int lcrc_reset(lcrc_ctx *ctx);
+int lcrc_push(lcrc_ctx *ctx, const float *mel, int n, float *post, int needed);
+int lcrc_delay(const lcrc_ctx *ctx);
+
+/* ---- measurement -------------------------------------------------------------
+ * Device time of the most recent posterior kernel launch on this context, from
+ * HIP events recorded around it on the stream it ran on.  Blocks until that
+ * launch has finished. */
+int lcrc_last_kernel_ms(lcrc_ctx *ctx, float *ms);
+/* Enable/disable the event pair (default on; costs two hipEventRecord per launch) */
+int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
+/* Name of the kernel variant selected for this model ("cz_11_18_9", "generic", ...) */
+const char *lcrc_kernel_name(const lcrc_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""ctypes view of include/lcrc.h (libphnrec_lcrc.so) for tests and bench.py.
+
+This is plumbing, not a second implementation: every call goes through the C
+ABI into the HIP kernel.  If the library has not been built, or no GPU is
+usable, it raises -- there is no fallback of any kind.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
+
+# every symbol include/lcrc.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "lcrc_create", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version",
+    "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
+    "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
+    "lcrc_reset", "lcrc_push", "lcrc_delay",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_kernel_name",
+]
+
+LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class LcrcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lcrc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+_hip = None
+
+
+def _load_hip_runtime():
+    """libphnrec_lcrc.so carries no DT_NEEDED on libamdhip64 (see csrc/Makefile): a
+    process may hold only one HIP runtime, and next to PyTorch it must be torch's
+    bundled copy.  Import torch FIRST when it is installed (so a later `import torch`
+    in the same process finds its own runtime already in place), then promote that
+    runtime to the global symbol scope for our library to bind against."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    candidates = []
+    if os.environ.get("PHNREC_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+            candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        except Exception:
+            pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    last = None
+    for p in candidates:
+        if os.path.isabs(p) and not os.path.exists(p):
+            continue
+        try:
+            _hip = C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return _hip
+        except OSError as e:   # try the next one
+            last = e
+    raise OSError("no HIP runtime (libamdhip64) could be loaded: %s" % last)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C phnrec_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    _load_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lcrc_destroy.argtypes = [vp]
+    L.lcrc_destroy.restype = None
+    L.lcrc_last_error.argtypes = [vp]
+    L.lcrc_last_error.restype = C.c_char_p
+    L.lcrc_kernel_name.argtypes = [vp]
+    L.lcrc_kernel_name.restype = C.c_char_p
+    for name in ("lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_delay",
+                 "lcrc_reset"):
+        getattr(L, name).argtypes = [vp]
+    L.lcrc_net_dims.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 3
+    L.lcrc_posteriors.argtypes = [vp, _f32p, C.c_int, _f32p]
+    L.lcrc_posteriors_batch.argtypes = [vp, _f32p, _i32p, C.c_int, _f32p]
+    L.lcrc_posteriors_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lcrc_posteriors_probe.argtypes = [vp, _f32p, C.c_int, _f32p] + [vp] * 5
+    L.lcrc_push.argtypes = [vp, _f32p, C.c_int, vp, C.c_int]
+    L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.lcrc_set_timing.argtypes = [vp, C.c_int]
+    _lib = L
+    return L
+
+
+class Lcrc:
+    """One estimator context on one GPU (mirrors class Traps' public surface)."""
+
+    def __init__(self, model_dir, nbanks, device=0, trap_len=31, add_c0=True):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.lcrc_create(C.byref(self.h), os.fsencode(model_dir), nbanks, trap_len,
+                                int(add_c0), device)
+        if rc != 0:
+            self.h = None
+            raise LcrcError(rc, self.L.lcrc_last_error(None).decode())
+        self.nbanks = nbanks
+        self.n_out = self.L.lcrc_num_outputs(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lcrc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LcrcError(rc, self.L.lcrc_last_error(self.h).decode())
+
+    @property
+    def kernel_name(self):
+        return self.L.lcrc_kernel_name(self.h).decode()
+
+    def net_dims(self, which):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.L.lcrc_net_dims(self.h, which, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # -- whole-utterance form (ProcessOffline's prime/main/flush) --
+    def posteriors(self, mel):
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        post = np.empty((mel.shape[0], self.n_out), np.float32)
+        self._check(self.L.lcrc_posteriors(self.h, mel, mel.shape[0], post))
+        return post
+
+    def posteriors_batch(self, mel, off):
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        post = np.zeros((mel.shape[0], self.n_out), np.float32)
+        self._check(self.L.lcrc_posteriors_batch(self.h, mel, off, len(off) - 1, post))
+        return post
+
+    def posteriors_probe(self, mel):
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        n = mel.shape[0]
+        k, _, ob = self.net_dims(0)
+        out = {"post": np.empty((n, self.n_out), np.float32),
+               "in0": np.empty((n, k), np.float32), "in1": np.empty((n, k), np.float32),
+               "p0": np.empty((n, ob), np.float32), "p1": np.empty((n, ob), np.float32),
+               "g": np.empty((n, 2 * ob), np.float32)}
+        self._check(self.L.lcrc_posteriors_probe(
+            self.h, mel, n, out["post"], *[out[k_].ctypes.data for k_ in ("in0", "in1", "p0", "p1", "g")]))
+        return out
+
+    def posteriors_device(self, d_mel_ptr, n_rows, d_post_ptr, d_off_ptr=None, n_utts=1, stream=None):
+        """Raw device pointers (ints); asynchronous on `stream` (int handle or None)."""
+        self._check(self.L.lcrc_posteriors_device(self.h, d_mel_ptr, d_off_ptr, n_utts, n_rows,
+                                                  d_post_ptr, stream))
+
+    # -- streaming form (Traps::Reset / CalcFeaturesBunched / GetDelay) --
+    def reset(self):
+        self._check(self.L.lcrc_reset(self.h))
+
+    def push(self, mel, needed=True):
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        post = np.empty((mel.shape[0], self.n_out), np.float32) if needed else None
+        self._check(self.L.lcrc_push(self.h, mel, mel.shape[0],
+                                     post.ctypes.data if needed else None, int(needed)))
+        return post
+
+    def delay(self):
+        return self.L.lcrc_delay(self.h)
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(self.L.lcrc_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_timing(self, on):
+        self._check(self.L.lcrc_set_timing(self.h, int(on)))

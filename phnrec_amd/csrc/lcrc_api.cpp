@@ -1,0 +1,436 @@
+// lcrc_api.cpp -- the C ABI of include/lcrc.h over the fused HIP kernel.
+//
+// Host side of the drop-in boundary: loads a PhnRec model directory with the
+// reference's file formats (nnet_io.cpp), re-packs the three MLPs into MFMA
+// fragment order, owns the device buffers / stream / events, and mirrors the
+// two ways SpeechRec drives Traps: whole utterances (srec.cpp:1035-1059) and the
+// streaming CalcFeaturesBunched form (traps.cpp:518-535).
+// There is deliberately no CPU path in this file.
+#include "../../include/lcrc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lcrc_dev.h"
+#include "nnet_io.h"
+
+using namespace phnrec;
+
+struct lcrc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nbanks = 0;
+    HostNet host[3];
+    NetDev nets[3];
+    std::vector<void *> allocs;
+    float *d_win = nullptr, *d_costab = nullptr;
+    float normc = 0.f;
+    // staging for the host-pointer entry points (grown on demand)
+    float *d_mel = nullptr, *d_post = nullptr;
+    int *d_off = nullptr;
+    float *h_mel = nullptr, *h_post = nullptr;
+    int *h_off = nullptr;
+    size_t cap_rows = 0, cap_utts = 0;
+    float *d_dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_dbg = 0;
+    // streaming state: the 30 most recent frames (Traps::be_mat minus its newest slot)
+    std::vector<float> hist;
+    bool hist_init = false;
+    int delay = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = true, timed = false;
+    std::string err;
+    const char *variant = "none";
+    unsigned lds_bytes = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_err = "";
+
+int fail(lcrc_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(ctx, LCRC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+hipError_t dev_upload(lcrc_ctx *c, const std::vector<T> &h, const T **out)
+{
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, h.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    c->allocs.push_back(d);
+    e = hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    *out = static_cast<const T *>(d);
+    return e;
+}
+
+// Fragment order of v_mfma_f32_16x16x4_f32's A operand (lane l: row l&15, k-slot l>>4).
+//   w1p[(ht*nkq + kq)*64 + l][j] = W1[16ht + (l&15)][16kq + 4j + (l>>4)]
+//   w2p[(ht*n_ot + ot)*64 + l][r] = W2[16ot + (l&15)][16ht + 4(l>>4) + r]
+// Out-of-range rows/columns are zeros, which is what makes padded hidden units and
+// padded k-steps contribute nothing (the reference zero-fills its x4 pads the same
+// way, nn.cpp:239-243,276-280).
+int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
+{
+    d.n_inp = h.n_inp; d.n_hid = h.n_hid; d.n_out = h.n_out;
+    d.ksteps = (h.n_inp + 3) / 4;
+    d.nkq = (d.ksteps + 3) / 4;
+    d.nht = (h.n_hid + 15) / 16;
+    d.n_ot = (h.n_out + 15) / 16;
+    std::vector<float> w1p((size_t)d.nht * d.nkq * 256, 0.f), w2p((size_t)d.nht * d.n_ot * 256, 0.f);
+    for (int ht = 0; ht < d.nht; ht++)
+        for (int kq = 0; kq < d.nkq; kq++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 4; j++) {
+                    const int hh = 16 * ht + (l & 15), k = 16 * kq + 4 * j + (l >> 4);
+                    if (hh < h.n_hid && k < h.n_inp)
+                        w1p[(((size_t)ht * d.nkq + kq) * 64 + l) * 4 + j] = h.w1[(size_t)hh * h.n_inp + k];
+                }
+    for (int ht = 0; ht < d.nht; ht++)
+        for (int ot = 0; ot < d.n_ot; ot++)
+            for (int l = 0; l < 64; l++)
+                for (int r = 0; r < 4; r++) {
+                    const int o = 16 * ot + (l & 15), hh = 16 * ht + 4 * (l >> 4) + r;
+                    if (o < h.n_out && hh < h.n_hid)
+                        w2p[(((size_t)ht * d.n_ot + ot) * 64 + l) * 4 + r] = h.w2[(size_t)o * h.n_hid + hh];
+                }
+    std::vector<float> b1((size_t)d.nht * 16, 0.f), b2((size_t)d.n_ot * 16, 0.f);
+    std::vector<float> mean((size_t)d.nkq * 16, 0.f), dev((size_t)d.nkq * 16, 1.f);
+    memcpy(b1.data(), h.b1.data(), sizeof(float) * h.n_hid);
+    memcpy(b2.data(), h.b2.data(), sizeof(float) * h.n_out);
+    memcpy(mean.data(), h.mean.data(), sizeof(float) * h.n_inp);
+    memcpy(dev.data(), h.dev.data(), sizeof(float) * h.n_inp);
+    const float *p = nullptr;
+    HIP_TRY(c, dev_upload(c, w1p, &p)); d.w1p = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, w2p, &p)); d.w2p = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, b1, &d.b1));
+    HIP_TRY(c, dev_upload(c, b2, &d.b2));
+    HIP_TRY(c, dev_upload(c, mean, &d.mean));
+    HIP_TRY(c, dev_upload(c, dev, &d.dev));
+    return LCRC_OK;
+}
+
+int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
+{
+    if (rows > c->cap_rows) {
+        size_t cap = rows + rows / 4 + 64;
+        if (c->d_mel) { (void)hipFree(c->d_mel); (void)hipFree(c->d_post); (void)hipHostFree(c->h_mel); (void)hipHostFree(c->h_post); }
+        c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
+        c->cap_rows = 0;
+        const size_t O = c->nets[2].n_out;
+        HIP_TRY(c, hipMalloc((void **)&c->d_mel, cap * c->nbanks * sizeof(float)));
+        HIP_TRY(c, hipMalloc((void **)&c->d_post, cap * O * sizeof(float)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_post, cap * O * sizeof(float), hipHostMallocDefault));
+        c->cap_rows = cap;
+    }
+    if (utts + 1 > c->cap_utts) {
+        size_t cap = utts + utts / 4 + 64;
+        if (c->d_off) { (void)hipFree(c->d_off); (void)hipHostFree(c->h_off); }
+        c->d_off = c->h_off = nullptr;
+        c->cap_utts = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_off, cap * sizeof(int)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_off, cap * sizeof(int), hipHostMallocDefault));
+        c->cap_utts = cap;
+    }
+    return LCRC_OK;
+}
+
+int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
+           hipStream_t s, float *const *dbg)
+{
+    LcrcParams p;
+    memset(&p, 0, sizeof p);
+    for (int i = 0; i < 3; i++) p.net[i] = c->nets[i];
+    p.mel = d_mel; p.off = d_off; p.post = d_post;
+    p.win = c->d_win; p.costab = c->d_costab; p.normc = c->normc;
+    p.n_utts = n_utts; p.n_rows = n_rows; p.nbanks = c->nbanks;
+    if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
+    HIP_TRY(c, lcrc_launch(p, s, nullptr));
+    if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
+    return LCRC_OK;
+}
+
+int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, float *post,
+             float *const *probes)
+{
+    const size_t nb = c->nbanks, O = c->nets[2].n_out;
+    int rc = ensure_staging(c, n, n_utts);
+    if (rc) return rc;
+    memcpy(c->h_mel, mel, (size_t)n * nb * sizeof(float));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const int *d_off = nullptr;
+    if (off) {
+        memcpy(c->h_off, off, (size_t)(n_utts + 1) * sizeof(int));
+        HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        d_off = c->d_off;
+    }
+    float *dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t K = c->nets[0].n_inp, Ob = c->nets[0].n_out;
+    const size_t widths[5] = {K, K, Ob, Ob, 2 * Ob};
+    bool any = false;
+    if (probes) {
+        for (int i = 0; i < 5; i++) any = any || probes[i];
+        if (any) {
+            if ((size_t)n > c->cap_dbg) {
+                for (int i = 0; i < 5; i++) { if (c->d_dbg[i]) (void)hipFree(c->d_dbg[i]); c->d_dbg[i] = nullptr; }
+                c->cap_dbg = 0;
+                for (int i = 0; i < 5; i++) HIP_TRY(c, hipMalloc((void **)&c->d_dbg[i], (size_t)n * widths[i] * sizeof(float)));
+                c->cap_dbg = n;
+            }
+            for (int i = 0; i < 5; i++) dbg[i] = probes[i] ? c->d_dbg[i] : nullptr;
+        }
+    }
+    rc = launch(c, c->d_mel, d_off, off ? n_utts : 1, n, c->d_post, c->stream, any ? dbg : nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
+    if (any)
+        for (int i = 0; i < 5; i++)
+            if (probes[i]) HIP_TRY(c, hipMemcpy(probes[i], c->d_dbg[i], (size_t)n * widths[i] * sizeof(float), hipMemcpyDeviceToHost));
+    return LCRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lcrc_abi_version(void) { return LCRC_ABI_VERSION; }
+
+const char *lcrc_last_error(const lcrc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len, int add_c0, int device_id)
+{
+    if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");
+    *out = nullptr;
+    if (nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_create: nbanks must be positive");
+    if (trap_len != kTrapLen || !add_c0)
+        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: only posteriors/system=LCRC with length=31, add_c0=true is implemented");
+
+    // -- files first, so that a bad model directory is reported even without a GPU
+    HostNet nets[3];
+    std::vector<float> win[2];
+    const std::string dir(model_dir);
+    const char *names[3] = {"band0", "band1", "merger"};
+    for (int i = 0; i < 3; i++) {
+        const std::string w = dir + "/weights/" + names[i] + ".weights";
+        const std::string n = dir + "/norms/" + names[i] + ".norms";
+        NetStatus s = load_net(w, n, nets[i]);
+        if (s != NET_OK)   // the reference prints this and exit(1)s, traps.cpp:141-145,162-166
+            return fail(nullptr, s == NET_NOWEIGHTS || s == NET_NONORMS ? LCRC_E_IO : LCRC_E_MODEL,
+                        "ERROR: Loading neural network: weights " + w + ", norms " + n + " (" + net_status_str(s) + ")");
+    }
+    for (int i = 0; i < 2; i++) {
+        const std::string w = dir + "/windows/band" + std::to_string(i) + ".window";
+        if (!load_window(w, kHalf, win[i]))
+            return fail(nullptr, LCRC_E_IO, "ERROR: Unable load window: " + w);
+    }
+    if (nets[0].n_inp != nbanks * kNCoef || nets[1].n_inp != nbanks * kNCoef)
+        return fail(nullptr, LCRC_E_MODEL, "band classifier input size " + std::to_string(nets[0].n_inp) +
+                    " != nbanks*11 = " + std::to_string(nbanks * kNCoef));
+    if (nets[0].n_out + nets[1].n_out != nets[2].n_inp)
+        return fail(nullptr, LCRC_E_MODEL, "merger input size does not equal the two band classifiers' outputs");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+
+    lcrc_ctx *c = new lcrc_ctx;
+    c->device = device_id;
+    c->nbanks = nbanks;
+    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        c->err = "cannot create HIP stream/events";
+        return bail(LCRC_E_DEVICE);
+    }
+    for (int i = 0; i < 3; i++) {
+        c->host[i] = nets[i];
+        int rc = pack_net(c, nets[i], c->nets[i]);
+        if (rc) return bail(rc);
+    }
+    // DCT basis exactly as sDCT evaluates it (dspc.h:206-221), in f32 with libm cosf
+    std::vector<float> cosv(10 * 16), winv(32);
+    const float pibyn = (float)M_PI / (float)kHalf;
+    for (int k = 0; k < 10; k++) {
+        const float v = pibyn * (float)(k + 1);
+        for (int j = 0; j < kHalf; j++) cosv[k * 16 + j] = cosf(v * ((float)j + 0.5f));
+    }
+    c->normc = sqrtf(2.0f / (float)kHalf);
+    for (int i = 0; i < 2; i++) memcpy(&winv[i * 16], win[i].data(), 16 * sizeof(float));
+    const float *p = nullptr;
+    if (dev_upload(c, cosv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_costab = const_cast<float *>(p);
+    if (dev_upload(c, winv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_win = const_cast<float *>(p);
+    const char *v = lcrc_variant_for(c->nets, nbanks, &c->lds_bytes);
+    if (!v) {
+        c->err = "model geometry not supported by the fused kernel (needs <= 23 banks, <= 208 outputs, LDS " +
+                 std::to_string(c->lds_bytes) + " B <= 160 KiB)";
+        return bail(LCRC_E_UNSUPPORTED);
+    }
+    c->variant = v;
+    c->hist.assign((size_t)(kTrapLen - 1) * nbanks, 0.f);
+    *out = c;
+    return LCRC_OK;
+}
+
+void lcrc_destroy(lcrc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->d_mel) (void)hipFree(c->d_mel);
+    if (c->d_post) (void)hipFree(c->d_post);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->h_mel) (void)hipHostFree(c->h_mel);
+    if (c->h_post) (void)hipHostFree(c->h_post);
+    if (c->h_off) (void)hipHostFree(c->h_off);
+    for (float *p : c->d_dbg) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lcrc_num_outputs(const lcrc_ctx *c) { return c ? c->nets[2].n_out : LCRC_E_ARG; }
+int lcrc_num_banks(const lcrc_ctx *c) { return c ? c->nbanks : LCRC_E_ARG; }
+int lcrc_trap_shift(const lcrc_ctx *c) { return c ? kShift : LCRC_E_ARG; }
+int lcrc_device(const lcrc_ctx *c) { return c ? c->device : LCRC_E_ARG; }
+const char *lcrc_kernel_name(const lcrc_ctx *c) { return c ? c->variant : "none"; }
+
+int lcrc_net_dims(const lcrc_ctx *c, int which, int *n_inp, int *n_hid, int *n_out)
+{
+    if (!c || which < 0 || which > 2) return LCRC_E_ARG;
+    if (n_inp) *n_inp = c->nets[which].n_inp;
+    if (n_hid) *n_hid = c->nets[which].n_hid;
+    if (n_out) *n_out = c->nets[which].n_out;
+    return LCRC_OK;
+}
+
+int lcrc_posteriors(lcrc_ctx *c, const float *mel, int n, float *post)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n < 0 || (n > 0 && (!mel || !post))) return fail(c, LCRC_E_ARG, "lcrc_posteriors: bad argument");
+    if (n == 0) return LCRC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_host(c, mel, nullptr, 1, n, post, nullptr);
+}
+
+int lcrc_posteriors_probe(lcrc_ctx *c, const float *mel, int n, float *post, float *in0, float *in1,
+                          float *p0, float *p1, float *g)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n < 0 || (n > 0 && (!mel || !post))) return fail(c, LCRC_E_ARG, "lcrc_posteriors_probe: bad argument");
+    if (n == 0) return LCRC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *probes[5] = {in0, in1, p0, p1, g};
+    return run_host(c, mel, nullptr, 1, n, post, probes);
+}
+
+int lcrc_posteriors_batch(lcrc_ctx *c, const float *mel, const int *off, int n_utts, float *post)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n_utts < 0 || (n_utts > 0 && !off)) return fail(c, LCRC_E_ARG, "lcrc_posteriors_batch: bad argument");
+    if (n_utts == 0) return LCRC_OK;
+    if (off[0] != 0) return fail(c, LCRC_E_ARG, "lcrc_posteriors_batch: off[0] must be 0");
+    for (int u = 0; u < n_utts; u++)
+        if (off[u + 1] < off[u]) return fail(c, LCRC_E_ARG, "lcrc_posteriors_batch: offsets must be non-decreasing");
+    const int n = off[n_utts];
+    if (n == 0) return LCRC_OK;
+    if (!mel || !post) return fail(c, LCRC_E_ARG, "lcrc_posteriors_batch: NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_host(c, mel, off, n_utts, n, post, nullptr);
+}
+
+int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows,
+                           float *d_post, void *hip_stream)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n_rows < 0 || n_utts < 1 || (n_rows > 0 && (!d_mel || !d_post)) || (n_utts > 1 && !d_off))
+        return fail(c, LCRC_E_ARG, "lcrc_posteriors_device: bad argument");
+    if (n_rows == 0) return LCRC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's default stream
+    return launch(c, d_mel, d_off, n_utts, n_rows, d_post, s, nullptr);
+}
+
+int lcrc_reset(lcrc_ctx *c)
+{
+    if (!c) return LCRC_E_ARG;
+    c->hist_init = false;
+    return LCRC_OK;
+}
+
+int lcrc_delay(const lcrc_ctx *c) { return c ? c->delay : LCRC_E_ARG; }
+
+// Traps::CalcFeaturesBunched.  The reference slides a 31-slot window one frame at a
+// time (traps.cpp:180-219) and evaluates the nets on what the window holds after
+// each push.  Here the 30 frames of history are put in front of the pushed
+// frames and the whole-utterance kernel is run on that strip: row 15+i of the
+// strip has the window [i, i+30], i.e. exactly the ring contents after push i.
+int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n < 0 || (n > 0 && !mel) || (n > 0 && needed && !post)) return fail(c, LCRC_E_ARG, "lcrc_push: bad argument");
+    if (n == 0) return LCRC_OK;
+    const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
+    if (!c->hist_init) {                     // first frame floods the history (traps.cpp:184-200)
+        for (size_t i = 0; i < H; i++) memcpy(&c->hist[i * nb], mel, nb * sizeof(float));
+    }
+    std::vector<float> strip((H + n) * nb);
+    memcpy(strip.data(), c->hist.data(), H * nb * sizeof(float));
+    memcpy(strip.data() + H * nb, mel, (size_t)n * nb * sizeof(float));
+    if (needed) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        std::vector<float> out((H + n) * O);
+        int rc = run_host(c, strip.data(), nullptr, 1, (int)(H + n), out.data(), nullptr);
+        if (rc) return rc;
+        memcpy(post, out.data() + (size_t)kShift * O, (size_t)n * O * sizeof(float));
+    }
+    memcpy(c->hist.data(), strip.data() + (size_t)n * nb, H * nb * sizeof(float));
+    if (!c->hist_init) { c->hist_init = true; c->delay = n - 1; }
+    else c->delay += n;
+    if (c->delay > 9999) c->delay = 9999;
+    return LCRC_OK;
+}
+
+int lcrc_set_timing(lcrc_ctx *c, int enabled)
+{
+    if (!c) return LCRC_E_ARG;
+    c->timing = enabled != 0;
+    return LCRC_OK;
+}
+
+int lcrc_last_kernel_ms(lcrc_ctx *c, float *ms)
+{
+    if (!c || !ms) return LCRC_E_ARG;
+    if (!c->timed) return fail(c, LCRC_E_ARG, "lcrc_last_kernel_ms: no timed launch yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return LCRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// lcrc_dev.h -- device-side parameter blocks shared by the packer, the launcher
+// and the kernels of the fused LCRC posterior kernel.
+#ifndef PHNREC_LCRC_DEV_H
+#define PHNREC_LCRC_DEV_H
+
+#include <hip/hip_runtime.h>
+
+namespace phnrec {
+
+constexpr int kBM = 32;        // frames per workgroup (two 16-frame MFMA column tiles)
+constexpr int kTrapLen = 31;   // posteriors/length
+constexpr int kHalf = 16;      // taps per half context
+constexpr int kShift = 15;     // Traps::GetTrapShift
+constexpr int kNCoef = 11;     // C0 + 10 DCT coefficients
+constexpr int kTileRows = kBM + 2 * kShift;   // mel rows staged per workgroup (62)
+
+// One MLP in MFMA fragment order (see lcrc_pack.cpp for the element maps).
+struct NetDev {
+    const float4 *w1p;   // [nht][nkq][64]  A fragments of layer 1 (4 k-steps per float4)
+    const float4 *w2p;   // [nht][not][64]  A fragments of layer 2 (4 hidden units per float4)
+    const float *b1;     // [nht*16]  zero padded
+    const float *b2;     // [not*16]  zero padded
+    const float *mean;   // [nkq*16]  pad 0
+    const float *dev;    // [nkq*16]  pad 1
+    int n_inp, n_hid, n_out;
+    int ksteps;          // ceil(n_inp / 4)   MFMA k-steps of layer 1
+    int nkq;             // ceil(ksteps / 4)  float4 groups of k-steps
+    int nht;             // ceil(n_hid / 16)  hidden tiles
+    int n_ot;            // ceil(n_out / 16)  output tiles
+};
+
+struct LcrcParams {
+    NetDev net[3];       // band0 (left context), band1 (right context), merger
+    const float *mel;    // [n_rows][nbanks]
+    const int *off;      // [n_utts + 1] utterance row offsets
+    float *post;         // [n_rows][n_out]
+    const float *win;    // [2][16] half-context windows
+    const float *costab; // [10][16] cosf(v_k * (j + 0.5f)) exactly as sDCT evaluates it
+    float normc;         // sqrtf(2/16)
+    int n_utts, n_rows, nbanks;
+    int n_ot_slab;       // max n_ot over the three nets (set by lcrc_launch)
+    // optional stage outputs (NULL in production)
+    float *dbg_in0, *dbg_in1, *dbg_p0, *dbg_p1, *dbg_g;
+};
+
+// LDS carve-up (bytes), computed identically on host and device.
+struct LdsPlan {
+    unsigned mel, rowinfo, tabs, xf, gf, slab, total;
+};
+
+__host__ __device__ inline unsigned lcrc_round16(unsigned v) { return (v + 15u) & ~15u; }
+
+__host__ __device__ inline LdsPlan lcrc_lds_plan(int nbanks, int nkq_band, int nkq_merger, int n_ot)
+{
+    LdsPlan p;
+    unsigned o = 0;
+    p.mel = o;      o += lcrc_round16((unsigned)kTileRows * nbanks * 4u);
+    p.rowinfo = o;  o += 2u * kBM * 4u;
+    p.tabs = o;     o += (10u * 16u + 2u * 16u) * 4u;
+    p.xf = o;       o += 2u * 2u * nkq_band * 1024u;     // [net][f][kq][64] float4
+    p.gf = o;       o += 2u * nkq_merger * 1024u;        // [f][kq][64] float4
+    p.slab = o;     o += 2u * (2u * n_ot * 1024u);       // two slabs of [ot][f][64] float4
+    p.total = o;
+    return p;
+}
+
+inline int lcrc_n_ot_slab(const NetDev *nets)
+{
+    int m = nets[0].n_ot;
+    if (nets[1].n_ot > m) m = nets[1].n_ot;
+    if (nets[2].n_ot > m) m = nets[2].n_ot;
+    return m;
+}
+
+// launcher (lcrc_kernels.hip)
+hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);
+// variant that WOULD be selected for these nets (no launch); NULL if unsupported
+const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes);
+
+}  // namespace phnrec
+#endif

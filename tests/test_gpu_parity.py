@@ -1,0 +1,191 @@
+"""HIP path (through the C ABI) vs the oracle and vs the reference's goldens.
+
+Bar (BASELINE.json north_star): posteriors within 1e-4 max-abs per frame of the
+reference CPU path.  TOL below is that bar; the measured differences are about
+1e-6 (summation order of the f32 products).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from phnrec_amd import modelgen
+from tests.util import GOLD, model_dir, read_htk
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # max-abs per frame, north_star
+TOL_STAGE = 2e-5    # per-stage probes (tighter: each stage is compared at its own scale)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from phnrec_amd import capi
+    capi.load()
+    return capi
+
+
+def _norm_mel(ob, system):
+    mel = read_htk(os.path.join(GOLD, system, "test.mel"))
+    if modelgen.SYSTEMS[system]["sent_mean_norm"]:
+        mel = ob.sentence_mean_norm(mel)
+    return mel
+
+
+@pytest.mark.parametrize("system", ["PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"])
+def test_real_system_vs_reference_golden(capi, oracle_mod, system):
+    """bundled test.raw: GPU posteriors vs the reference CLI's own -t post dump"""
+    spec = modelgen.SYSTEMS[system]
+    mel = _norm_mel(oracle_mod, system)
+    lop = read_htk(os.path.join(GOLD, system, "test.lop"))
+    g = capi.Lcrc(model_dir(system), spec["nbanks"])
+    assert g.n_out == spec["n_out"]
+    assert g.kernel_name.startswith(("cz_", "en_"))
+    post = g.posteriors(mel)
+    err = np.abs(post - lop).max(axis=1)
+    assert err.max() < TOL, err.max()
+    assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
+    assert np.array_equal(post.argmax(axis=1), lop.argmax(axis=1)) or \
+        (post.argmax(axis=1) != lop.argmax(axis=1)).mean() < 0.005
+
+
+@pytest.mark.parametrize("system", ["PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"])
+def test_stage_probes_vs_reference(capi, oracle_mod, system):
+    """each fused stage against the reference's own intermediates (Traps members)"""
+    spec = modelgen.SYSTEMS[system]
+    mel = _norm_mel(oracle_mod, system)
+    g = capi.Lcrc(model_dir(system), spec["nbanks"])
+    pr = g.posteriors_probe(mel)
+    gold = np.load(os.path.join(GOLD, system, "probe.npz"))
+    rows = gold["rows"]
+    for key in ("in0", "in1", "p0", "p1"):
+        err = np.abs(pr[key][rows] - gold[key]).max()
+        scale = max(1.0, np.abs(gold[key]).max())
+        assert err < TOL_STAGE * scale, (key, err)
+    # ln() of tiny posteriors amplifies relative error: compare where p > 1e-30
+    err = np.abs(pr["g"][rows] - gold["g"])
+    assert err.max() < 1e-3, err.max()
+
+
+def test_synthetic_goldens_all_shapes(capi, tmp_path):
+    """reference outputs on seeded synthetic models: every shipped shape, the generic
+    kernel on odd shapes, and utterances of 1..40 frames (edge replication)"""
+    g = np.load(os.path.join(GOLD, "synth.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    seen = set()
+    for name in names:
+        nb, hid, nout, seed = [int(v) for v in g[name + "/dims"]]
+        d = tmp_path / name
+        nets = modelgen.write_model_dir(str(d), nb, hid, nout, seed=seed)
+        assert bytes(g[name + "/digest"]).hex() == modelgen.nets_digest(nets)
+        ctx = capi.Lcrc(str(d), nb)
+        seen.add(ctx.kernel_name)
+        off = g[name + "/off"]
+        mel, want = g[name + "/mel"], g[name + "/post"]
+        got = ctx.posteriors_batch(mel, off)
+        assert np.abs(got - want).max() < TOL, (name, np.abs(got - want).max())
+        # utterance by utterance through the single-utterance entry point
+        for i in range(len(off) - 1):
+            a, b = int(off[i]), int(off[i + 1])
+            one = ctx.posteriors(mel[a:b])
+            assert np.abs(one - want[a:b]).max() < TOL, (name, i)
+            assert np.array_equal(one, got[a:b]), "batched and single launches must agree bit for bit"
+        ctx.close()
+    assert {"generic", "cz_42_69_9", "hu_42_93_12", "ru_42_80_10", "en_64_60_8"} <= seen, seen
+
+
+def test_vs_oracle_random_batches(capi, oracle_mod, tmp_path):
+    """seeded ragged batches incl. empty utterances, tile-straddling boundaries"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 200, 45, seed=21)
+    o = oracle_mod.Oracle(d, 15)
+    ctx = capi.Lcrc(d, 15)
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        lens = [int(v) for v in rng.integers(0, 70, size=9)]
+        lens[rng.integers(0, 9)] = 0
+        lens[rng.integers(0, 9)] = 1
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), 15, seed=100 + trial, mean_norm=False)
+        want = o.posteriors_batch(mel, off)
+        got = ctx.posteriors_batch(mel, off)
+        assert np.abs(got - want).max() < TOL
+
+
+def test_streaming_push_matches_traps_semantics(capi, oracle_mod, tmp_path):
+    """lcrc_reset/lcrc_push/lcrc_delay == Traps::Reset/CalcFeaturesBunched/GetDelay"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 64, 24, seed=3)
+    o = oracle_mod.Oracle(d, 15)
+    ctx = capi.Lcrc(d, 15)
+    mel = modelgen.synth_mel(90, 15, seed=8)
+    # the ProcessOffline sequence (srec.cpp:1035-1059) through the streaming entry points
+    ctx.reset()
+    assert ctx.push(mel[:15], needed=False) is None
+    assert ctx.delay() == 14
+    main = ctx.push(mel[15:])
+    tail = ctx.push(np.repeat(mel[-1:], 15, axis=0))
+    got = np.concatenate([main, tail])
+    want = o.posteriors(mel)
+    assert np.abs(got - want).max() < TOL
+    # arbitrary chunking gives the same frames as the oracle's ring buffer
+    ctx.reset()
+    o.reset()
+    pos = 0
+    for n in (1, 4, 5, 7, 30, 2):
+        a = ctx.push(mel[pos:pos + n])
+        b = o.push(mel[pos:pos + n], needed=True)
+        assert np.abs(a - b).max() < TOL
+        pos += n
+        assert ctx.delay() == o.delay()
+
+
+def test_extreme_inputs_saturate_like_the_reference(capi, oracle_mod, tmp_path):
+    """large-magnitude features drive sigmoids/softmax into FEXP's tails"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 128, 33, seed=4)
+    o = oracle_mod.Oracle(d, 15)
+    ctx = capi.Lcrc(d, 15)
+    mel = modelgen.synth_mel(64, 15, seed=9) * np.float32(25.0)
+    mel[10] = 300.0
+    mel[11] = -300.0
+    want = o.posteriors(mel)
+    got = ctx.posteriors(mel)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() < TOL
+
+
+def test_api_errors(capi, tmp_path):
+    with pytest.raises(capi.LcrcError) as e:
+        capi.Lcrc(str(tmp_path / "nope"), 15)
+    assert e.value.code == capi.LCRC_E_IO and "Loading neural network" in str(e.value)
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 32, 12, seed=1)
+    with pytest.raises(capi.LcrcError) as e:
+        capi.Lcrc(d, 23)                     # wrong nbanks for these nets
+    assert e.value.code == capi.LCRC_E_MODEL
+    with pytest.raises(capi.LcrcError) as e:
+        capi.Lcrc(d, 15, trap_len=21)
+    assert e.value.code == capi.LCRC_E_UNSUPPORTED
+    ctx = capi.Lcrc(d, 15)
+    assert ctx.posteriors(np.zeros((0, 15), np.float32)).shape == (0, 12)
+    with pytest.raises(capi.LcrcError):
+        ctx.posteriors_batch(np.zeros((4, 15), np.float32), np.array([0, 3, 2, 4], np.int32))
+
+
+def test_device_pointer_entry_and_determinism(capi, tmp_path):
+    import torch
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 96, 30, seed=2)
+    ctx = capi.Lcrc(d, 15)
+    mel = modelgen.synth_mel(1000, 15, seed=1)
+    host = ctx.posteriors(mel)
+    t_mel = torch.from_numpy(mel).cuda()
+    t_post = torch.empty((1000, 30), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream()
+    ctx.posteriors_device(t_mel.data_ptr(), 1000, t_post.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(t_post.cpu().numpy(), host)
+    assert ctx.last_kernel_ms() > 0
+    again = ctx.posteriors(mel)
+    assert np.array_equal(again, host), "the kernel must be run-to-run deterministic"
