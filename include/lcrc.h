@@ -66,6 +66,13 @@ const char *lcrc_last_error(const lcrc_ctx *ctx);
 
 int lcrc_abi_version(void);
 
+/* Host-only pre-flight (no GPU touched): loads and validates the model directory
+ * exactly as lcrc_create does and reports the three nets' dims
+ * (dims9 = {inp,hid,out} x {band0, band1, merger}), the kernel variant that
+ * would run and its LDS footprint.  Any out pointer may be NULL. */
+int lcrc_model_info(const char *model_dir, int nbanks, int *dims9, char *kernel,
+                    size_t kernel_cap, unsigned *lds_bytes);
+
 /* ---- geometry (Traps getters, traps.h:66-68) ------------------------------- */
 int lcrc_num_outputs(const lcrc_ctx *ctx);   /* Traps::GetNumOuts            */
 int lcrc_num_banks(const lcrc_ctx *ctx);

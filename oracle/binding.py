@@ -240,6 +240,12 @@ def _ref(blas):
         p = ref_lib_path(blas)
         if p is None:
             raise FileNotFoundError("oracle/_ref not built (needs /root/reference at build time)")
+        if blas:
+            # libmkl_rt picks its threading layer at first use; next to PyTorch's OpenMP
+            # runtime the default (Intel OpenMP) layer returns NaNs.  The reference is a
+            # single-threaded program, so sequential MKL is also the faithful baseline.
+            os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
+            os.environ.setdefault("MKL_NUM_THREADS", "1")
         L = C.CDLL(p)
         L.refshim_traps_create.restype = C.c_void_p
         L.refshim_traps_create.argtypes = [C.c_char_p, C.c_int, C.c_int]

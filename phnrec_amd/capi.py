@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 
 # every symbol include/lcrc.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "lcrc_create", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version",
+    "lcrc_create", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
@@ -94,10 +94,26 @@ def load():
     L.lcrc_posteriors_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.lcrc_posteriors_probe.argtypes = [vp, _f32p, C.c_int, _f32p] + [vp] * 5
     L.lcrc_push.argtypes = [vp, _f32p, C.c_int, vp, C.c_int]
+    L.lcrc_model_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t,
+                                  C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.lcrc_set_timing.argtypes = [vp, C.c_int]
     _lib = L
     return L
+
+
+def model_info(model_dir, nbanks):
+    """Host-only pre-flight: dims of the three nets, kernel variant, LDS bytes (no GPU needed)."""
+    L = load()
+    dims = (C.c_int * 9)()
+    name = C.create_string_buffer(64)
+    lds = C.c_uint()
+    rc = L.lcrc_model_info(os.fsencode(model_dir), nbanks, dims, name, 64, C.byref(lds))
+    if rc != 0:
+        raise LcrcError(rc, L.lcrc_last_error(None).decode())
+    d = list(dims)
+    return {"dims": [tuple(d[0:3]), tuple(d[3:6]), tuple(d[6:9])], "kernel": name.value.decode(),
+            "lds_bytes": lds.value}
 
 
 class Lcrc:

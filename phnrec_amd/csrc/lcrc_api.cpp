@@ -208,25 +208,9 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
     return LCRC_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int lcrc_abi_version(void) { return LCRC_ABI_VERSION; }
-
-const char *lcrc_last_error(const lcrc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
-
-int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len, int add_c0, int device_id)
+// Files + consistency checks shared by lcrc_create and lcrc_model_info (no GPU needed).
+int load_model(const char *model_dir, int nbanks, HostNet *nets, std::vector<float> *win)
 {
-    if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");
-    *out = nullptr;
-    if (nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_create: nbanks must be positive");
-    if (trap_len != kTrapLen || !add_c0)
-        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: only posteriors/system=LCRC with length=31, add_c0=true is implemented");
-
-    // -- files first, so that a bad model directory is reported even without a GPU
-    HostNet nets[3];
-    std::vector<float> win[2];
     const std::string dir(model_dir);
     const char *names[3] = {"band0", "band1", "merger"};
     for (int i = 0; i < 3; i++) {
@@ -247,6 +231,63 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
                     " != nbanks*11 = " + std::to_string(nbanks * kNCoef));
     if (nets[0].n_out + nets[1].n_out != nets[2].n_inp)
         return fail(nullptr, LCRC_E_MODEL, "merger input size does not equal the two band classifiers' outputs");
+    return LCRC_OK;
+}
+
+void shape_of(const HostNet &h, NetDev &d)
+{
+    memset(&d, 0, sizeof d);
+    d.n_inp = h.n_inp; d.n_hid = h.n_hid; d.n_out = h.n_out;
+    d.ksteps = (h.n_inp + 3) / 4;
+    d.nkq = (d.ksteps + 3) / 4;
+    d.nht = (h.n_hid + 15) / 16;
+    d.n_ot = (h.n_out + 15) / 16;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lcrc_abi_version(void) { return LCRC_ABI_VERSION; }
+
+int lcrc_model_info(const char *model_dir, int nbanks, int *dims9, char *kernel, size_t kernel_cap,
+                    unsigned *lds_bytes)
+{
+    if (!model_dir || nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_model_info: bad argument");
+    HostNet nets[3];
+    std::vector<float> win[2];
+    int rc = load_model(model_dir, nbanks, nets, win);
+    if (rc) return rc;
+    NetDev nd[3];
+    for (int i = 0; i < 3; i++) {
+        shape_of(nets[i], nd[i]);
+        if (dims9) { dims9[3 * i] = nets[i].n_inp; dims9[3 * i + 1] = nets[i].n_hid; dims9[3 * i + 2] = nets[i].n_out; }
+    }
+    unsigned lds = 0;
+    const char *v = lcrc_variant_for(nd, nbanks, &lds);
+    if (lds_bytes) *lds_bytes = lds;
+    if (kernel && kernel_cap) snprintf(kernel, kernel_cap, "%s", v ? v : "");
+    if (!v) return fail(nullptr, LCRC_E_UNSUPPORTED, "model geometry not supported by the fused kernel");
+    return LCRC_OK;
+}
+
+const char *lcrc_last_error(const lcrc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len, int add_c0, int device_id)
+{
+    if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");
+    *out = nullptr;
+    if (nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_create: nbanks must be positive");
+    if (trap_len != kTrapLen || !add_c0)
+        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: only posteriors/system=LCRC with length=31, add_c0=true is implemented");
+
+    // -- files first, so that a bad model directory is reported even without a GPU
+    HostNet nets[3];
+    std::vector<float> win[2];
+    {
+        int rc = load_model(model_dir, nbanks, nets, win);
+        if (rc) return rc;
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -209,8 +209,11 @@ NetStatus load_net(const std::string &weights, const std::string &norms, HostNet
     size_t dot = bin.rfind('.'), slash = bin.find_last_of("/\\");
     if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) bin.erase(dot);
     bin += ".nbin";
-    if (load_nbin(bin, net) == NET_OK) return NET_OK;
+    const NetStatus sb = load_nbin(bin, net);
+    if (sb == NET_OK) return NET_OK;
     NetStatus s = load_ascii(weights, norms, net);
+    // a .nbin that exists but is damaged, with no ASCII to fall back to: report the damage
+    if (s == NET_NOWEIGHTS && sb != NET_NOWEIGHTS) return sb == NET_WRITEERR ? NET_BADWEIGHTS : sb;
     if (s == NET_OK && write_cache) save_nbin(bin, net);   // failure ignored, as nn.cpp:613-618
     return s;
 }

@@ -1,0 +1,85 @@
+"""The one-process-per-GPU harness on CPU: gloo, world_size 2 (127.0.0.1 rendezvous)."""
+import os
+import socket
+import subprocess
+import sys
+
+from phnrec_amd import distrun
+from tests.util import ROOT
+
+WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, %r)
+from phnrec_amd import distrun
+r = distrun.Ranks(gpus=2).init("gloo")
+assert r.world == 2 and r.pg
+lengths = [300, 1500, 700, 20, 999, 1, 450, 1200, 640]
+owner = distrun.shard_by_frames(lengths, r.world)
+mine = [i for i, o in enumerate(owner) if o == r.rank]
+state = {"n": 0}
+def step():
+    time.sleep(0.01 * (1 + r.rank))       # rank 1 is slower: MAX over ranks must see it
+    state["n"] += sum(lengths[i] for i in mine)
+t = distrun.timed_steps(r, step, lambda: None, steps=5, warmup=1)
+total = r.sum_int(state["n"])
+print(json.dumps({"rank": r.rank, "t": t, "total": total, "mine": mine}))
+r.finish()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_timing_and_sharding(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e.decode()[-2000:]
+        outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+    assert outs[0]["t"] == outs[1]["t"], "every rank must report the MAX over ranks"
+    assert outs[0]["t"] >= 5 * 0.02 * 0.9, "the slower rank (20 ms/step) sets the time"
+    lengths = [300, 1500, 700, 20, 999, 1, 450, 1200, 640]
+    assert sorted(outs[0]["mine"] + outs[1]["mine"]) == list(range(9)), "every utterance owned exactly once"
+    assert outs[0]["total"] == outs[1]["total"] == 6 * sum(lengths)   # 1 warmup + 5 timed steps
+
+
+def test_shard_by_frames_balance_and_determinism():
+    import random
+    rnd = random.Random(3)
+    lengths = [rnd.randint(300, 1500) for _ in range(10000)]     # BASELINE configs[3] list
+    for world in (1, 2, 4, 8):
+        owner = distrun.shard_by_frames(lengths, world)
+        assert owner == distrun.shard_by_frames(lengths, world)
+        loads = [sum(l for l, o in zip(lengths, owner) if o == r) for r in range(world)]
+        assert max(loads) - min(loads) <= 1500, loads
+        assert sum(loads) == sum(lengths)
+    assert distrun.shard_by_frames([], 4) == []
+    assert set(distrun.shard_by_frames([5], 8)) == {0}
+
+
+def test_single_process_is_a_noop_world():
+    r = distrun.Ranks(gpus=1)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert r.world == env_world
+    if env_world == 1:
+        r.init("gloo")
+        assert not r.pg
+        assert r.max_float(1.5) == 1.5 and r.sum_int(7) == 7
+        r.barrier()
+        t = distrun.timed_steps(r, lambda: None, lambda: None, steps=3, warmup=1)
+        assert t >= 0
