@@ -45,6 +45,8 @@ struct lcrc_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = true, timed = false;
+    unsigned long long *d_stamps = nullptr;   // diagnostic build only
+    int dbg_flags = 0;
     std::string err;
     const char *variant = "none";
     unsigned lds_bytes = 0;
@@ -160,6 +162,8 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     p.mel = d_mel; p.off = d_off; p.post = d_post;
     p.win = c->d_win; p.costab = c->d_costab; p.normc = c->normc;
     p.n_utts = n_utts; p.n_rows = n_rows; p.nbanks = c->nbanks;
+    p.stamps = c->d_stamps;
+    p.dbg_flags = c->dbg_flags;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
     HIP_TRY(c, lcrc_launch(p, s, nullptr));
@@ -456,6 +460,22 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
     if (c->delay > 9999) c->delay = 9999;
     return LCRC_OK;
 }
+
+#ifdef LCRC_STAMPS
+// diagnostic build only (not declared in include/lcrc.h): phase stamps buffer, device pointer
+int lcrc_debug_set_stamps(lcrc_ctx *c, void *d_buf)
+{
+    if (!c) return LCRC_E_ARG;
+    c->d_stamps = static_cast<unsigned long long *>(d_buf);
+    return LCRC_OK;
+}
+int lcrc_debug_set_flags(lcrc_ctx *c, int flags)
+{
+    if (!c) return LCRC_E_ARG;
+    c->dbg_flags = flags;
+    return LCRC_OK;
+}
+#endif
 
 int lcrc_set_timing(lcrc_ctx *c, int enabled)
 {

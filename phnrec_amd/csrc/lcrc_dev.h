@@ -41,11 +41,14 @@ struct LcrcParams {
     int n_ot_slab;       // max n_ot over the three nets (set by lcrc_launch)
     // optional stage outputs (NULL in production)
     float *dbg_in0, *dbg_in1, *dbg_p0, *dbg_p1, *dbg_g;
+    // [grid][8 waves][16] s_memtime stamps; only written by the diagnostic build (-DLCRC_STAMPS)
+    unsigned long long *stamps;
+    int dbg_flags;       // diagnostic build only
 };
 
 // LDS carve-up (bytes), computed identically on host and device.
 struct LdsPlan {
-    unsigned mel, rowinfo, tabs, xf, gf, slab, total;
+    unsigned mel, rowinfo, tabs, norms, xf, gf, slab, total;
 };
 
 __host__ __device__ inline unsigned lcrc_round16(unsigned v) { return (v + 15u) & ~15u; }
@@ -57,6 +60,7 @@ __host__ __device__ inline LdsPlan lcrc_lds_plan(int nbanks, int nkq_band, int n
     p.mel = o;      o += lcrc_round16((unsigned)kTileRows * nbanks * 4u);
     p.rowinfo = o;  o += 2u * kBM * 4u;
     p.tabs = o;     o += (10u * 16u + 2u * 16u) * 4u;
+    p.norms = o;    o += (4u * 16u * nkq_band + 2u * 16u * nkq_merger) * 4u;   // mean|dev of the 3 nets
     p.xf = o;       o += 2u * 2u * nkq_band * 1024u;     // [net][f][kq][64] float4
     p.gf = o;       o += 2u * nkq_merger * 1024u;        // [f][kq][64] float4
     p.slab = o;     o += 2u * (2u * n_ot * 1024u);       // two slabs of [ot][f][64] float4

@@ -47,6 +47,21 @@ namespace phnrec {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// In-kernel phase stamps exist only in the DIAGNOSTIC build (make stamps ->
+// libphnrec_lcrc_stamps.so, tools/stamp_profile.py); in the product the macro is empty.
+#ifdef LCRC_STAMPS
+#define LCRC_STAMP(p, wave, lane, idx)                                                        \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        if ((p).stamps && (lane) == 0) (p).stamps[((size_t)blockIdx.x * 8 + (wave)) * 16 + (idx)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define LCRC_STAMP(p, wave, lane, idx) do { } while (0)
+#endif
+
 __device__ __forceinline__ f4 mfma16x16x4(float a, float b, f4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -55,13 +70,14 @@ __device__ __forceinline__ f4 mfma16x16x4(float a, float b, f4 c)
 // ---- FEXP (fexp.h:14-21) ----------------------------------------------------------
 // hi32 = (int)(2^20/ln2 * y) + (1072693248 - 60801); lo32 = 0; reinterpret as double.
 // (int) is x86 cvttsd2si: INT_MIN when the product is >= 2^31 or NaN.  v_cvt_i32_f64
-// saturates instead, so that one case is patched (y >= 2^11*ln2 = 1419.565...).
+// saturates instead, so that one case is patched; the test is made on y itself
+// (0x1.62e43p+10f = 1419.5654296875 is the smallest float whose product reaches 2^31;
+// !(y < T) is also true for NaN).  Below -2^31 both conversions give INT_MIN.
 __device__ __forceinline__ double fexp_d(float y)
 {
     const double a = 1048576.0 / 0.69314718055994530942;
-    double t = a * (double)y;
-    int i = __double2int_rz(t);
-    if (!(t < 2147483648.0)) i = INT_MIN;
+    int i = __double2int_rz(a * (double)y);
+    if (!(y < 0x1.62e43p+10f)) i = INT_MIN;
     unsigned hi = (unsigned)i + 1072632447u;
     return __hiloint2double((int)hi, 0);
 }
@@ -69,21 +85,211 @@ __device__ __forceinline__ double fexp_d(float y)
 __device__ __forceinline__ float fexp_f(float y) { return (float)fexp_d(y); }
 
 // fexp_sigmoid (fexp.h:33-38): the macro yields a double, so 1.0f + .. and 1.0f / ..
-// are double operations; one rounding to float.
+// are double operations; one rounding to float.  The quotient only has to be good
+// for a correct ROUNDING TO FLOAT, so the full IEEE f64 division sequence is replaced
+// by v_rcp_f64 + one Newton step (relative error ~2^-50, i.e. the float result differs
+// from the correctly rounded one with probability ~2^-26) + v_div_fixup_f64, which
+// restores 1/inf = 0 and 1/0 = inf for FEXP's out-of-range garbage.
 __device__ __forceinline__ float fexp_sigmoid(float x)
 {
-    return (float)(1.0 / (1.0 + fexp_d(-x)));
+    const double s = 1.0 + fexp_d(-x);
+    double r = __builtin_amdgcn_rcp(s);
+    const double e = __builtin_fma(-s, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    r = __builtin_amdgcn_div_fixup(r, s, 1.0);
+    return (float)r;
+}
+
+// Loads the first N (1..4) components of a weight fragment.  The last float4 group of
+// layer 1 is only partly used when ksteps % 4 != 0; loading all four components would
+// leave the unused ones as dead registers with a load in flight, and the first reuse
+// of such a register costs an s_waitcnt vmcnt(0) that drains the whole prefetch.
+template <int N>
+__device__ __forceinline__ f4 load_frag(const f4 *p)
+{
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (N >= 4) {
+        v = *p;
+    } else if constexpr (N == 3) {
+        typedef float f3 __attribute__((ext_vector_type(3)));
+        const f3 t = *reinterpret_cast<const f3 *>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2];
+    } else if constexpr (N == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 t = *reinterpret_cast<const f2 *>(p);
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        v[0] = *reinterpret_cast<const float *>(p);
+    }
+    return v;
 }
 
 // ---- one MLP on the workgroup's 32 frames ------------------------------------------
 // XF: LDS image of the normalised input, [f][kq][lane] float4 where element j of
 //     lane l holds X[frame 16f + (l&15)][k = 16kq + 4j + (l>>4)].
-// On return dense[frame][o] (row stride 16*n_ot floats, aliases slab 1) holds the
-// softmax output for all 32 frames; the caller must __syncthreads() before the
-// LDS regions are reused.
-template <int KS, int NOT, int NW, bool EXACT>
-__device__ __forceinline__ void run_net(const NetDev &nd, const f4 *__restrict__ XF,
-                                        f4 *__restrict__ slab, int n_ot_slab, int lane, int wave)
+//
+// Hidden-loop schedule per wave (one wave per SIMD, so nothing else hides latency):
+//
+//   prologue   W1(t0) -> layer 1 of tile t0 -> pre
+//   per tile t    issue W2(t)                                         | fence
+//       block A   sig(pre(t)) on the VALU  ||  layer 1 of tile t+1 on the MFMA pipe
+//                 issue W1(t+2), bias(t+2)                             | fence
+//       block B   layer 2 of tile t (72 MFMAs, operands all ready)
+//   last tile     sigmoid + layer 2 only
+//
+// i.e. the sigmoid of a tile never sits between two dependent MFMA phases: it runs in the
+// issue shadow of the NEXT tile's layer 1, and every weight fragment is requested one
+// whole phase before it is used.
+template <int KS, int NKQ, bool EXACT>
+__device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
+{
+    // `t` (tile base) stays in SGPRs (saddr addressing); only lane*16 is a vector offset
+    return (EXACT && kq == NKQ - 1) ? load_frag<KS - 4 * (NKQ - 1)>(t + kq * 64 + lane) : t[kq * 64 + lane];
+}
+
+template <int KS, int NKQ, bool EXACT>
+__device__ __forceinline__ void load_w1(f4 (&a)[NKQ], f4 &bias, const f4 *w1, const float *b1,
+                                        int h, int nkq, int lane)
+{
+    const f4 *t = w1 + (size_t)h * nkq * 64;
+#pragma unroll
+    for (int kq = 0; kq < NKQ; kq++)
+        if (EXACT || kq < nkq) a[kq] = load_w1_frag<KS, NKQ, EXACT>(t, kq, lane);
+    bias = *reinterpret_cast<const f4 *>(b1 + 16 * h + 4 * (lane >> 4));
+}
+
+// layer 1 of one hidden tile, bias first (nn.cpp:883-884):
+// p[f][r] = S^T[16ht + 4g + r][16f + (lane&15)]
+template <int KS, bool EXACT>
+__device__ __forceinline__ void gemm1_group(f4 &p0, f4 &p1, const f4 &akq, const f4 *__restrict__ XF,
+                                            int kq, int nkq, int ks, int lane)
+{
+    const f4 x0 = XF[kq * 64 + lane];
+    const f4 x1 = XF[(nkq + kq) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
+            p0 = mfma16x16x4(akq[j], x0[j], p0);
+            p1 = mfma16x16x4(akq[j], x1[j], p1);
+        }
+    }
+}
+
+template <int KS, int NKQ, bool EXACT>
+__device__ __forceinline__ void gemm1(f4 &p0, f4 &p1, const f4 (&a)[NKQ], const f4 *__restrict__ XF,
+                                      int nkq, int ks, int lane)
+{
+#pragma unroll
+    for (int kq = 0; kq < NKQ; kq++)
+        if (EXACT || kq < nkq) gemm1_group<KS, EXACT>(p0, p1, a[kq], XF, kq, nkq, ks, lane);
+}
+
+// Sigmoid (nn.cpp:796-820) of the 8 pre-activations a lane holds, as a sequence of
+// STAGES: stage k applies step k to all eight values, so the eight dependency chains
+// advance together and consecutive VALU instructions are independent.  The hidden loop
+// issues one stage behind each 8-MFMA group of the next tile's layer 1.
+//
+// Cost matters here: v_mfma_f32_16x16x4_f32 runs on the SIMD's f32 FMA lanes, so VALU
+// work does NOT hide behind it (measured, tools/ubench/valu_overlap.hip: every VALU
+// instruction adds its full issue time to the 32 cycles of an MFMA).  Hence:
+//   * FEXP's integer part stays exact (f64 product, truncation, x86 overflow value);
+//   * FEXP's value is exactly representable in f32 (20 mantissa bits), so one
+//     v_cvt_f32_f64 of {0, hi} yields it without error in the whole normal range;
+//   * 1/(1+e) is evaluated in f32: v_rcp_f32 + one Newton step + v_div_fixup_f32
+//     (1/inf = 0 etc.).  The reference evaluates it in f64 and rounds once; this form is
+//     within 2 ulp (2.4e-7 relative) of it, an order of magnitude below the effect of the
+//     products' summation order, and costs ~40 instead of ~90 issue cycles per value.
+// Pad hidden units (>= n_hid) need no zeroing: their layer-2 weights are packed as zeros.
+struct Sig8 {
+    float x[8];      // -x, then e, 1+e, and finally the sigmoid
+    double t[8];
+    float r[8];
+    static constexpr int kStages = 8;
+
+    __device__ __forceinline__ void begin(const f4 &p0, const f4 &p1)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { x[i] = -p0[i]; x[4 + i] = -p1[i]; }
+    }
+    __device__ __forceinline__ void stage(int k)
+    {
+        const double a = 1048576.0 / 0.69314718055994530942;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            switch (k) {
+            case 0: t[i] = a * (double)x[i]; break;
+            case 1: {                                   // FEXP's integer hi word (see fexp_d)
+                unsigned hi = (unsigned)__double2int_rz(t[i]) + 1072632447u;
+                if (!(x[i] < 0x1.62e43p+10f)) hi = 0x80000000u + 1072632447u;
+                t[i] = __hiloint2double((int)hi, 0);
+                break;
+            }
+            case 2: x[i] = 1.0f + (float)t[i]; break;
+            case 3: r[i] = __builtin_amdgcn_rcpf(x[i]); break;
+            case 4: { const float e = __builtin_fmaf(-x[i], r[i], 1.0f); r[i] = __builtin_fmaf(r[i], e, r[i]); break; }
+            case 5: x[i] = __builtin_amdgcn_div_fixupf(r[i], x[i], 1.0f); break;
+            default: break;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(f4 &s0, f4 &s1) const
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { s0[i] = x[i]; s1[i] = x[4 + i]; }
+    }
+};
+
+__device__ __forceinline__ void sigmoid8(f4 &s0, f4 &s1, const f4 &p0, const f4 &p1)
+{
+    Sig8 sg;
+    sg.begin(p0, p1);
+#pragma unroll
+    for (int k = 0; k < Sig8::kStages; k++) sg.stage(k);
+    sg.finish(s0, s1);
+}
+
+// layer 2: k-slot g of step r is hidden unit 16ht + 4g + r on both operands
+__device__ __forceinline__ void gemm2_group(f4 &acc0, f4 &acc1, const f4 &wot, const f4 &s0, const f4 &s1)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        acc0 = mfma16x16x4(wot[r], s0[r], acc0);
+        acc1 = mfma16x16x4(wot[r], s1[r], acc1);
+    }
+}
+
+template <int NOT, bool EXACT>
+__device__ __forceinline__ void gemm2(f4 (&acc)[NOT][2], const f4 (&w)[NOT], const f4 &s0, const f4 &s1,
+                                      int n_ot)
+{
+#pragma unroll
+    for (int ot = 0; ot < NOT; ot++)
+        if (EXACT || ot < n_ot) gemm2_group(acc[ot][0], acc[ot][1], w[ot], s0, s1);
+}
+
+// Compiler fences (no instruction).  hipcc otherwise SINKS read-only prefetch loads down
+// to their first use (IR level) or hoists the register-only MFMA/VALU work of the next
+// phase above them (machine scheduler); either way the prefetch becomes a just-in-time
+// load and an L2 round trip per fragment is exposed.
+#define LCRC_FENCE()                        \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+
+// Scatter one value of a net-input row into the MFMA B image.
+__device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, float v)
+{
+    const int f = frame >> 4, kq = k >> 4, j = (k >> 2) & 3, l = (frame & 15) + 16 * (k & 3);
+    img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
+}
+
+// Runs one net.  On return `epi(frame, o, posterior)` has been called once for every
+// (frame, output) of the tile by SOME thread, and a __syncthreads() has been passed.
+template <int KS, int NOT, int NW, bool EXACT, typename Epi>
+__device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const NetDev &nd,
+                                        const f4 *__restrict__ XF, f4 *__restrict__ slab,
+                                        int n_ot_slab, int lane, int wave, Epi epi)
 {
     constexpr int NKQ = (KS + 3) / 4;
     const int ks = EXACT ? KS : nd.ksteps;
@@ -105,67 +311,106 @@ __device__ __forceinline__ void run_net(const NetDev &nd, const f4 *__restrict__
     const int tpw = (nd.nht + NW - 1) / NW;
     const int ht0 = wave * tpw;
     const int ht1 = min(nd.nht, ht0 + tpw);
-    const f4 *w1 = reinterpret_cast<const f4 *>(nd.w1p) + lane;
-    const f4 *w2 = reinterpret_cast<const f4 *>(nd.w2p) + lane;
+    // pointers into locals: kernarg fields would be re-read behind every memory fence
+    const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
+    const f4 *const w2 = reinterpret_cast<const f4 *>(nd.w2p);
+    const float *const b1 = nd.b1;
+    // compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
+    // weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads
+#ifndef LCRC_DBG
+#define LCRC_DBG 0
+#endif
+    constexpr int dbg_skip_sig = LCRC_DBG & 2;
+    constexpr int dbg_skip_ld = LCRC_DBG & 4;
+    const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+    constexpr int wsel = (LCRC_DBG & 1) ? 0 : 1;
 
+    // All prefetches are UNCONDITIONAL (indices clamped instead): a load under a branch
+    // makes the compiler fall back to s_waitcnt vmcnt(0) at the join.
     f4 a[NKQ];
-    if (ht0 < ht1) {
-#pragma unroll
-        for (int kq = 0; kq < NKQ; kq++)
-            if (EXACT || kq < nkq) a[kq] = w1[(size_t)(ht0 * nkq + kq) * 64];
-    }
+    f4 bias;
+    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0, hlast), nkq, lane);
+    LCRC_FENCE();
+    f4 p0 = bias, p1 = bias;
+    gemm1<KS, NKQ, EXACT>(p0, p1, a, XF, nkq, ks, lane);   // (a wave without tiles computes a dummy)
+    LCRC_FENCE();
+    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0 + 1, hlast), nkq, lane);
+    LCRC_FENCE();
 
-    for (int ht = ht0; ht < ht1; ht++) {
-        // layer-2 weights of this tile: in flight during layer 1
+    for (int ht = ht0; ht < ht1 - 1; ht++) {
         f4 w[NOT];
+        f4 q0 = bias, q1 = bias, s0, s1;
+        if constexpr (EXACT) {
+            // ---- region A: sigmoid(t) as ONE block of VALU work, then layer 1 of tile t+1 in
+            //      8-MFMA groups with the requests for W2(t) spread behind them.
+            //      v_mfma_f32_16x16x4_f32 executes on the SIMD's f32 FMA lanes: VALU work
+            //      does not overlap with it, and every MFMA<->VALU switch costs ~3 idle cycles
+            //      on top (tools/ubench/valu_overlap.hip: MFMA 32.1, +6.4 for one v_fma_f32
+            //      behind it, +2.5..3 for each further one).  So VALU instructions are kept
+            //      together, not interleaved, and their number is what is optimised. ----
+            constexpr int WPG = (NOT + NKQ - 1) / NKQ;      // W2 fragments per layer-1 group
+            const f4 *t2 = w2 + (size_t)wsel * ht * NOT * 64;
+            Sig8 sg;
+            sg.begin(p0, p1);
+            if (!dbg_skip_sig) {
+#pragma unroll
+                for (int k = 0; k < Sig8::kStages; k++) sg.stage(k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kq = 0; kq < NKQ; kq++) {
+#pragma unroll
+                for (int i = 0; i < WPG; i++)
+                    if (kq * WPG + i < NOT && (!dbg_skip_ld || ht == ht0)) w[kq * WPG + i] = t2[(kq * WPG + i) * 64 + lane];
+                gemm1_group<KS, EXACT>(q0, q1, a[kq], XF, kq, nkq, ks, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sg.finish(s0, s1);
+            LCRC_FENCE();
+            // ---- region B: layer 2 of tile t; behind group ot go the requests for
+            //      W1(t+2) fragments (and the bias) ----
+            const int hn = min(ht + 2, hlast);
+            const f4 *t1 = w1 + (size_t)hn * NKQ * 64;
+            constexpr int LPG = (NKQ + NOT - 1) / NOT;      // W1 fragments per layer-2 group
+#pragma unroll
+            for (int ot = 0; ot < NOT; ot++) {
+#pragma unroll
+                for (int i = 0; i < LPG; i++)
+                    if (ot * LPG + i < NKQ && !dbg_skip_ld) a[ot * LPG + i] = load_w1_frag<KS, NKQ, EXACT>(t1, ot * LPG + i, lane);
+                if (ot == NOT - 1 && !dbg_skip_ld) bias = *reinterpret_cast<const f4 *>(b1 + 16 * hn + 4 * g);
+                gemm2_group(acc[ot][0], acc[ot][1], w[ot], s0, s1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            LCRC_FENCE();
+        } else {
+            // generic shapes: same phases, no hand-placed interleave
+            const f4 *t2 = w2 + (size_t)wsel * ht * n_ot * 64;
+#pragma unroll
+            for (int ot = 0; ot < NOT; ot++)
+                if (ot < n_ot) w[ot] = t2[ot * 64 + lane];
+            LCRC_FENCE();
+            sigmoid8(s0, s1, p0, p1);
+            gemm1<KS, NKQ, EXACT>(q0, q1, a, XF, nkq, ks, lane);
+            LCRC_FENCE();
+            load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht + 2, hlast), nkq, lane);
+            LCRC_FENCE();
+            gemm2<NOT, EXACT>(acc, w, s0, s1, n_ot);
+        }
+        p0 = q0;
+        p1 = q1;
+    }
+    if (ht0 < ht1) {                       // last tile of this wave
+        f4 w[NOT];
+        const f4 *t = w2 + (size_t)wsel * (ht1 - 1) * n_ot * 64;
 #pragma unroll
         for (int ot = 0; ot < NOT; ot++)
-            if (EXACT || ot < n_ot) w[ot] = w2[(size_t)(ht * n_ot + ot) * 64];
-
-        // layer 1, bias first (nn.cpp:883-884): pre[f][r] = S^T[16ht + 4g + r][16f + (lane&15)]
-        const f4 bias = *reinterpret_cast<const f4 *>(nd.b1 + 16 * ht + 4 * g);
-        f4 p0 = bias, p1 = bias;
-#pragma unroll
-        for (int kq = 0; kq < NKQ; kq++) {
-            if (EXACT || kq < nkq) {
-                const f4 x0 = XF[kq * 64 + lane];
-                const f4 x1 = XF[(nkq + kq) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
-                        p0 = mfma16x16x4(a[kq][j], x0[j], p0);
-                        p1 = mfma16x16x4(a[kq][j], x1[j], p1);
-                    }
-                }
-            }
-        }
-        // next tile's layer-1 weights: in flight during sigmoid + layer 2
-        if (ht + 1 < ht1) {
-#pragma unroll
-            for (int kq = 0; kq < NKQ; kq++)
-                if (EXACT || kq < nkq) a[kq] = w1[(size_t)((ht + 1) * nkq + kq) * 64];
-        }
-        // Sigmoid (nn.cpp:796-820).  Pad hidden units (>= n_hid) need no zeroing:
-        // their layer-2 weights are packed as zeros.
+            if (EXACT || ot < n_ot) w[ot] = t[ot * 64 + lane];
         f4 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            s0[r] = fexp_sigmoid(p0[r]);
-            s1[r] = fexp_sigmoid(p1[r]);
-        }
-        // layer 2: k-slot g of step r is hidden unit 16ht + 4g + r on both operands
-#pragma unroll
-        for (int ot = 0; ot < NOT; ot++) {
-            if (EXACT || ot < n_ot) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    acc[ot][0] = mfma16x16x4(w[ot][r], s0[r], acc[ot][0]);
-                    acc[ot][1] = mfma16x16x4(w[ot][r], s1[r], acc[ot][1]);
-                }
-            }
-        }
+        sigmoid8(s0, s1, p0, p1);
+        gemm2<NOT, EXACT>(acc, w, s0, s1, n_ot);
     }
 
+    LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
     // ---- fold the NW partial tiles: top two waves down by two until one is left ----
     const int slab_f4 = 2 * n_ot_slab * 64;     // float4 per slab
 #pragma unroll
@@ -194,7 +439,8 @@ __device__ __forceinline__ void run_net(const NetDev &nd, const f4 *__restrict__
         __syncthreads();
     }
 
-    // ---- logits -> dense[frame][o] (slab 1), softmax on all threads (nn.cpp:822-855) ----
+    // ---- logits -> dense[frame][o] (slab 1); softmax in registers on all threads
+    //      (nn.cpp:822-855): LPF lanes share a frame, each holds every LPF-th output ----
     float *dense = reinterpret_cast<float *>(slab + slab_f4);
     const int os = 16 * n_ot_slab;
     if (wave == 0) {
@@ -209,33 +455,39 @@ __device__ __forceinline__ void run_net(const NetDev &nd, const f4 *__restrict__
     __syncthreads();
     {
         constexpr int LPF = NW * 64 / kBM;       // lanes cooperating on one frame
+        constexpr int NV = 16 * NOT / LPF;       // values per lane
         const int tid = wave * 64 + lane;
         const int frame = tid / LPF, part = tid % LPF;
-        float *row = dense + frame * os;
+        const float *row = dense + frame * os;
         const int O = nd.n_out;
+        float v[NV];
         float m = -FLT_MAX;
-        for (int o = part; o < O; o += LPF) m = fmaxf(m, row[o]);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int o = part + LPF * j;
+            v[j] = o < O ? row[o] : -FLT_MAX;
+            m = fmaxf(m, v[j]);
+        }
 #pragma unroll
         for (int d = 1; d < LPF; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
         float sum = 0.0f;
-        for (int o = part; o < O; o += LPF) {
-            float e = fexp_f(row[o] - m);
-            row[o] = e;
-            sum += e;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            if (part + LPF * j < O) {
+                v[j] = fexp_f(v[j] - m);
+                sum += v[j];
+            }
         }
 #pragma unroll
         for (int d = 1; d < LPF; d <<= 1) sum += __shfl_xor(sum, d);
         const float scale = 1.0f / sum;
-        for (int o = part; o < O; o += LPF) row[o] *= scale;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int o = part + LPF * j;
+            if (o < O) epi(frame, o, v[j] * scale);
+        }
     }
     __syncthreads();
-}
-
-// Scatter one value of a net-input row into the MFMA B image (see run_net).
-__device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, float v)
-{
-    const int f = frame >> 4, kq = k >> 4, j = (k >> 2) & 3, l = (frame & 15) + 16 * (k & 3);
-    img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
 }
 
 template <int KS1, int KSM, int NOT, int NW, bool EXACT>
@@ -257,6 +509,9 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     int *rowhi = rowlo + kBM;
     float *costab = reinterpret_cast<float *>(smem + lp.tabs);
     float *win = costab + 10 * 16;
+    // normalisation vectors of the three nets: [mean | dev] per net
+    float *nrm_band = reinterpret_cast<float *>(smem + lp.norms);          // [2 nets][2][16*nkq1]
+    float *nrm_merger = nrm_band + 4 * 16 * nkq1;                           // [2][16*nkqm]
     float *xf = reinterpret_cast<float *>(smem + lp.xf);
     float *gf = reinterpret_cast<float *>(smem + lp.gf);
     f4 *slab = reinterpret_cast<f4 *>(smem + lp.slab);
@@ -264,6 +519,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int r0 = blockIdx.x * kBM;
     const int tbase = r0 - kShift;
 
+    LCRC_STAMP(p, wave, lane, 0);
     // ---- stage 0: utterance bounds per frame, mel tile, tables, zeroed operand images ----
     if (tid < kBM) {
         const int r = min(r0 + tid, p.n_rows - 1);
@@ -287,6 +543,13 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     for (int i = tid; i < 10 * 16 + 2 * 16; i += NT)
         costab[i] = i < 160 ? p.costab[i] : p.win[i - 160];
     {
+        const int w1n = 16 * nkq1, wmn = 16 * nkqm;
+        for (int i = tid; i < 4 * w1n; i += NT) {
+            const int n = i / (2 * w1n), k = i % w1n, isdev = (i / w1n) & 1;
+            nrm_band[i] = isdev ? p.net[n].dev[k] : p.net[n].mean[k];
+        }
+        for (int i = tid; i < 2 * wmn; i += NT)
+            nrm_merger[i] = i < wmn ? p.net[2].mean[i] : p.net[2].dev[i - wmn];
         f4 *z = reinterpret_cast<f4 *>(xf);
         const int n = (int)((lp.slab - lp.xf) / 16);    // xf and gf are adjacent
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -294,11 +557,11 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     }
     __syncthreads();
 
+    LCRC_STAMP(p, wave, lane, 1);
     // ---- stage 1: window * DCT projection + input normalisation (traps.cpp:285-343,
     //      dspc.h:107-112,206-233, nn.cpp:702-716) ----
     {
-        const NetDev &n0 = p.net[0];
-        const int K = n0.n_inp;                  // nbanks * 11
+        const int K = p.net[0].n_inp;            // nbanks * 11
         const int items = 2 * nb * kBM;
         for (int it = tid; it < items; it += NT) {
             const int i = it % kBM;
@@ -313,73 +576,82 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 s = max(lo, min(hi, s));
                 xw[j] = melT[(s - tbase) * nb + b] * win[n * kHalf + j];
             }
-            const NetDev &nd = p.net[n];
+            const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (2 * nkq1 * 256);
             float *dbg = n == 0 ? p.dbg_in0 : p.dbg_in1;
+            const bool dbg_on = dbg && r0 + i < p.n_rows;
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < kHalf; j++) sum += xw[j];
             sum *= p.normc;                                          // CalcC0
             {
                 const int k = b * kNCoef;
-                if (dbg && r0 + i < p.n_rows) dbg[(size_t)(r0 + i) * K + k] = sum;
-                float v = sum - nd.mean[k];
-                v *= nd.dev[k];
+                if (dbg_on) dbg[(size_t)(r0 + i) * K + k] = sum;
+                float v = sum - mean[k];
+                v *= dev[k];
                 xf_store(img, nkq1, i, k, v);
             }
+#pragma unroll 2
             for (int c = 0; c < kNCoef - 1; c++) {                   // sDCT
                 float acc = 0.0f;
 #pragma unroll
                 for (int j = 0; j < kHalf; j++) acc += xw[j] * costab[c * 16 + j];
                 acc *= p.normc;
                 const int k = b * kNCoef + 1 + c;
-                if (dbg && r0 + i < p.n_rows) dbg[(size_t)(r0 + i) * K + k] = acc;
-                float v = acc - nd.mean[k];
-                v *= nd.dev[k];
+                if (dbg_on) dbg[(size_t)(r0 + i) * K + k] = acc;
+                float v = acc - mean[k];
+                v *= dev[k];
                 xf_store(img, nkq1, i, k, v);
             }
         }
     }
     __syncthreads();
 
-    // ---- stage 2: the two band nets; their ln() outputs build the merger's image ----
+    LCRC_STAMP(p, wave, lane, 10);              // projection done
+    // ---- stage 2: the two band nets; ln() of their outputs, normalised for the merger,
+    //      goes straight from the softmax registers into the merger's operand image ----
     const NetDev &nm = p.net[2];
-    float *dense = reinterpret_cast<float *>(slab + 2 * n_ot * 64);
-    const int os = 16 * n_ot;
+    const float *mmean = nrm_merger, *mdev = nrm_merger + 16 * nkqm;
 #pragma unroll 1
     for (int n = 0; n < 2; n++) {
         const NetDev &nd = p.net[n];
-        run_net<KS1, NOT, NW, EXACT>(nd, reinterpret_cast<const f4 *>(xf) + (size_t)n * (2 * nkq1 * 64),
-                                     slab, n_ot, lane, wave);
         const int O = nd.n_out;
         const int kofs = n * p.net[0].n_out;
         float *dp = n == 0 ? p.dbg_p0 : p.dbg_p1;
-        for (int it = tid; it < kBM * O; it += NT) {
-            const int i = it / O, o = it % O;
-            const float q = dense[i * os + o];
+        auto epi = [&](int i, int o, float q) {
             const float gl = q > 0.0f ? logf(q) : 0.0f;             // sLn dspc.h:155-160
-            if (r0 + i < p.n_rows) {
+            if ((dp || p.dbg_g) && r0 + i < p.n_rows) {
                 if (dp) dp[(size_t)(r0 + i) * O + o] = q;
                 if (p.dbg_g) p.dbg_g[(size_t)(r0 + i) * nm.n_inp + kofs + o] = gl;
             }
-            float v = gl - nm.mean[kofs + o];
-            v *= nm.dev[kofs + o];
+            float v = gl - mmean[kofs + o];                          // Normalize nn.cpp:702-716
+            v *= mdev[kofs + o];
             xf_store(gf, nkqm, i, kofs + o, v);
-        }
-        __syncthreads();
+        };
+        run_net<KS1, NOT, NW, EXACT>(p, 2 + 3 * n, nd,
+                                     reinterpret_cast<const f4 *>(xf) + (size_t)n * (2 * nkq1 * 64), slab,
+                                     n_ot, lane, wave, epi);
+        LCRC_STAMP(p, wave, lane, 3 + 3 * n);   // fold + softmax + ln() done
+        LCRC_STAMP(p, wave, lane, 4 + 3 * n);
     }
 
-    // ---- stage 3: merger; posteriors leave as whole contiguous rows ----
-    run_net<KSM, NOT, NW, EXACT>(nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave);
+    // ---- stage 3: merger; posteriors are gathered as contiguous rows in LDS (slab 0 is
+    //      free again) and leave as one linear, 16-byte-per-lane copy ----
     {
         const int O = nm.n_out;
+        float *outbuf = reinterpret_cast<float *>(slab);
+        auto epi = [&](int i, int o, float q) { outbuf[i * O + o] = q; };
+        run_net<KSM, NOT, NW, EXACT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
+        LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(kBM, p.n_rows - r0);
-        float *dst = p.post + (size_t)r0 * O;
-        for (int it = tid; it < rows * O; it += NT) {
-            const int i = it / O, o = it % O;
-            dst[it] = dense[i * os + o];
-        }
+        const int total = rows * O;
+        float *dst = p.post + (size_t)r0 * O;      // 32*O*4 bytes per tile: 16-byte aligned
+        const int n4 = total >> 2;
+        for (int i = tid; i < n4; i += NT)
+            reinterpret_cast<f4 *>(dst)[i] = reinterpret_cast<const f4 *>(outbuf)[i];
+        for (int i = (n4 << 2) + tid; i < total; i += NT) dst[i] = outbuf[i];
     }
+    LCRC_STAMP(p, wave, lane, 11);
 }
 
 // ---- variants --------------------------------------------------------------------------
