@@ -1,0 +1,51 @@
+// phndec.h -- phoneme-loop Viterbi decoder of the shipped configs (decoder/type=phndec).
+// Stays on the host (BASELINE.json north_star).  Behaviour follows the reference's PhnDec
+// (phndec.cpp): S-state left-to-right models, ln 0.5 self/next transitions, insertion
+// penalty at every phoneme entry, labels emitted when a phoneme boundary falls exactly at
+// the `time_pruning` horizon, the rest traced back at Done().
+#ifndef PHNREC_HOST_PHNDEC_H
+#define PHNREC_HOST_PHNDEC_H
+
+#include <string>
+#include <vector>
+
+namespace phnrec {
+
+struct Label {
+    int start, end;          // frames
+    std::string phn;
+    float score;
+};
+
+class PhnDec {
+public:
+    bool LoadPhnList(const std::string &path);            // one symbol per line (phndec.cpp:305-349)
+    void SetStatesPerPhn(int n) { S_ = n; }
+    void SetTimePruning(int n) { prune_ = n; }
+    void SetWPenalty(float p) { wpen_ = p; }
+    int NumPhonemes() const { return (int)phn_.size(); }
+    void Init();                                          // phndec.cpp:44-94
+    void ProcessFrame(const float *logpost);              // phndec.cpp:160-167
+    void Done();                                          // phndec.cpp:236-303
+    const std::vector<Label> &Labels() const { return labels_; }
+
+private:
+    void TimePruning();
+    std::vector<std::string> phn_;
+    int S_ = 1, prune_ = 50, nframes_ = 0;
+    float wpen_ = 0.0f, prev_alpha_ = 0.0f;
+    std::vector<float> alpha_;      // [nphn][S+1]
+    std::vector<int> prev_, len_;   // [nphn][S+1]
+    std::vector<int> hphn_, hlen_;  // [prune+1] history of network-level winners
+    std::vector<float> halpha_;
+    std::vector<Label> labels_;
+};
+
+// Label text exactly as the reference prints it.
+// direct label file: "%d00000 %d00000 %s %f\n" (phndec.cpp:230,292) -> "000000 ..." at frame 0
+std::string FormatLabelLine(const Label &l);
+// MLF entry: "0" for zero, "%u00000" otherwise (SpeechRec::OnWordMLF, srec.cpp:137-161)
+std::string FormatMlfLine(const Label &l);
+
+}  // namespace phnrec
+#endif

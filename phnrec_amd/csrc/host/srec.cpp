@@ -1,0 +1,475 @@
+// srec.cpp -- see srec.h
+#include "srec.h"
+
+#include <sys/stat.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "htk.h"
+
+namespace phnrec {
+
+// ---- small helpers ---------------------------------------------------------------------
+
+DataFormat ParseDataFormat(const std::string &s)
+{
+    if (s == "wf") return dfWaveform;
+    if (s == "par") return dfParams;
+    if (s == "post") return dfPosteriors;
+    if (s == "str") return dfStrings;
+    return dfUnknown;
+}
+
+static size_t LastSep(const std::string &s)
+{
+    const size_t a = s.rfind('/'), b = s.rfind('\\');
+    if (a == std::string::npos) return b;
+    if (b == std::string::npos) return a;
+    return a > b ? a : b;
+}
+
+// Replace what follows the last '.' of the base name, or append ".suffix" (filename.cpp:30-46)
+std::string ChangeFileSuffix(const std::string &name, const std::string &suffix)
+{
+    const size_t dot = name.rfind('.'), sep = LastSep(name);
+    if (dot == std::string::npos || (sep != std::string::npos && sep > dot)) return name + "." + suffix;
+    return name.substr(0, dot + 1) + suffix;
+}
+
+// Replace the directory part; unchanged when the name has no separator (filename.cpp:100-114)
+std::string ChangeFilePath(const std::string &name, const std::string &new_path)
+{
+    const size_t sep = LastSep(name);
+    if (sep == std::string::npos) return name;
+    return new_path + name.substr(sep);
+}
+
+// Strip the last component; "" when there is no separator (filename.cpp:116-128)
+std::string GetFilePath(const std::string &name)
+{
+    const size_t sep = LastSep(name);
+    return sep == std::string::npos ? std::string() : name.substr(0, sep);
+}
+
+static void ParallelFor(int n, int threads, const std::function<void(int)> &fn)
+{
+    if (threads <= 1 || n <= 1) {
+        for (int i = 0; i < n; i++) fn(i);
+        return;
+    }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    const int t = threads < n ? threads : n;
+    for (int k = 0; k < t; k++)
+        pool.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto &th : pool) th.join();
+}
+
+// posteriors/softening_func and decoder/softening_func (srec.cpp:164-176, srec.h:192-194)
+static float Soften(const std::string &f, float v, const float *a)
+{
+    if (f == "none") return v;
+    if (f == "log") return logf(v);
+    if (f == "igor") {
+        if (v < a[0]) return logf(v * (1.0f / a[0])) / logf(a[2]);
+        return -1.0f * logf((1.0f + (-1.0f * v)) * (1.0f / (1.0f - a[0]))) / logf(a[1]);
+    }
+    return sqrtf(-2.0f * logf(v));                       // gmm_bypass
+}
+
+static bool ParseSoftFunc(const std::string &s, std::string &name, float *a)
+{
+    char func[256];
+    a[0] = a[1] = a[2] = 0.0f;
+    if (sscanf(s.c_str(), "%255s %f %f %f", func, &a[0], &a[1], &a[2]) != 4) return false;
+    name = func;
+    return name == "none" || name == "log" || name == "igor" || name == "gmm_bypass";
+}
+
+// ---- Init ------------------------------------------------------------------------------
+
+bool SpeechRec::Init(const std::string &config_file)
+{
+    config_dir_ = GetFilePath(config_file);
+    int line = 0;
+    char msg[1200];
+    switch (C.Load(config_file, &line)) {
+    case Config::OK: break;
+    case Config::UNKVAR:
+        snprintf(msg, sizeof msg, "Unknown variable in configuration file '%s', line %d\n", config_file.c_str(), line);
+        return Fail(msg);
+    case Config::BADVAL:
+        snprintf(msg, sizeof msg, "Invalid argument for a vatiable in configuration file '%s', line %d\n", config_file.c_str(), line);
+        return Fail(msg);
+    case Config::FILEERR:
+        snprintf(msg, sizeof msg, "Can not open configuration file '%s'\n", config_file.c_str());
+        return Fail(msg);
+    case Config::INVVAR:
+        snprintf(msg, sizeof msg, "Invalid notation of variable in configuration file '%s', line %d\n", config_file.c_str(), line);
+        return Fail(msg);
+    }
+    // $C / $T substitution (srec.cpp:268-332); the temp dir is created, failure ignored
+    C.SetString("dirs", "tmp", C.Subst(C.GetString("dirs", "tmp"), config_dir_));
+    mkdir(C.GetString("dirs", "tmp").c_str(), 0777);
+    const char *paths[][2] = {{"models", "hmm_defs"}, {"dicts", "phoneme_list"}, {"networks", "default"},
+                              {"dicts", "lexicon1"}, {"dicts", "lexicon2"}, {"dicts", "keyword_list"},
+                              {"kws", "thresholds_file"}, {"gptransc", "rules"}, {"gptransc", "symbols"},
+                              {"onlinenorm", "file"}};
+    for (auto &p : paths) C.SetString(p[0], p[1], C.Subst(C.GetString(p[0], p[1]), config_dir_));
+
+    // source
+    wave_.format = ParseWaveFormat(C.GetString("source", "format"));
+    if (wave_.format == WF_UNKNOWN) {
+        snprintf(msg, sizeof msg, "Invalid waveform format '%s'. Supported data formats are 'lin16' and 'alaw'.\n",
+                 C.GetString("source", "format").c_str());
+        return Fail(msg);
+    }
+    wave_.scale = C.GetFloat("source", "scale");
+    wave_.dc_shift = C.GetFloat("source", "dc_shift");
+    wave_.noise_level = C.GetFloat("source", "noise_level");
+
+    Log("\nSystem initialization\n");
+    if (C.GetString("params", "kind") != "fbanks") {
+        snprintf(msg, sizeof msg, "Unknown parameterization (parameters/kind): '%s'\n", C.GetString("params", "kind").c_str());
+        return Fail(msg);
+    }
+    Log("  - mel-banks ...\n");
+    nbanks_ = C.GetInt("melbanks", "nbanks");
+    mb_proto_.Configure(nbanks_, C.GetInt("melbanks", "nbanks_full"), C.GetInt("source", "sample_freq"),
+                        C.GetInt("melbanks", "vector_size"), C.GetInt("melbanks", "vector_step"),
+                        C.GetFloat("melbanks", "preem_coef"), C.GetBool("melbanks", "z_mean_source"),
+                        C.GetFloat("melbanks", "lower_freq"), C.GetFloat("melbanks", "higher_freq"));
+    Log("  - online normalization ...\n");
+    sent_mean_norm_ = C.GetBool("offlinenorm", "sent_mean_norm");
+    if (C.GetBool("offlinenorm", "sent_var_norm"))
+        return Fail("offlinenorm/sent_var_norm=true is not supported (the reference aborts on it: srec.cpp:1531 reads a variable that is not in its schema)\n");
+
+    Log("  - posteriors (loading NNs) ...\n");
+    const std::string sys = C.GetString("posteriors", "system");
+    if (sys != "LCRC" && sys != "3BT" && sys != "1BT" && sys != "1BT_DCT") {
+        snprintf(msg, sizeof msg, "Unknown system, check configuration: %s", sys.c_str());
+        return Fail(msg);
+    }
+    traps_enabled_ = C.GetBool("posteriors", "enabled");
+    if (traps_enabled_) {
+        if (sys != "LCRC" || C.GetBool("posteriors", "hamming") || C.GetInt("posteriors", "length") != 31 ||
+            !C.GetBool("posteriors", "add_c0"))
+            return Fail("only posteriors/system=LCRC, length=31, add_c0=true, hamming=false runs on the GPU path\n");
+        // host-only validation of the model directory (the GPU is claimed lazily, when a
+        // par -> post conversion is actually requested)
+        int dims[9];
+        if (lcrc_model_info(config_dir_.c_str(), nbanks_, dims, nullptr, 0, nullptr) != LCRC_OK) {
+            snprintf(msg, sizeof msg, "%s\n", lcrc_last_error(nullptr));
+            return Fail(msg);
+        }
+        n_out_ = dims[8];
+    }
+
+    Log("  - decoder ...\n\n");
+    const std::string dtype = C.GetString("decoder", "type");
+    if (dtype != "phndec") {
+        snprintf(msg, sizeof msg, "Unknown dekoder, check configuration: %s", dtype.c_str());
+        return Fail(msg);
+    }
+    states_per_phn_ = C.GetInt("decoder", "num_states_per_phn");
+    time_pruning_ = C.GetInt("decoder", "time_pruning");
+    phoneme_list_ = C.GetString("dicts", "phoneme_list");
+    {
+        PhnDec probe;
+        if (!probe.LoadPhnList(phoneme_list_)) {
+            snprintf(msg, sizeof msg, "Can not load phoneme list: %s", phoneme_list_.c_str());
+            return Fail(msg);
+        }
+    }
+    if (!wpenalty_set_) wpenalty_ = C.GetFloat("decoder", "wpenalty");
+    if (C.GetString("decoder", "mode") == "kws") return Fail("decoder/mode=kws needs the STK decoder, which is outside this path\n");
+    if (!ParseSoftFunc(C.GetString("posteriors", "softening_func"), post_soft_, post_soft_arg_) ||
+        !ParseSoftFunc(C.GetString("decoder", "softening_func"), dec_soft_, dec_soft_arg_))
+        return Fail("Invalid softening function format. The format should be function identificator and three floating point arguments.\n");
+
+    if (verbose_) {
+        printf("------------------- SUMMARY -------------------\n");
+        printf("Dictionary:   %s\n", C.GetString("dicts", "phoneme_list").c_str());
+        printf("Network file: %s\n", C.GetString("networks", "default").c_str());
+        printf("HMM file:     %s\n", C.GetString("models", "hmm_defs").c_str());
+        printf("#States/Phn:  %d\n", C.GetInt("models", "nstates"));
+        printf("Time pruning: %d\n", C.GetInt("decoder", "time_pruning"));
+        printf("Word penalty: %f\n", C.GetFloat("decoder", "wpenalty"));
+        printf("Soft func:    %s\n", C.GetString("decoder", "softening_func").c_str());
+        printf("-----------------------------------------------\n\n");
+    }
+    return true;
+}
+
+bool SpeechRec::EnsureGpus()
+{
+    if (!gpus_.empty()) return true;
+    int n = n_gpus_;
+    if (n <= 0) n = 1;
+    for (int d = 0; d < n; d++) {
+        std::unique_ptr<Traps> t(new Traps);
+        t->SetSystem(C.GetString("posteriors", "system").c_str());
+        t->SetTrapLen(C.GetInt("posteriors", "length"));
+        t->SetHamming(C.GetBool("posteriors", "hamming"));
+        t->SetNBanks(nbanks_);
+        t->SetAddC0(C.GetBool("posteriors", "add_c0"));
+        t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
+        t->SetDevice(d);
+        if (!t->Init(config_dir_.c_str())) return Fail(t->LastError() + "\n");
+        gpus_.push_back(std::move(t));
+    }
+    return true;
+}
+
+// ---- per-utterance stages --------------------------------------------------------------
+
+static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long len = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bytes.resize((size_t)len);
+    const bool ok = len == 0 || fread(bytes.data(), 1, (size_t)len, f) == (size_t)len;
+    fclose(f);
+    return ok;
+}
+
+void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
+{
+    char msg[1200];
+    if (in == dfWaveform) {
+        std::vector<unsigned char> bytes;
+        if (!ReadFile(job.src, bytes)) {
+            snprintf(msg, sizeof msg, "Can not open waveform file: %s\n", job.src.c_str());
+            job.ok = false; job.err = msg;
+            return;
+        }
+        std::vector<float> samples;
+        int n = 0;
+        DecodeWaveform(bytes, wave_, samples, &n);
+        MelBanks mb = mb_proto_;                       // private FFT scratch per call
+        mb.Compute(samples, n, job.mel);
+        job.frames = mb.NumFrames(n);
+        job.cols = nbanks_;
+        const float shift = C.GetFloat("framenorm", "shift"), floor_ = C.GetFloat("framenorm", "min_floor");
+        if (shift != 0.0f) for (float &v : job.mel) v += shift;                 // srec.cpp:1594-1620
+        if (floor_ != -9999.9f) for (float &v : job.mel) if (v < floor_) v = floor_;
+    } else {
+        std::vector<float> data;
+        int rows = 0, cols = 0;
+        if (!LoadHTK(job.src, data, &rows, &cols)) {
+            snprintf(msg, sizeof msg, "Can not open file: %s\n", job.src.c_str());
+            job.ok = false; job.err = msg;
+            return;
+        }
+        job.frames = rows;
+        if (in == dfParams) {
+            if (cols < nbanks_) { job.ok = false; job.err = "Invalid dimensionality of parameter vectors\n"; return; }
+            job.mel.resize((size_t)rows * nbanks_);
+            for (int r = 0; r < rows; r++) memcpy(&job.mel[(size_t)r * nbanks_], &data[(size_t)r * cols], sizeof(float) * nbanks_);
+            job.cols = nbanks_;
+        } else {
+            job.post.swap(data);
+            job.cols = cols;
+        }
+    }
+    // sentence normalisation happens after the `-t par` exit (srec.cpp:973-974,999)
+    if ((in == dfWaveform || in == dfParams) && out != dfParams && sent_mean_norm_ && job.frames > 0)
+        SentenceMeanNorm(job.mel.data(), job.frames, nbanks_);
+}
+
+void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf)
+{
+    char msg[1200];
+    if (out == dfParams) {
+        if (!SaveHTK(job.tgt, job.mel.data(), job.frames, nbanks_)) {
+            snprintf(msg, sizeof msg, "Can not create file: %s\n", job.tgt.c_str());
+            job.ok = false; job.err = msg;
+        }
+        return;
+    }
+    if (out == dfPosteriors) {
+        if (!SaveHTK(job.tgt, job.post.data(), job.frames, job.cols)) {
+            snprintf(msg, sizeof msg, "Can not create file: %s\n", job.tgt.c_str());
+            job.ok = false; job.err = msg;
+        }
+        return;
+    }
+    // strings: decoder softening (log), Viterbi, labels
+    for (float &v : job.post) v = Soften(dec_soft_, v, dec_soft_arg_);
+    PhnDec dec;
+    dec.LoadPhnList(phoneme_list_);
+    dec.SetStatesPerPhn(states_per_phn_);
+    dec.SetTimePruning(time_pruning_);
+    dec.SetWPenalty(wpenalty_);
+    dec.Init();
+    if (job.cols < dec.NumPhonemes() * states_per_phn_) {
+        job.ok = false;
+        job.err = "posterior vectors are shorter than the phoneme list needs\n";
+        return;
+    }
+    for (int r = 0; r < job.frames; r++) dec.ProcessFrame(&job.post[(size_t)r * job.cols]);
+    dec.Done();
+    std::string text;
+    if (mlf) {
+        text = "\"" + job.tgt + "\"\n";
+        for (const Label &l : dec.Labels()) text += FormatMlfLine(l);
+        text += ".\n";
+        job.labels.swap(text);
+    } else {
+        for (const Label &l : dec.Labels()) text += FormatLabelLine(l);
+        FILE *f = fopen(job.tgt.c_str(), "w");
+        if (!f) { job.ok = false; job.err = "Can not create file: " + job.tgt + "\n"; return; }
+        fputs(text.c_str(), f);
+        fclose(f);
+    }
+}
+
+// ---- lists -----------------------------------------------------------------------------
+
+std::string SpeechRec::LabelNameForMlf(const std::string &file) const
+{
+    std::string s = file;
+    for (char &c : s) if (c == '\\') c = '/';
+    s = ChangeFileSuffix(s, C.GetString("labels", "suffix"));
+    if (C.GetBool("labels", "remove_path")) s = ChangeFilePath(s, "*");
+    return s;
+}
+
+bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job &job)
+{
+    char f1[1024], f2[1024], sep[256];
+    if (sscanf(line.c_str(), "%1023[^ \n\r\t]%255[ \t]%1023[^ \n\r\t]", f1, sep, f2) == 3) {
+        job.src = f1; job.tgt = f2;
+        return true;
+    }
+    if (sscanf(line.c_str(), "%1023s", f1) != 1) return Fail("Invalid line in file list: " + line + "\n");
+    job.src = f1;
+    switch (out) {
+    case dfParams: job.tgt = ChangeFileSuffix(f1, C.GetString("params", "suffix")); break;
+    // the reference looks up ("traps","suffix"), which its schema lacks, and aborts
+    // (srec.cpp:1224); the documented variable is posteriors/suffix
+    case dfPosteriors: job.tgt = ChangeFileSuffix(f1, C.GetString("posteriors", "suffix")); break;
+    case dfStrings: job.tgt = mlf ? LabelNameForMlf(f1) : ChangeFileSuffix(f1, C.GetString("labels", "suffix")); break;
+    default: break;
+    }
+    return true;
+}
+
+bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int threads = host_threads_ > 0 ? host_threads_ : (int)std::max(1u, std::thread::hardware_concurrency());
+    const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
+    if (need_gpu) {
+        if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
+        if (!EnsureGpus()) return false;
+    }
+    const int n = (int)jobs.size();
+    for (const Job &j : jobs) Log(j.tgt.empty() ? j.src + "\n" : j.src + " -> " + j.tgt + "\n");
+    ParallelFor(n, threads, [&](int i) { Stage1(in, out, jobs[i]); });
+    for (const Job &j : jobs) if (!j.ok) return Fail(j.err);
+
+    if (need_gpu) {
+        // consecutive utterances are packed into launches of <= batch_frames_ frames;
+        // the GPUs pull launches from one queue (no exchange, every GPU holds all weights)
+        std::vector<std::pair<int, int>> batches;      // [first, last) job index
+        for (int i = 0; i < n;) {
+            int j = i, frames = 0;
+            while (j < n && (j == i || frames + jobs[j].frames <= batch_frames_)) frames += jobs[j++].frames;
+            batches.emplace_back(i, j);
+            i = j;
+        }
+        std::atomic<int> next(0);
+        std::atomic<bool> failed(false);
+        std::vector<std::string> errs(gpus_.size());
+        std::vector<double> kms(gpus_.size(), 0.0);
+        auto worker = [&](int g) {
+            Traps &tr = *gpus_[g];
+            std::vector<float> mel, post;
+            std::vector<int> off;
+            for (int b; (b = next.fetch_add(1)) < (int)batches.size() && !failed;) {
+                off.assign(1, 0);
+                mel.clear();
+                for (int i = batches[b].first; i < batches[b].second; i++) {
+                    mel.insert(mel.end(), jobs[i].mel.begin(), jobs[i].mel.end());
+                    off.push_back(off.back() + jobs[i].frames);
+                }
+                post.resize((size_t)off.back() * n_out_);
+                if (!tr.CalcBatch(mel.data(), off.data(), (int)off.size() - 1, post.data())) {
+                    errs[g] = tr.LastError();
+                    failed = true;
+                    return;
+                }
+                if (off.back() > 0) kms[g] += tr.LastKernelMs();
+                for (int i = batches[b].first, k = 0; i < batches[b].second; i++, k++) {
+                    Job &j = jobs[i];
+                    j.post.assign(post.begin() + (size_t)off[k] * n_out_, post.begin() + (size_t)off[k + 1] * n_out_);
+                    j.cols = n_out_;
+                    std::vector<float>().swap(j.mel);
+                    if (post_soft_ != "none") for (float &v : j.post) v = Soften(post_soft_, v, post_soft_arg_);
+                }
+            }
+        };
+        std::vector<std::thread> gt;
+        for (size_t g = 0; g < gpus_.size(); g++) gt.emplace_back(worker, (int)g);
+        for (auto &t : gt) t.join();
+        for (size_t g = 0; g < gpus_.size(); g++) {
+            if (!errs[g].empty()) return Fail(errs[g] + "\n");
+            stats_.gpu_kernel_ms += kms[g];
+        }
+        for (const Job &j : jobs) stats_.frames += j.frames;
+    }
+    ParallelFor(n, threads, [&](int i) { Stage3(out, jobs[i], mlf != nullptr); });
+    for (Job &j : jobs) {
+        if (!j.ok) return Fail(j.err);
+        if (mlf) fputs(j.labels.c_str(), mlf);
+    }
+    stats_.files += n;
+    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+bool SpeechRec::ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line)
+{
+    std::vector<Job> jobs(1);
+    if (!ParseLine(line, out, false, jobs[0])) return false;
+    return RunJobs(in, out, jobs, nullptr);
+}
+
+bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf_path)
+{
+    FILE *fl = fopen(list.c_str(), "r");
+    if (!fl) return Fail("Can not open the file list: " + list + "\n");
+    FILE *mlf = nullptr;
+    if (!mlf_path.empty()) {
+        mlf = fopen(mlf_path.c_str(), "w");
+        if (!mlf) { fclose(fl); return Fail("Can not create the MLF: " + mlf_path + "\n"); }
+        fprintf(mlf, "#!MLF!#\n");
+    }
+    const size_t kChunk = 1024;                       // utterances in flight (bounds host memory)
+    char buf[1024];
+    bool ok = true, eof = false;
+    while (ok && !eof) {
+        std::vector<Job> jobs;
+        while (jobs.size() < kChunk) {
+            if (!fgets(buf, 1023, fl)) { eof = true; break; }
+            Job j;
+            if (!ParseLine(buf, out, mlf != nullptr, j)) { ok = false; break; }
+            jobs.push_back(std::move(j));
+        }
+        if (ok && !jobs.empty()) ok = RunJobs(in, out, jobs, mlf);
+    }
+    if (mlf) fclose(mlf);
+    fclose(fl);
+    return ok;
+}
+
+}  // namespace phnrec

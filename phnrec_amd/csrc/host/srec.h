@@ -1,0 +1,91 @@
+// srec.h -- orchestration of the drop-in `phnrec` CLI: the part of the reference's
+// SpeechRec (srec.cpp) that surrounds the posterior path -- configuration, file / list
+// modes, the wf -> par -> post -> str data-format ladder, HTK dumps, label and MLF output.
+// The par -> post step is the GPU path (class Traps over include/lcrc.h); everything else
+// here is host plumbing kept byte-compatible with the reference's files and messages.
+//
+// What is different by design: utterances are independent, so a file list is processed in
+// chunks -- front-end and Viterbi on a host thread pool, posteriors in multi-utterance
+// launches spread over all selected GPUs (no exchange between GPUs; outputs are written in
+// list order).  Live audio (-a) and the STK decoder are outside this path's scope.
+#ifndef PHNREC_HOST_SREC_H
+#define PHNREC_HOST_SREC_H
+
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "config.h"
+#include "frontend.h"
+#include "phndec.h"
+#include "traps.h"
+
+namespace phnrec {
+
+enum DataFormat { dfUnknown = 0, dfWaveform, dfParams, dfPosteriors, dfStrings };
+DataFormat ParseDataFormat(const std::string &s);          // wf | par | post | str
+
+struct RunStats {
+    long long frames = 0, files = 0;
+    double seconds = 0, gpu_kernel_ms = 0;
+};
+
+class SpeechRec {
+public:
+    bool Init(const std::string &config_file);             // srec.cpp:235-707
+    void SetVerbose(bool v) { verbose_ = v; }
+    void SetWaveFormat(WaveFormat f) { wave_.format = f; }
+    void SetWPenalty(float p) { wpenalty_ = p; wpenalty_set_ = true; }
+    void SetGpus(int n) { n_gpus_ = n; }
+    void SetBatchFrames(int n) { batch_frames_ = n; }
+    void SetHostThreads(int n) { host_threads_ = n; }
+    // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
+    bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
+    bool ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf);
+    const std::string &LastError() const { return err_; }
+    const RunStats &Stats() const { return stats_; }
+    Config C;
+
+private:
+    struct Job {
+        std::string src, tgt;
+        std::vector<float> mel;            // [frames][nbanks] (par) or posteriors when in == post
+        std::vector<float> post;
+        int frames = 0, cols = 0;
+        std::string labels;                // formatted label / MLF text
+        bool ok = true;
+        std::string err;
+    };
+    bool ParseLine(const std::string &line, DataFormat out, bool mlf, Job &job);
+    bool RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf);
+    void Stage1(DataFormat in, DataFormat out, Job &job);              // load [+ front-end] [+ sentence norm]
+    void Stage3(DataFormat out, Job &job, bool mlf);                   // soft funcs, decode / dump
+    bool EnsureGpus();
+    void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
+    bool Fail(const std::string &msg) { err_ = msg; return false; }
+    std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
+
+    std::string config_dir_, err_;
+    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false;
+    WaveOptions wave_;
+    int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
+    float wpenalty_ = -2.0f;
+    bool wpenalty_set_ = false;
+    int states_per_phn_ = 1, time_pruning_ = 40;
+    std::string post_soft_ = "none", dec_soft_ = "log";
+    float post_soft_arg_[3] = {0, 0, 0}, dec_soft_arg_[3] = {0, 0, 0};
+    std::vector<std::string> phonemes_path_;
+    std::string phoneme_list_;
+    std::vector<std::unique_ptr<Traps>> gpus_;
+    RunStats stats_;
+    MelBanks mb_proto_;
+};
+
+// file-name helpers with the reference's semantics (filename.cpp:30-46,100-128)
+std::string ChangeFileSuffix(const std::string &name, const std::string &suffix);
+std::string ChangeFilePath(const std::string &name, const std::string &new_path);
+std::string GetFilePath(const std::string &name);
+
+}  // namespace phnrec
+#endif

@@ -1,0 +1,82 @@
+// traps.h -- host-side mirror of the reference's `class Traps` (traps.h:21-76) over the
+// C ABI of libphnrec_lcrc.so.  Same method names, argument meaning and call order as the
+// reference (setters, then Init(dir), then Reset()/CalcFeaturesBunched()), so code written
+// against the reference class reads the same; the work happens in the fused HIP kernel.
+// Differences, all deliberate: Init() reports failure by return value + LastError()
+// instead of exit(1); CalcUtterance()/CalcBatch() expose the whole-utterance forms the
+// GPU wants (ProcessOffline's prime/main/flush collapses into one launch).
+#ifndef PHNREC_HOST_TRAPS_H
+#define PHNREC_HOST_TRAPS_H
+
+#include <string>
+
+#include "../../../include/lcrc.h"
+
+namespace phnrec {
+
+class Traps {
+public:
+    Traps() = default;
+    ~Traps() { if (ctx_) lcrc_destroy(ctx_); }
+    Traps(const Traps &) = delete;
+    Traps &operator=(const Traps &) = delete;
+
+    // -- the reference's interface (traps.h:59-75) --
+    bool SetSystem(const char *sys) { system_ = sys; return system_ == "LCRC" || system_ == "3BT" || system_ == "1BT" || system_ == "1BT_DCT"; }
+    void SetTrapLen(int v) { trap_len_ = v; }
+    void SetHamming(bool v) { hamming_ = v; }
+    void SetNBanks(int v) { nbanks_ = v; }
+    void SetAddC0(bool v) { add_c0_ = v; }
+    void SetBunchSize(int v) { bunch_ = v; }        // grouping only; never changes values
+    bool Init(const char *dir)
+    {
+        if (system_ != "LCRC" || hamming_) {
+            err_ = "posteriors/system=" + system_ + (hamming_ ? " with hamming=true" : "") +
+                   " is not implemented on the GPU path (only LCRC, hamming=false)";
+            return false;
+        }
+        if (ctx_) { lcrc_destroy(ctx_); ctx_ = nullptr; }
+        const int rc = lcrc_create(&ctx_, dir, nbanks_, trap_len_, add_c0_ ? 1 : 0, device_);
+        if (rc != LCRC_OK) { err_ = lcrc_last_error(nullptr); ctx_ = nullptr; return false; }
+        return true;
+    }
+    void Reset() { lcrc_reset(ctx_); }
+    void CalcFeaturesBunched(float *band_energies, float *features, int n = 1, bool neededFea = true)
+    {
+        if (lcrc_push(ctx_, band_energies, n, features, neededFea ? 1 : 0) != LCRC_OK) err_ = lcrc_last_error(ctx_);
+    }
+    void CalcFeatures(float *band_energies, float *features, int n = 1, bool neededFea = true)
+    {
+        CalcFeaturesBunched(band_energies, features, n, neededFea);
+    }
+    int GetNumOuts() const { return lcrc_num_outputs(ctx_); }
+    int GetTrapShift() const { return (trap_len_ - 1) / 2; }
+    int GetDelay() const { return lcrc_delay(ctx_); }
+
+    // -- additions --
+    void SetDevice(int d) { device_ = d; }
+    bool CalcUtterance(const float *mel, int n, float *post)
+    {
+        if (lcrc_posteriors(ctx_, mel, n, post) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    bool CalcBatch(const float *mel, const int *off, int n_utts, float *post)
+    {
+        if (lcrc_posteriors_batch(ctx_, mel, off, n_utts, post) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
+    const std::string &LastError() const { return err_; }
+    bool Ready() const { return ctx_ != nullptr; }
+
+private:
+    lcrc_ctx *ctx_ = nullptr;
+    std::string system_ = "LCRC", err_;
+    int trap_len_ = 31, nbanks_ = 15, bunch_ = 1, device_ = 0;
+    bool hamming_ = false, add_c0_ = true;
+};
+
+}  // namespace phnrec
+#endif
