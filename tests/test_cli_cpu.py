@@ -1,0 +1,154 @@
+"""The drop-in `phnrec` CLI, host-only legs (no GPU): front-end (-t par), decoder (-s post),
+list / MLF modes, configuration and command-line errors -- against files produced by the
+reference CLI itself (tests/golden, tools/make_golden.py)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from phnrec_amd import modelgen
+from tests.util import GOLD, ROOT, model_dir, read_htk, read_htk_header
+
+BIN = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
+
+
+def run(*args, ok=True):
+    p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True)
+    if ok:
+        assert p.returncode == 0, p.stderr
+    return p
+
+
+def test_binary_exists():
+    assert os.path.exists(BIN), "build with make -C phnrec_amd/csrc"
+
+
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_front_end_dump_is_bit_identical(system, tmp_path):
+    out = tmp_path / "t.mel"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-t", "par", "-o", out)
+    gold = os.path.join(GOLD, system, "test.mel")
+    assert open(out, "rb").read() == open(gold, "rb").read()
+    n, period, size, kind = read_htk_header(str(out))
+    assert (period, kind) == (100000, 6) and size == 4 * modelgen.SYSTEMS[system]["nbanks"]
+
+
+def test_alaw_front_end(tmp_path):
+    out = tmp_path / "a.mel"
+    run("-c", model_dir(CZ), "-w", "alaw", "-i", os.path.join(GOLD, "test.raw"), "-t", "par", "-o", out)
+    assert open(out, "rb").read() == open(os.path.join(GOLD, "cli", "test_alaw.mel"), "rb").read()
+
+
+def _system_dir(tmp_path, system):
+    """Model dir for the decoder leg: the shipped one, or synthetic nets + the real config/phonemes."""
+    d = model_dir(system)
+    if d:
+        return d
+    d = str(tmp_path / system)
+    modelgen.write_system(d, system, seed=1)
+    shutil.copyfile(os.path.join(GOLD, system, "config"), os.path.join(d, "config"))
+    shutil.copyfile(os.path.join(GOLD, system, "phonemes"), os.path.join(d, "dicts", "phonemes"))
+    return d
+
+
+@pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
+def test_decoder_reproduces_reference_labels(system, tmp_path):
+    """post -> str on the reference's own posteriors: byte-identical .rec, and the same labels
+    and times as the label file SHIPPED with the reference (scores within 1e-2)."""
+    out = tmp_path / "t.rec"
+    run("-c", _system_dir(tmp_path, system), "-s", "post", "-i", os.path.join(GOLD, system, "test.lop"), "-o", out)
+    assert open(out).read() == open(os.path.join(GOLD, system, "test.rec")).read()
+    mine = [l.split() for l in open(out)]
+    shipped = [l.split() for l in open(os.path.join(GOLD, "rec", system + ".rec"))]
+    assert [m[:3] for m in mine] == [s[:3] for s in shipped]
+    assert max(abs(float(m[3]) - float(s[3])) for m, s in zip(mine, shipped)) < 1e-2
+    assert mine[0][0] == "000000"            # "%d00000" of frame 0, as the reference prints it
+
+
+def test_list_mode_mlf_and_derived_names(tmp_path):
+    data = tmp_path / "data"
+    data.mkdir()
+    for n in ("utt_a", "utt_b", "utt_c"):
+        shutil.copyfile(os.path.join(GOLD, "cli", n + ".lop"), data / (n + ".lop"))
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s\n" % (data / (n + ".lop")) for n in ("utt_a", "utt_b", "utt_c")))
+    mlf = tmp_path / "out.mlf"
+    run("-c", model_dir(CZ), "-s", "post", "-l", lst, "-m", mlf)
+    assert mlf.read_text() == open(os.path.join(GOLD, "cli", "list.mlf")).read()
+    # without -m: one label file next to each input, suffix labels/suffix
+    run("-c", model_dir(CZ), "-s", "post", "-l", lst)
+    for n in ("utt_a", "utt_b", "utt_c"):
+        assert (data / (n + ".rec")).read_text() == open(os.path.join(GOLD, "cli", n + ".rec")).read()
+    # two-column lines name the target explicitly
+    lst2 = tmp_path / "list2.txt"
+    lst2.write_text("%s \t %s\n" % (data / "utt_b.lop", tmp_path / "x.lab"))
+    run("-c", model_dir(CZ), "-s", "post", "-l", lst2, "-j", 2)
+    assert (tmp_path / "x.lab").read_text() == open(os.path.join(GOLD, "cli", "utt_b.rec")).read()
+
+
+def test_short_file_front_end_and_param_suffix(tmp_path):
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    (tmp_path / "utt_c.raw").write_bytes(raw[:3000])
+    lst = tmp_path / "l.txt"
+    lst.write_text("%s\n" % (tmp_path / "utt_c.raw"))
+    run("-c", model_dir(CZ), "-l", lst, "-t", "par")          # target derived with params/suffix = mel
+    assert (tmp_path / "utt_c.mel").read_bytes() == open(os.path.join(GOLD, "cli", "utt_c.mel"), "rb").read()
+    assert read_htk(str(tmp_path / "utt_c.mel")).shape == (17, 15)
+    # a signal shorter than one frame still yields one frame (srec.cpp:731,945)
+    (tmp_path / "tiny.raw").write_bytes(raw[:100])
+    run("-c", model_dir(CZ), "-i", tmp_path / "tiny.raw", "-t", "par", "-o", tmp_path / "tiny.mel")
+    assert read_htk(str(tmp_path / "tiny.mel")).shape == (1, 15)
+
+
+def test_insertion_penalty_option(tmp_path):
+    lop = os.path.join(GOLD, CZ, "test.lop")
+    run("-c", model_dir(CZ), "-s", "post", "-i", lop, "-o", tmp_path / "a.rec", "-p", "-4.6875")
+    run("-c", model_dir(CZ), "-s", "post", "-i", lop, "-o", tmp_path / "b.rec", "-p-20")
+    assert (tmp_path / "a.rec").read_text() == open(os.path.join(GOLD, CZ, "test.rec")).read()
+    assert len((tmp_path / "b.rec").read_text().splitlines()) < len((tmp_path / "a.rec").read_text().splitlines())
+
+
+def test_errors_match_the_reference_texts(tmp_path):
+    p = run("-i", "x", ok=False)
+    assert p.returncode == 1 and "ERROR: Configuration directory is not set (-c)" in p.stderr
+    p = run("-c", tmp_path / "none", "-i", "x", ok=False)
+    assert p.returncode == 1 and "Can not open configuration file" in p.stderr
+    d = tmp_path / "m"
+    modelgen.write_model_dir(str(d), 15, 32, 12, seed=1)
+    p = run("-c", d, "-s", "str", "-t", "par", "-i", "x", ok=False)
+    assert "Unsupported data conversion (-s, -t)" in p.stderr
+    p = run("-c", d, "-o", "y", ok=False)
+    assert "The input file is not specified (-i)" in p.stderr
+    p = run("-c", d, "-s", "foo", "-i", "x", ok=False)
+    assert "Invalid data format 'foo'" in p.stderr
+    p = run("-c", d, "-i", tmp_path / "missing.raw", "-t", "par", "-o", tmp_path / "o.mel", ok=False)
+    assert "Can not open waveform file" in p.stderr
+    p = run("-c", d, "-q", ok=False)
+    assert "Error during command line parsing" in p.stderr
+    # unknown configuration variable is fatal, with the line number (srec.cpp:242,251)
+    cfg = open(os.path.join(d, "config")).read().replace("[melbanks]\n", "[melbanks]\nbogus=1\n")
+    open(os.path.join(d, "config"), "w").write(cfg)
+    p = run("-c", d, "-i", "x", ok=False)
+    assert "Unknown variable in configuration file" in p.stderr and "line" in p.stderr
+    cfg = cfg.replace("bogus=1\n", "nbanks=abc\n")
+    open(os.path.join(d, "config"), "w").write(cfg)
+    p = run("-c", d, "-i", "x", ok=False)
+    assert "Invalid argument for a vatiable" in p.stderr
+    # a damaged model is reported at start-up, before any GPU is touched
+    d2 = tmp_path / "m2"
+    modelgen.write_model_dir(str(d2), 15, 32, 12, seed=1)
+    os.remove(os.path.join(d2, "weights", "band1.nbin"))
+    p = run("-c", d2, "-i", "x", ok=False)
+    assert "ERROR: Loading neural network" in p.stderr
+
+
+def test_verbose_banner(tmp_path):
+    p = run("-v", "-c", model_dir(CZ), "-s", "post", "-i", os.path.join(GOLD, CZ, "test.lop"), "-o", tmp_path / "v.rec")
+    for needle in ("System initialization", "- mel-banks ...", "- posteriors (loading NNs) ...",
+                   "------------------- SUMMARY -------------------", "Word penalty: -4.687500", "test.lop -> "):
+        assert needle in p.stdout
+    q = run("-c", model_dir(CZ), "-s", "post", "-i", os.path.join(GOLD, CZ, "test.lop"), "-o", tmp_path / "q.rec")
+    assert q.stdout == ""

@@ -1,0 +1,76 @@
+"""End-to-end through the drop-in CLI on the GPU: waveform -> labels / posteriors, against
+what the reference CLI wrote for the same inputs (tests/golden)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.util import GOLD, ROOT, model_dir, read_htk
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
+
+
+def run(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, env=e)
+    assert p.returncode == 0, p.stderr
+    return p
+
+
+def _labels_match(mine_path, gold_path):
+    mine = [l.split() for l in open(mine_path) if len(l.split()) == 4]
+    gold = [l.split() for l in open(gold_path) if len(l.split()) == 4]
+    assert [m[:3] for m in mine] == [g[:3] for g in gold], "labels / times differ from the reference"
+    assert max(abs(float(m[3]) - float(g[3])) for m, g in zip(mine, gold)) < 1e-2
+
+
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_bundled_utterance_end_to_end(system, tmp_path):
+    """the reference's own smoke test (test.sh): phnrec -c DIR -i test.raw -o test.rec"""
+    out = tmp_path / "t.rec"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-o", out)
+    _labels_match(out, os.path.join(GOLD, "rec", system + ".rec"))       # the SHIPPED golden
+    _labels_match(out, os.path.join(GOLD, system, "test.rec"))
+    lop = tmp_path / "t.lop"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-t", "post", "-o", lop)
+    got, want = read_htk(str(lop)), read_htk(os.path.join(GOLD, system, "test.lop"))
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-4
+
+
+def test_file_list_batched_over_the_gpu(tmp_path):
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    pieces = {"utt_a": raw, "utt_b": raw[:20000], "utt_c": raw[:3000]}
+    data = tmp_path / "data"
+    data.mkdir()
+    for n, blob in pieces.items():
+        (data / (n + ".raw")).write_bytes(blob)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s\n" % (data / (n + ".raw")) for n in pieces))
+    mlf = tmp_path / "out.mlf"
+    p = run("-c", model_dir(CZ), "-l", lst, "-m", mlf, "-g", 1, env={"PHNREC_STATS": "1"})
+    assert "frames=%d" % (747 + 123 + 17) in p.stderr
+    gold = open(os.path.join(GOLD, "cli", "list.mlf")).read().splitlines()
+    mine = mlf.read_text().splitlines()
+    assert len(mine) == len(gold)
+    for a, b in zip(mine, gold):
+        pa, pb = a.split(), b.split()
+        if len(pb) == 4:
+            assert pa[:3] == pb[:3] and abs(float(pa[3]) - float(pb[3])) < 1e-2
+        else:
+            assert a == b                       # "#!MLF!#", "*/utt_a.rec", "."
+    # posteriors of every piece (one launch for the three utterances vs one launch each)
+    run("-c", model_dir(CZ), "-l", lst, "-t", "post")
+    for n in pieces:
+        got = read_htk(str(data / (n + ".lop")))
+        want = read_htk(os.path.join(GOLD, "cli", n + ".lop"))
+        assert np.abs(got - want).max() < 1e-4, n
+    run("-c", model_dir(CZ), "-l", lst, "-t", "post", "-b", 1)    # one utterance per launch
+    for n in pieces:
+        got = read_htk(str(data / (n + ".lop")))
+        want = read_htk(os.path.join(GOLD, "cli", n + ".lop"))
+        assert np.abs(got - want).max() < 1e-4, n

@@ -113,7 +113,37 @@ def main():
         assert np.array_equal(post, lop), "shim-driven posteriors differ from the CLI dump"
         np.savez_compressed(os.path.join(out, "probe.npz"), rows=np.array(keep, np.int32),
                             **{key: v[keep] for key, v in probes.items()})
+        # config + phoneme list (tiny text) so the CLI's decoder can be tested on all four systems
+        shutil.copyfile(os.path.join(mdir, "config"), os.path.join(out, "config"))
+        shutil.copyfile(os.path.join(mdir, "dicts", "phonemes"), os.path.join(out, "phonemes"))
         print(sysname, "frames", n, "ok")
+
+    # -- CLI goldens (CZ): A-law front-end, list mode with an MLF, short files --
+    cz = "PHN_CZ_SPDAT_LCRC_N1500"
+    cli_dir = os.path.join(GOLD, "cli")
+    os.makedirs(cli_dir, exist_ok=True)
+    raw = open(os.path.join(REF, "test.raw"), "rb").read()
+    with tempfile.TemporaryDirectory() as td:
+        run([cli, "-c", os.path.join(REF, cz), "-w", "alaw", "-i", os.path.join(REF, "test.raw"), "-t", "par",
+             "-o", os.path.join(cli_dir, "test_alaw.mel")])
+        # three utterances cut from test.raw: full, 1.25 s, 0.19 s (17 frames: shorter than the context)
+        pieces = {"utt_a.raw": raw, "utt_b.raw": raw[:20000], "utt_c.raw": raw[:3000]}
+        sub = os.path.join(td, "data")
+        os.makedirs(sub)
+        for name, blob in pieces.items():
+            open(os.path.join(sub, name), "wb").write(blob)
+        lst = os.path.join(td, "list.txt")
+        open(lst, "w").write("".join(os.path.join(sub, n) + "\n" for n in pieces))
+        run([cli, "-c", os.path.join(REF, cz), "-l", lst, "-m", os.path.join(cli_dir, "list.mlf")])
+        run([cli, "-c", os.path.join(REF, cz), "-l", lst])          # one .rec next to each input
+        for name in pieces:
+            shutil.copyfile(os.path.join(sub, name[:-4] + ".rec"), os.path.join(cli_dir, name[:-4] + ".rec"))
+        run([cli, "-c", os.path.join(REF, cz), "-l", lst, "-t", "par"])   # one-column list, params/suffix
+        shutil.copyfile(os.path.join(sub, "utt_c.mel"), os.path.join(cli_dir, "utt_c.mel"))
+        for name in pieces:                                              # posteriors of each piece
+            run([cli, "-c", os.path.join(REF, cz), "-i", os.path.join(sub, name), "-t", "post",
+                 "-o", os.path.join(cli_dir, name[:-4] + ".lop")])
+    print("cli goldens ok")
 
     synth = {}
     for name, nb, hid, nout, seed, lens in SYNTH_CASES:
