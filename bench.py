@@ -189,6 +189,18 @@ def main():
                              "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
                              "flop_per_frame": flops_frame},
             }
+            if ranks.world == 1:
+                # the host-pointer entry point (pageable buffers in, pageable out): PCIe-inclusive,
+                # reported beside `value`, never as it
+                reps = 20
+                ctx.posteriors(mel)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.posteriors(mel)
+                dt = (time.perf_counter() - t0) / reps
+                line["host_path"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
+                                     "ms_per_call": round(dt * 1e3, 4),
+                                     "what": "lcrc_posteriors(): memcpy to pinned + H2D + kernel + D2H + memcpy, synchronous"}
             if ranks.world == 1 and not args.no_cpu:
                 gpu_post = d_post.cpu().numpy()
                 line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds)
