@@ -411,14 +411,13 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
-    // ---- fold the NW partial tiles: top two waves down by two until one is left ----
+    // ---- fold the NW partial tiles down to TWO slabs, then every thread sums the two while
+    //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
     const int slab_f4 = 2 * n_ot_slab * 64;     // float4 per slab
 #pragma unroll
-    for (int top = NW; top > 1; top -= (top > 2 ? 2 : 1)) {
-        const int nsrc = top > 2 ? 2 : 1;        // waves [top-nsrc, top) fold into [top-2*nsrc.. )
-        const int src0 = top - nsrc, dst0 = src0 - nsrc;
-        if (wave >= src0 && wave < top) {
-            f4 *s = slab + (wave - src0) * slab_f4 + lane;
+    for (int top = NW; top > 2; top -= 2) {      // waves [top-2, top) fold into [top-4, top-2)
+        if (wave >= top - 2 && wave < top) {
+            f4 *s = slab + (wave - (top - 2)) * slab_f4 + lane;
 #pragma unroll
             for (int ot = 0; ot < NOT; ot++)
                 if (EXACT || ot < n_ot) {
@@ -427,45 +426,41 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
                 }
         }
         __syncthreads();
-        if (wave >= dst0 && wave < src0) {
-            const f4 *s = slab + (wave - dst0) * slab_f4 + lane;
+        if (wave >= top - 4 && wave < top - 2) {
+            f4 *s = slab + (wave - (top - 4)) * slab_f4 + lane;
+            const bool last = top - 4 == 0;     // the two surviving waves publish their sums in place
 #pragma unroll
             for (int ot = 0; ot < NOT; ot++)
                 if (EXACT || ot < n_ot) {
                     acc[ot][0] += s[(ot * 2 + 0) * 64];
                     acc[ot][1] += s[(ot * 2 + 1) * 64];
+                    if (last) {
+                        s[(ot * 2 + 0) * 64] = acc[ot][0];
+                        s[(ot * 2 + 1) * 64] = acc[ot][1];
+                    }
                 }
         }
         __syncthreads();
     }
-
-    // ---- logits -> dense[frame][o] (slab 1); softmax in registers on all threads
-    //      (nn.cpp:822-855): LPF lanes share a frame, each holds every LPF-th output ----
-    float *dense = reinterpret_cast<float *>(slab + slab_f4);
-    const int os = 16 * n_ot_slab;
-    if (wave == 0) {
-#pragma unroll
-        for (int ot = 0; ot < NOT; ot++)
-            if (EXACT || ot < n_ot) {
-#pragma unroll
-                for (int f = 0; f < 2; f++)
-                    *reinterpret_cast<f4 *>(dense + (16 * f + (lane & 15)) * os + 16 * ot + 4 * g) = acc[ot][f];
-            }
-    }
-    __syncthreads();
+    // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a frame, each
+    // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
+    // frame = 16f + c  ->  float index ((2ot + f)*64 + 16g + c)*4 + rr.
     {
         constexpr int LPF = NW * 64 / kBM;       // lanes cooperating on one frame
         constexpr int NV = 16 * NOT / LPF;       // values per lane
         const int tid = wave * 64 + lane;
         const int frame = tid / LPF, part = tid % LPF;
-        const float *row = dense + frame * os;
+        const float *sa = reinterpret_cast<const float *>(slab);
+        const float *sb = sa + slab_f4 * 4;
+        const int fbase = ((frame >> 4) * 64 + (frame & 15)) * 4;
         const int O = nd.n_out;
         float v[NV];
         float m = -FLT_MAX;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
-            v[j] = o < O ? row[o] : -FLT_MAX;
+            const int idx = fbase + (o >> 4) * 512 + ((o >> 2) & 3) * 64 + (o & 3);
+            v[j] = o < O ? sa[idx] + sb[idx] : -FLT_MAX;
             m = fmaxf(m, v[j]);
         }
 #pragma unroll
@@ -481,6 +476,7 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
 #pragma unroll
         for (int d = 1; d < LPF; d <<= 1) sum += __shfl_xor(sum, d);
         const float scale = 1.0f / sum;
+        __syncthreads();                          // slabs are free again (the epilogue may reuse them)
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
@@ -544,12 +540,16 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         costab[i] = i < 160 ? p.costab[i] : p.win[i - 160];
     {
         const int w1n = 16 * nkq1, wmn = 16 * nkqm;
-        for (int i = tid; i < 4 * w1n; i += NT) {
-            const int n = i / (2 * w1n), k = i % w1n, isdev = (i / w1n) & 1;
-            nrm_band[i] = isdev ? p.net[n].dev[k] : p.net[n].mean[k];
+        for (int i = tid; i < w1n; i += NT) {
+            nrm_band[i] = p.net[0].mean[i];
+            nrm_band[w1n + i] = p.net[0].dev[i];
+            nrm_band[2 * w1n + i] = p.net[1].mean[i];
+            nrm_band[3 * w1n + i] = p.net[1].dev[i];
         }
-        for (int i = tid; i < 2 * wmn; i += NT)
-            nrm_merger[i] = i < wmn ? p.net[2].mean[i] : p.net[2].dev[i - wmn];
+        for (int i = tid; i < wmn; i += NT) {
+            nrm_merger[i] = p.net[2].mean[i];
+            nrm_merger[wmn + i] = p.net[2].dev[i];
+        }
         f4 *z = reinterpret_cast<f4 *>(xf);
         const int n = (int)((lp.slab - lp.xf) / 16);    // xf and gf are adjacent
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -559,49 +559,53 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 
     LCRC_STAMP(p, wave, lane, 1);
     // ---- stage 1: window * DCT projection + input normalisation (traps.cpp:285-343,
-    //      dspc.h:107-112,206-233, nn.cpp:702-716) ----
+    //      dspc.h:107-112,206-233, nn.cpp:702-716) as small MFMA products:
+    //      out[frame][c] = sum_tap (x[frame][tap] * win[tap]) * D[tap][c],  D[:,0] = 1 (C0), D[:,1..10] = cos.
+    //      A = windowed half context (16 frames x 4 taps per step, gathered from the mel tile with
+    //      clamped indices), B = basis (4 registers per lane, loaded once).  Taps are summed in
+    //      ascending order as in the reference; the MFMA fuses each multiply-add (<= 1 ulp apart
+    //      from the reference's separate mul and add). ----
     {
         const int K = p.net[0].n_inp;            // nbanks * 11
-        const int items = 2 * nb * kBM;
-        for (int it = tid; it < items; it += NT) {
-            const int i = it % kBM;
-            const int b = (it / kBM) % nb;
-            const int n = it / (kBM * nb);
-            const int r = min(r0 + i, p.n_rows - 1);
-            const int lo = rowlo[i], hi = rowhi[i];
-            float xw[kHalf];
+        const int g = lane >> 4, c = lane & 15;
+        float basis[4];
 #pragma unroll
-            for (int j = 0; j < kHalf; j++) {
-                int s = r - kShift + n * kShift + j;
-                s = max(lo, min(hi, s));
-                xw[j] = melT[(s - tbase) * nb + b] * win[n * kHalf + j];
-            }
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int tap = 4 * s4 + g;
+            basis[s4] = c == 0 ? 1.0f : (c < kNCoef ? costab[(c - 1) * 16 + tap] : 0.0f);
+        }
+        const int items = 2 * nb;                // (net, band) pairs, dealt to the waves
+        for (int it = wave; it < items; it += NW) {
+            const int n = it / nb, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (2 * nkq1 * 256);
             float *dbg = n == 0 ? p.dbg_in0 : p.dbg_in1;
-            const bool dbg_on = dbg && r0 + i < p.n_rows;
-            float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kHalf; j++) sum += xw[j];
-            sum *= p.normc;                                          // CalcC0
-            {
-                const int k = b * kNCoef;
-                if (dbg_on) dbg[(size_t)(r0 + i) * K + k] = sum;
-                float v = sum - mean[k];
-                v *= dev[k];
-                xf_store(img, nkq1, i, k, v);
-            }
-#pragma unroll 2
-            for (int c = 0; c < kNCoef - 1; c++) {                   // sDCT
-                float acc = 0.0f;
+            for (int f = 0; f < 2; f++) {
+                const int i = 16 * f + c;        // this lane's frame as an A-operand row
+                const int r = min(r0 + i, p.n_rows - 1);
+                const int lo = rowlo[i], hi = rowhi[i];
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < kHalf; j++) acc += xw[j] * costab[c * 16 + j];
-                acc *= p.normc;
-                const int k = b * kNCoef + 1 + c;
-                if (dbg_on) dbg[(size_t)(r0 + i) * K + k] = acc;
-                float v = acc - mean[k];
-                v *= dev[k];
-                xf_store(img, nkq1, i, k, v);
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const int tap = 4 * s4 + g;
+                    const int srow = max(lo, min(hi, r - kShift + n * kShift + tap));
+                    const float xw = melT[(srow - tbase) * nb + b] * win[n * kHalf + tap];
+                    acc = mfma16x16x4(xw, basis[s4], acc);
+                }
+                if (c < kNCoef) {                // D layout: row = frame 16f + 4g + reg, col = c
+                    const int k = b * kNCoef + c;
+                    const float mk = mean[k], dk = dev[k];
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int fr = 16 * f + 4 * g + reg;
+                        const float val = acc[reg] * p.normc;            // CalcC0 / sDCT scaling
+                        if (dbg && r0 + fr < p.n_rows) dbg[(size_t)(r0 + fr) * K + k] = val;
+                        float v = val - mk;                              // Normalize nn.cpp:702-716
+                        v *= dk;
+                        xf_store(img, nkq1, fr, k, v);
+                    }
+                }
             }
         }
     }
