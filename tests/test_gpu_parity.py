@@ -189,3 +189,75 @@ def test_device_pointer_entry_and_determinism(capi, tmp_path):
     assert ctx.last_kernel_ms() > 0
     again = ctx.posteriors(mel)
     assert np.array_equal(again, host), "the kernel must be run-to-run deterministic"
+
+
+# ---- BASELINE.json full-size configurations: size-independent properties + oracle spot checks ----
+
+def _spot_check(ctx, o, mel, post, starts, width=48):
+    """oracle rows [a, a+width) of a long utterance need only mel[a-15 : a+width+15]"""
+    n = mel.shape[0]
+    for a in starts:
+        lo, hi = max(0, a - 15), min(n, a + width + 15)
+        want = o.posteriors(mel[lo:hi])[a - lo:a - lo + width]
+        assert np.abs(post[a:a + width] - want).max() < TOL, a
+
+
+@pytest.mark.parametrize("system,batch", [("PHN_EN_TIMIT_LCRC_N500", 4096), ("PHN_CZ_SPDAT_LCRC_N1500", 8192)])
+def test_baseline_batch_sizes(capi, oracle_mod, system, batch):
+    """configs[1] (EN, 4096 frames) and configs[2] (CZ, 8192 frames) at full size"""
+    spec = modelgen.SYSTEMS[system]
+    nb = spec["nbanks"]
+    mel = modelgen.synth_mel(batch, nb, seed=77, mean_norm=spec["sent_mean_norm"])
+    ctx = capi.Lcrc(model_dir(system), nb)
+    o = oracle_mod.Oracle(model_dir(system), nb)
+    post = ctx.posteriors(mel)
+    assert np.isfinite(post).all() and (post >= 0).all()
+    assert np.abs(post.sum(axis=1) - 1).max() < 1e-5                 # every frame is a distribution
+    _spot_check(ctx, o, mel, post, [0, 17, batch // 2 - 5, batch - 48])
+    # idempotence / determinism at full size
+    assert np.array_equal(ctx.posteriors(mel), post)
+    # locality: cutting the batch into two utterances changes only rows within 15 frames of the cut
+    cut = batch // 2 + 7
+    two = ctx.posteriors_batch(mel, np.array([0, cut, batch], np.int32))
+    same = np.ones(batch, bool)
+    same[cut - 15:cut + 15] = False
+    assert np.array_equal(two[same], post[same])
+    assert not np.array_equal(two[cut - 15:cut + 15], post[cut - 15:cut + 15])
+    # and each half equals the stand-alone run of that half
+    assert np.array_equal(two[:cut], ctx.posteriors(mel[:cut]))
+    assert np.array_equal(two[cut:], ctx.posteriors(mel[cut:]))
+
+
+def test_sharded_file_list_shape(capi, oracle_mod, tmp_path):
+    """configs[3]-like: HU-shaped nets, a list of ragged 3-15 s utterances in multi-utterance launches"""
+    d = str(tmp_path / "hu")
+    modelgen.write_system(d, "PHN_HU_SPDAT_LCRC_N1500", seed=5)
+    ctx = capi.Lcrc(d, 15)
+    assert ctx.kernel_name == "hu_42_93_12"
+    o = oracle_mod.Oracle(d, 15)
+    rng = np.random.default_rng(9)
+    lens = rng.integers(300, 1501, size=40)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    mel = np.concatenate([modelgen.synth_mel(int(n), 15, seed=500 + i) for i, n in enumerate(lens)])
+    post = ctx.posteriors_batch(mel, off)
+    assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
+    for u in (0, 7, 39):                                          # whole utterances, bit for bit
+        a, b = int(off[u]), int(off[u + 1])
+        assert np.array_equal(post[a:b], ctx.posteriors(mel[a:b]))
+    u = 3                                                          # first / last frames of an utterance vs the oracle
+    a, b = int(off[u]), int(off[u + 1])
+    want_head = o.posteriors(mel[a:a + 40 + 15])[:40]
+    want_tail = o.posteriors(mel[b - 40 - 15:b])[-40:]
+    assert np.abs(post[a:a + 40] - want_head).max() < TOL
+    assert np.abs(post[b - 40:b] - want_tail).max() < TOL
+
+
+def test_large_launch(capi):
+    """a 200k-frame launch (6250 workgroups): grid-stride independence, no overflow in addressing"""
+    system = "PHN_EN_TIMIT_LCRC_N500"
+    ctx = capi.Lcrc(model_dir(system), 23)
+    mel = np.tile(modelgen.synth_mel(1000, 23, seed=3, mean_norm=False), (200, 1))
+    post = ctx.posteriors(mel)
+    assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
+    # interior repetitions of the 1000-frame block see identical contexts except across block seams
+    assert np.array_equal(post[1000 + 15:2000 - 15], post[150000 + 15:151000 - 15])
