@@ -18,10 +18,13 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.gpus = gpus
+        self.launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
         self.pg = False
 
     def init(self, backend):
-        if self.world > 1:
+        # also under a launcher with a single rank, so that the rendezvous / RCCL path is the one
+        # exercised whenever the driver starts us through torch.distributed.run
+        if self.world > 1 or (self.launched and backend == "nccl"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
