@@ -101,6 +101,15 @@ int lcrc_posteriors_batch(lcrc_ctx *ctx, const float *mel, const int *off, int n
 int lcrc_posteriors_device(lcrc_ctx *ctx, const float *d_mel, const int *d_off, int n_utts,
                            int n_rows, float *d_post, void *hip_stream);
 
+/* Zero-copy variant of lcrc_posteriors_batch for callers that assemble batches themselves
+ * (this repository's SpeechRec does): lcrc_stage_buffers returns pinned host buffers owned
+ * by the context with room for `rows` frames (valid until the next lcrc_stage_buffers call
+ * with a larger size, or lcrc_destroy); the caller writes mel[rows][nbanks] into *mel,
+ * calls lcrc_stage_run (H2D, kernel, D2H, synchronous) and reads post[rows][n_out] from
+ * *post.  `rows` of lcrc_stage_run is off[n_utts]. */
+int lcrc_stage_buffers(lcrc_ctx *ctx, int rows, float **mel, float **post);
+int lcrc_stage_run(lcrc_ctx *ctx, const int *off, int n_utts);
+
 /* Test/diagnostic variant of lcrc_posteriors that also returns the stage
  * outputs the reference keeps in Traps::band_input / band_output /
  * merger_input (traps.h:27-29).  Any of the probe pointers may be NULL.

@@ -17,6 +17,7 @@ SYMBOLS = [
     "lcrc_create", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
+    "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_kernel_name",
 ]
@@ -94,6 +95,8 @@ def load():
     L.lcrc_posteriors_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
     L.lcrc_posteriors_probe.argtypes = [vp, _f32p, C.c_int, _f32p] + [vp] * 5
     L.lcrc_push.argtypes = [vp, _f32p, C.c_int, vp, C.c_int]
+    L.lcrc_stage_buffers.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
+    L.lcrc_stage_run.argtypes = [vp, _i32p, C.c_int]
     L.lcrc_model_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t,
                                   C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -167,6 +170,18 @@ class Lcrc:
         post = np.zeros((mel.shape[0], self.n_out), np.float32)
         self._check(self.L.lcrc_posteriors_batch(self.h, mel, off, len(off) - 1, post))
         return post
+
+    def posteriors_staged(self, mel, off):
+        """lcrc_stage_buffers + lcrc_stage_run: the caller writes into the context's pinned buffers"""
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        n = mel.shape[0]
+        pm, pp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        self._check(self.L.lcrc_stage_buffers(self.h, n, C.byref(pm), C.byref(pp)))
+        if n:
+            np.ctypeslib.as_array(pm, shape=(n, self.nbanks))[:] = mel
+        self._check(self.L.lcrc_stage_run(self.h, off, len(off) - 1))
+        return np.ctypeslib.as_array(pp, shape=(n, self.n_out)).copy() if n else np.zeros((0, self.n_out), np.float32)
 
     def posteriors_probe(self, mel):
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)

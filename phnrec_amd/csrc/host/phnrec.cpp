@@ -143,9 +143,10 @@ int main(int argc, char **argv)
 
     if (getenv("PHNREC_STATS")) {
         const RunStats &s = SR.Stats();
-        fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f\n",
+        fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f "
+                        "(front_end_s=%.3f setup_s=%.3f)\n",
                 s.files, s.frames, s.seconds, s.seconds > 0 ? s.frames / s.seconds : 0.0,
-                s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms);
+                s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds);
     }
     return 0;
 }

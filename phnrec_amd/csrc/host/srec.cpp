@@ -56,18 +56,63 @@ std::string GetFilePath(const std::string &name)
     return sep == std::string::npos ? std::string() : name.substr(0, sep);
 }
 
-static void ParallelFor(int n, int threads, const std::function<void(int)> &fn)
+struct Group {
+    std::mutex mu;
+    std::condition_variable cv;
+    int pending = 0;
+};
+
+ThreadPool::ThreadPool(int n)
 {
-    if (threads <= 1 || n <= 1) {
+    for (int i = 0; i < n; i++) threads_.emplace_back([this] { Run(); });
+}
+
+ThreadPool::~ThreadPool()
+{
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+}
+
+void ThreadPool::Run()
+{
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [this] { return stop_ || !queue_.empty(); });
+            if (queue_.empty()) return;
+            t = queue_.front();
+            queue_.pop_front();
+        }
+        for (int i = t.begin; i < t.end; i++) (*t.fn)(i);
+        std::lock_guard<std::mutex> l(t.group->mu);
+        if (--t.group->pending == 0) t.group->cv.notify_all();
+    }
+}
+
+void ThreadPool::ParallelFor(int n, const std::function<void(int)> &fn)
+{
+    if (n <= 0) return;
+    if (threads_.empty() || n == 1) {
         for (int i = 0; i < n; i++) fn(i);
         return;
     }
-    std::atomic<int> next(0);
-    std::vector<std::thread> pool;
-    const int t = threads < n ? threads : n;
-    for (int k = 0; k < t; k++)
-        pool.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
-    for (auto &th : pool) th.join();
+    // a few chunks per worker keeps the tail short without flooding the queue
+    const int chunks = std::min(n, 4 * (int)threads_.size());
+    Group g;
+    g.pending = chunks;
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        for (int c = 0; c < chunks; c++)
+            queue_.push_back(Task{&fn, (int)((long long)n * c / chunks), (int)((long long)n * (c + 1) / chunks), &g});
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l(g.mu);
+    g.cv.wait(l, [&g] { return g.pending == 0; });
 }
 
 // posteriors/softening_func and decoder/softening_func (srec.cpp:164-176, srec.h:192-194)
@@ -211,7 +256,8 @@ bool SpeechRec::EnsureGpus()
     if (!gpus_.empty()) return true;
     int n = n_gpus_;
     if (n <= 0) n = 1;
-    for (int d = 0; d < n; d++) {
+    for (int k = 0; k < 2 * n; k++) {              // two contexts per GPU: one stages / decodes while
+        const int d = k / 2;                       // the other's launch is in flight
         std::unique_ptr<Traps> t(new Traps);
         t->SetSystem(C.GetString("posteriors", "system").c_str());
         t->SetTrapLen(C.GetInt("posteriors", "length"));
@@ -285,7 +331,7 @@ void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
         SentenceMeanNorm(job.mel.data(), job.frames, nbanks_);
 }
 
-void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf)
+void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols)
 {
     char msg[1200];
     if (out == dfParams) {
@@ -296,26 +342,28 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf)
         return;
     }
     if (out == dfPosteriors) {
-        if (!SaveHTK(job.tgt, job.post.data(), job.frames, job.cols)) {
+        if (!SaveHTK(job.tgt, post, job.frames, cols)) {
             snprintf(msg, sizeof msg, "Can not create file: %s\n", job.tgt.c_str());
             job.ok = false; job.err = msg;
         }
         return;
     }
     // strings: decoder softening (log), Viterbi, labels
-    for (float &v : job.post) v = Soften(dec_soft_, v, dec_soft_arg_);
+    const size_t nvals = (size_t)job.frames * cols;
+    if (dec_soft_ == "log") for (size_t i = 0; i < nvals; i++) post[i] = logf(post[i]);
+    else for (size_t i = 0; i < nvals; i++) post[i] = Soften(dec_soft_, post[i], dec_soft_arg_);
     PhnDec dec;
     dec.LoadPhnList(phoneme_list_);
     dec.SetStatesPerPhn(states_per_phn_);
     dec.SetTimePruning(time_pruning_);
     dec.SetWPenalty(wpenalty_);
     dec.Init();
-    if (job.cols < dec.NumPhonemes() * states_per_phn_) {
+    if (cols < dec.NumPhonemes() * states_per_phn_) {
         job.ok = false;
         job.err = "posterior vectors are shorter than the phoneme list needs\n";
         return;
     }
-    for (int r = 0; r < job.frames; r++) dec.ProcessFrame(&job.post[(size_t)r * job.cols]);
+    for (int r = 0; r < job.frames; r++) dec.ProcessFrame(post + (size_t)r * cols);
     dec.Done();
     std::string text;
     if (mlf) {
@@ -366,20 +414,33 @@ bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job
 bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    const int threads = host_threads_ > 0 ? host_threads_ : (int)std::max(1u, std::thread::hardware_concurrency());
+    if (!pool_) {
+        const int threads = host_threads_ > 0 ? host_threads_ : (int)std::max(1u, std::thread::hardware_concurrency());
+        pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
+    }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
         if (!EnsureGpus()) return false;
     }
+    const auto t1 = std::chrono::steady_clock::now();
+    stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
     const int n = (int)jobs.size();
     for (const Job &j : jobs) Log(j.tgt.empty() ? j.src + "\n" : j.src + " -> " + j.tgt + "\n");
-    ParallelFor(n, threads, [&](int i) { Stage1(in, out, jobs[i]); });
+    pool_->ParallelFor(n, [&](int i) { Stage1(in, out, jobs[i]); });
     for (const Job &j : jobs) if (!j.ok) return Fail(j.err);
+    stats_.stage1_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 
-    if (need_gpu) {
-        // consecutive utterances are packed into launches of <= batch_frames_ frames;
-        // the GPUs pull launches from one queue (no exchange, every GPU holds all weights)
+    if (!need_gpu) {
+        pool_->ParallelFor(n, [&](int i) {
+            Job &j = jobs[i];
+            Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
+        });
+    } else {
+        // Consecutive utterances are packed into launches of <= batch_frames_ frames.  The GPU
+        // contexts pull launches from one queue (no exchange between GPUs: every context holds all
+        // weights).  Per launch: features are gathered straight into the context's pinned staging
+        // buffer, and the decoder / HTK writer read the posteriors straight out of it.
         std::vector<std::pair<int, int>> batches;      // [first, last) job index
         for (int i = 0; i < n;) {
             int j = i, frames = 0;
@@ -391,31 +452,31 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
         std::atomic<bool> failed(false);
         std::vector<std::string> errs(gpus_.size());
         std::vector<double> kms(gpus_.size(), 0.0);
+        const bool soften_post = post_soft_ != "none";
         auto worker = [&](int g) {
             Traps &tr = *gpus_[g];
-            std::vector<float> mel, post;
             std::vector<int> off;
             for (int b; (b = next.fetch_add(1)) < (int)batches.size() && !failed;) {
+                const int first = batches[b].first, cnt = batches[b].second - first;
                 off.assign(1, 0);
-                mel.clear();
-                for (int i = batches[b].first; i < batches[b].second; i++) {
-                    mel.insert(mel.end(), jobs[i].mel.begin(), jobs[i].mel.end());
-                    off.push_back(off.back() + jobs[i].frames);
-                }
-                post.resize((size_t)off.back() * n_out_);
-                if (!tr.CalcBatch(mel.data(), off.data(), (int)off.size() - 1, post.data())) {
-                    errs[g] = tr.LastError();
-                    failed = true;
-                    return;
-                }
-                if (off.back() > 0) kms[g] += tr.LastKernelMs();
-                for (int i = batches[b].first, k = 0; i < batches[b].second; i++, k++) {
-                    Job &j = jobs[i];
-                    j.post.assign(post.begin() + (size_t)off[k] * n_out_, post.begin() + (size_t)off[k + 1] * n_out_);
-                    j.cols = n_out_;
+                for (int k = 0; k < cnt; k++) off.push_back(off.back() + jobs[first + k].frames);
+                float *h_mel = nullptr, *h_post = nullptr;
+                if (!tr.StageBuffers(off.back(), &h_mel, &h_post)) { errs[g] = tr.LastError(); failed = true; return; }
+                pool_->ParallelFor(cnt, [&](int k) {
+                    Job &j = jobs[first + k];
+                    memcpy(h_mel + (size_t)off[k] * nbanks_, j.mel.data(), j.mel.size() * sizeof(float));
                     std::vector<float>().swap(j.mel);
-                    if (post_soft_ != "none") for (float &v : j.post) v = Soften(post_soft_, v, post_soft_arg_);
-                }
+                });
+                if (!tr.StageRun(off.data(), cnt)) { errs[g] = tr.LastError(); failed = true; return; }
+                if (off.back() > 0) kms[g] += tr.LastKernelMs();
+                pool_->ParallelFor(cnt, [&](int k) {
+                    Job &j = jobs[first + k];
+                    float *post = h_post + (size_t)off[k] * n_out_;
+                    j.cols = n_out_;
+                    if (soften_post)
+                        for (size_t i = 0; i < (size_t)j.frames * n_out_; i++) post[i] = Soften(post_soft_, post[i], post_soft_arg_);
+                    Stage3(out, j, mlf != nullptr, post, n_out_);
+                });
             }
         };
         std::vector<std::thread> gt;
@@ -427,13 +488,12 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
         }
         for (const Job &j : jobs) stats_.frames += j.frames;
     }
-    ParallelFor(n, threads, [&](int i) { Stage3(out, jobs[i], mlf != nullptr); });
     for (Job &j : jobs) {
         if (!j.ok) return Fail(j.err);
         if (mlf) fputs(j.labels.c_str(), mlf);
     }
     stats_.files += n;
-    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     return true;
 }
 

@@ -12,7 +12,12 @@
 #define PHNREC_HOST_SREC_H
 
 #include <cstdio>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -28,7 +33,27 @@ DataFormat ParseDataFormat(const std::string &s);          // wf | par | post | 
 
 struct RunStats {
     long long frames = 0, files = 0;
-    double seconds = 0, gpu_kernel_ms = 0;
+    double seconds = 0, gpu_kernel_ms = 0;      // seconds: processing without one-off GPU/pool set-up
+    double init_seconds = 0, stage1_seconds = 0;
+};
+
+// Persistent worker pool; ParallelFor may be called from several threads at once (each GPU
+// worker farms its gather / decode loops out to the same pool).
+class ThreadPool {
+public:
+    explicit ThreadPool(int n);
+    ~ThreadPool();
+    void ParallelFor(int n, const std::function<void(int)> &fn);
+    int Size() const { return (int)threads_.size(); }
+
+private:
+    struct Task { const std::function<void(int)> *fn; int begin, end; struct Group *group; };
+    void Run();
+    std::vector<std::thread> threads_;
+    std::deque<Task> queue_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
 };
 
 class SpeechRec {
@@ -60,7 +85,8 @@ private:
     bool ParseLine(const std::string &line, DataFormat out, bool mlf, Job &job);
     bool RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf);
     void Stage1(DataFormat in, DataFormat out, Job &job);              // load [+ front-end] [+ sentence norm]
-    void Stage3(DataFormat out, Job &job, bool mlf);                   // soft funcs, decode / dump
+    // soft funcs, decode / dump; `post` = job.frames x cols posteriors (writable)
+    void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols);
     bool EnsureGpus();
     void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
     bool Fail(const std::string &msg) { err_ = msg; return false; }
@@ -77,7 +103,8 @@ private:
     float post_soft_arg_[3] = {0, 0, 0}, dec_soft_arg_[3] = {0, 0, 0};
     std::vector<std::string> phonemes_path_;
     std::string phoneme_list_;
-    std::vector<std::unique_ptr<Traps>> gpus_;
+    std::vector<std::unique_ptr<Traps>> gpus_;        // two contexts per GPU (alternating launches)
+    std::unique_ptr<ThreadPool> pool_;
     RunStats stats_;
     MelBanks mb_proto_;
 };

@@ -67,6 +67,19 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // zero-copy staging (lcrc_stage_buffers / lcrc_stage_run)
+    bool StageBuffers(int rows, float **mel, float **post)
+    {
+        if (lcrc_stage_buffers(ctx_, rows, mel, post) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    bool StageRun(const int *off, int n_utts)
+    {
+        if (lcrc_stage_run(ctx_, off, n_utts) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

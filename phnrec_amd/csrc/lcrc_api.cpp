@@ -409,6 +409,44 @@ int lcrc_posteriors_batch(lcrc_ctx *c, const float *mel, const int *off, int n_u
     return run_host(c, mel, off, n_utts, n, post, nullptr);
 }
 
+int lcrc_stage_buffers(lcrc_ctx *c, int rows, float **mel, float **post)
+{
+    if (!c || rows < 0 || !mel || !post) return LCRC_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, rows > 0 ? rows : 1, 1);
+    if (rc) return rc;
+    *mel = c->h_mel;
+    *post = c->h_post;
+    return LCRC_OK;
+}
+
+int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
+{
+    if (!c || !off || n_utts < 1 || off[0] != 0) return fail(c, LCRC_E_ARG, "lcrc_stage_run: bad argument");
+    for (int u = 0; u < n_utts; u++)
+        if (off[u + 1] < off[u]) return fail(c, LCRC_E_ARG, "lcrc_stage_run: offsets must be non-decreasing");
+    const int n = off[n_utts];
+    if (n == 0) return LCRC_OK;
+    if ((size_t)n > c->cap_rows) return fail(c, LCRC_E_ARG, "lcrc_stage_run: more rows than lcrc_stage_buffers reserved");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nb = c->nbanks, O = c->nets[2].n_out;
+    // only the offsets still have to be staged; the frame buffers are the pinned ones already
+    float *keep_mel = c->h_mel, *keep_post = c->h_post, *dm = c->d_mel, *dp = c->d_post;
+    const size_t keep_cap = c->cap_rows;
+    int rc = ensure_staging(c, keep_cap, n_utts);
+    if (rc) return rc;
+    if (c->h_mel != keep_mel || c->h_post != keep_post || c->d_mel != dm || c->d_post != dp)
+        return fail(c, LCRC_E_NOMEM, "lcrc_stage_run: staging buffers moved");
+    memcpy(c->h_off, off, (size_t)(n_utts + 1) * sizeof(int));
+    HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = launch(c, c->d_mel, c->d_off, n_utts, n, c->d_post, c->stream, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return LCRC_OK;
+}
+
 int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows,
                            float *d_post, void *hip_stream)
 {

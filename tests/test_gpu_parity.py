@@ -261,3 +261,15 @@ def test_large_launch(capi):
     assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
     # interior repetitions of the 1000-frame block see identical contexts except across block seams
     assert np.array_equal(post[1000 + 15:2000 - 15], post[150000 + 15:151000 - 15])
+
+
+def test_staged_zero_copy_entry_equals_batch(capi, tmp_path):
+    """lcrc_stage_buffers / lcrc_stage_run (what the CLI uses) vs lcrc_posteriors_batch, incl. buffer regrowth"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 80, 27, seed=6)
+    ctx = capi.Lcrc(d, 15)
+    for lens in ([40, 3, 0, 25], [700, 1, 900], [5]):
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), 15, seed=len(lens))
+        assert np.array_equal(ctx.posteriors_staged(mel, off), ctx.posteriors_batch(mel, off))
+    assert ctx.posteriors_staged(np.zeros((0, 15), np.float32), np.array([0, 0], np.int32)).shape == (0, 27)
