@@ -118,6 +118,38 @@ int lcrc_stage_run(lcrc_ctx *ctx, const int *off, int n_utts);
 int lcrc_posteriors_probe(lcrc_ctx *ctx, const float *mel, int n, float *post,
                           float *in0, float *in1, float *p0, float *p1, float *g);
 
+/* ---- waveform entry ("next" row of the path: the mel-bank front-end on the GPU) -----------
+ * Replaces, for whole files, the wf -> par block of SpeechRec::ProcessOffline
+ * (srec.cpp:939-999): ConvertWaveformFormat, MelBanks::GetFeatures per frame, and the
+ * sentence mean normalisation, with the values SpeechRec::Init hands to MelBanks
+ * (srec.cpp:537-561).  The FFT, window and mel filters follow the reference operation by
+ * operation (ln is evaluated in double and rounded once: last-bit agreement with glibc's logf in
+ * all but rare cases).  source/noise_level
+ * (libc rand()) has no device equivalent and is not offered. */
+typedef struct lcrc_frontend {
+    int wave_format;         /* 1 = lin16 (host byte order), 2 = A-law                     source/format      */
+    int sample_freq;         /*                                                            source/sample_freq */
+    int vector_size;         /* samples per frame (<= 512)                                 melbanks/vector_size */
+    int vector_step;         /*                                                            melbanks/vector_step */
+    int nbanks_full;         /* -1 = nbanks                                                melbanks/nbanks_full */
+    float lower_freq, higher_freq, preem_coef;            /*                               melbanks/...       */
+    float scale, dc_shift;   /*                                                            source/scale, dc_shift */
+    int z_mean_source;       /*                                                            melbanks/z_mean_source */
+    int sent_mean_norm;      /* applied before the posteriors, never to lcrc_wave_to_mel   offlinenorm/sent_mean_norm */
+} lcrc_frontend;
+
+int lcrc_frontend_configure(lcrc_ctx *ctx, const lcrc_frontend *cfg);
+/* frames a file of n_bytes yields: len > vs ? (len - vs)/step + 1 : 1   (srec.cpp:945) */
+int lcrc_frontend_frames(const lcrc_ctx *ctx, long long n_bytes);
+/* bytes: the raw files back to back (no header parsing, like the reference); byte_off[n_utts+1].
+ * frame_off (out, [n_utts+1]) receives the first row of each utterance.  mel / post must have
+ * room for sum of lcrc_frontend_frames() rows.  lcrc_wave_to_mel returns the features BEFORE
+ * sentence normalisation (what `-t par` dumps). */
+int lcrc_wave_to_mel(lcrc_ctx *ctx, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                     float *mel, int *frame_off);
+int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const long long *byte_off,
+                            int n_utts, float *post, int *frame_off);
+
 /* ---- streaming form (Traps semantics) -----------------------------------------
  * lcrc_reset == Traps::Reset (traps.cpp:174-177).
  * lcrc_push  == Traps::CalcFeaturesBunched(mel, post, n, needed)

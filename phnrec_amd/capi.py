@@ -18,6 +18,7 @@ SYMBOLS = [
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_stage_buffers", "lcrc_stage_run",
+    "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_kernel_name",
 ]
@@ -27,6 +28,14 @@ LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class Frontend(C.Structure):
+    """struct lcrc_frontend (include/lcrc.h)"""
+    _fields_ = [("wave_format", C.c_int), ("sample_freq", C.c_int), ("vector_size", C.c_int),
+                ("vector_step", C.c_int), ("nbanks_full", C.c_int), ("lower_freq", C.c_float),
+                ("higher_freq", C.c_float), ("preem_coef", C.c_float), ("scale", C.c_float),
+                ("dc_shift", C.c_float), ("z_mean_source", C.c_int), ("sent_mean_norm", C.c_int)]
 
 
 class LcrcError(RuntimeError):
@@ -97,6 +106,12 @@ def load():
     L.lcrc_push.argtypes = [vp, _f32p, C.c_int, vp, C.c_int]
     L.lcrc_stage_buffers.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
     L.lcrc_stage_run.argtypes = [vp, _i32p, C.c_int]
+    L.lcrc_frontend_configure.argtypes = [vp, C.POINTER(Frontend)]
+    L.lcrc_frontend_frames.argtypes = [vp, C.c_longlong]
+    _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    L.lcrc_wave_to_mel.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
+    L.lcrc_wave_to_posteriors.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
     L.lcrc_model_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t,
                                   C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -182,6 +197,37 @@ class Lcrc:
             np.ctypeslib.as_array(pm, shape=(n, self.nbanks))[:] = mel
         self._check(self.L.lcrc_stage_run(self.h, off, len(off) - 1))
         return np.ctypeslib.as_array(pp, shape=(n, self.n_out)).copy() if n else np.zeros((0, self.n_out), np.float32)
+
+    # -- waveform entry (GPU mel-bank front-end) --
+    def configure_frontend(self, wave_format="lin16", sample_freq=8000, vector_size=200, vector_step=80,
+                           nbanks_full=-1, lower_freq=64.0, higher_freq=4000.0, preem_coef=0.0, scale=1.0,
+                           dc_shift=0.0, z_mean_source=False, sent_mean_norm=True):
+        fe = Frontend({"lin16": 1, "alaw": 2}[wave_format], sample_freq, vector_size, vector_step, nbanks_full,
+                      lower_freq, higher_freq, preem_coef, scale, dc_shift, int(z_mean_source), int(sent_mean_norm))
+        self._check(self.L.lcrc_frontend_configure(self.h, C.byref(fe)))
+
+    def frontend_frames(self, n_bytes):
+        n = self.L.lcrc_frontend_frames(self.h, n_bytes)
+        if n < 0:
+            raise LcrcError(n, "front-end not configured (lcrc_frontend_configure)")
+        return n
+
+    def _wave(self, fn, blobs, width):
+        blobs = [bytes(b) for b in blobs]
+        off = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.int64)
+        raw = np.frombuffer(b"".join(blobs) + b"\0", dtype=np.uint8).copy()
+        rows = sum(self.frontend_frames(len(b)) for b in blobs)
+        out = np.zeros((rows, width), np.float32)
+        foff = np.zeros(len(blobs) + 1, np.int32)
+        self._check(fn(self.h, raw, off, len(blobs), out, foff))
+        return out, foff
+
+    def wave_to_mel(self, blobs):
+        """raw files (bytes objects) -> (mel BEFORE sentence normalisation, frame offsets)"""
+        return self._wave(self.L.lcrc_wave_to_mel, blobs, self.nbanks)
+
+    def wave_to_posteriors(self, blobs):
+        return self._wave(self.L.lcrc_wave_to_posteriors, blobs, self.n_out)
 
     def posteriors_probe(self, mel):
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)

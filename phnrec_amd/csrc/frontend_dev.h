@@ -1,0 +1,30 @@
+// frontend_dev.h -- parameter block of the GPU mel-bank front-end (frontend_kernels.hip)
+#ifndef PHNREC_FRONTEND_DEV_H
+#define PHNREC_FRONTEND_DEV_H
+
+#include <hip/hip_runtime.h>
+
+namespace phnrec {
+
+struct FrontendParams {
+    const unsigned char *bytes;   // raw utterances back to back (each at an even byte offset)
+    const long long *sample_start; // [2*n_utts] first sample of each utterance, then its sample count
+    const int *frame_off;         // [n_utts+1] first frame of each utterance
+    float *mel;                   // [n_frames][nbanks]
+    const float *hamming;         // [vector_size]
+    const double *twiddle;        // [fft-1] (wr, wi) pairs: stage with half-size h starts at h-1
+    const float *coeffs;          // [fft/2] mel filter weights per bin
+    const int *run_begin;         // [2*nbanks_full] see melbank_kernel
+    const int *run_end;
+    int n_utts, n_frames, nbanks, fft;
+    int wave_format;              // 1 lin16, 2 A-law
+    int vector_size, vector_step;
+    float dc_shift, scale, preem_coef;
+    int z_mean_source;
+};
+
+hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
+hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int nbanks, hipStream_t stream);
+
+}  // namespace phnrec
+#endif

@@ -1,0 +1,187 @@
+// frontend_kernels.hip -- "next" row f1 of SURVEY.md 8: the mel-bank front-end on the GPU.
+//
+// raw samples -> log mel-bank energies, one wave per 10 ms frame, following the reference's
+// arithmetic operation by operation; ln() is evaluated in double and rounded once (glibc's logf is
+// correctly rounded in all but rare cases), so dumps agree with the reference's to the last bit or one ulp:
+//   waveform decode   srec.cpp:709-791, alaw.cpp      lin16 / A-law, dc_shift, scale
+//   framing           srec.cpp:945, melbanks.cpp:151   frame t = samples [t*step, t*step + vs)
+//   pre-processing    dspc.h:64-84                     z_mean_source, pre-emphasis (both off in shipped configs)
+//   Hamming           dspc.h:162-167                   table built on the host with the reference's expression
+//   FFT               dspc.cpp:24-78                   radix-2 DIT on interleaved floats; twiddles from the
+//                                                      reference's double-precision recurrence (table built on
+//                                                      the host), butterfly products in double, rounded to float
+//   power, mel        dspc.h:141-146, dspc.cpp:236-269 per bank, bins accumulated in ascending order
+//   ln                dspc.h:155-160
+// and the sentence mean normalisation (srec.cpp:1500-1511) with its sequential f32 column sums.
+#include <hip/hip_runtime.h>
+
+#include "frontend_dev.h"
+
+namespace phnrec {
+
+// G.711 A-law expansion (== 8 * ALawTableD5[b], alaw.cpp:14-48, srec.cpp:769)
+__device__ __forceinline__ float alaw_to_linear(unsigned b)
+{
+    const unsigned a = b ^ 0x55u;
+    int mant = (int)(a & 0x0Fu) << 4;
+    const int seg = (int)(a & 0x70u) >> 4;
+    if (seg == 0) mant += 8;
+    else mant = (mant + 0x108) << (seg - 1);
+    return (float)((a & 0x80u) ? mant : -mant);
+}
+
+template <int FFT>
+__global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
+{
+    constexpr int LOG2 = FFT == 256 ? 8 : 9;
+    __shared__ float buf[4][2 * FFT];           // interleaved (re, im) per wave
+    __shared__ float pw[4][FFT / 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = blockIdx.x * 4 + wave;
+    const bool live = fr < p.n_frames;
+    float *d = buf[wave];
+
+    int u = 0, t = 0;
+    long long s0 = 0, ns = 0;
+    if (live) {
+        int lo = 0, hi = p.n_utts;              // largest u with frame_off[u] <= fr
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (p.frame_off[mid] <= fr) lo = mid; else hi = mid;
+        }
+        u = lo;
+        t = fr - p.frame_off[u];
+        s0 = p.sample_start[u];
+        ns = p.sample_start[p.n_utts + u];      // second half of the array: sample counts
+    }
+    // ---- decode + pre-process one frame into registers (vs <= 512: up to 8 samples per lane) ----
+    const int vs = p.vector_size;
+    float x[FFT / 64];
+#pragma unroll
+    for (int k = 0; k < FFT / 64; k++) {
+        const int i = lane + 64 * k;
+        float v = 0.0f;
+        const long long si = (long long)t * p.vector_step + i;
+        if (live && i < vs && si < ns) {        // samples past the end of a short signal are zeros
+            if (p.wave_format == 1) {
+                const short *w = reinterpret_cast<const short *>(p.bytes) + s0 + si;
+                v = (float)*w;
+            } else {
+                v = alaw_to_linear(p.bytes[s0 + si]);
+            }
+            if (p.dc_shift != 0.0f) v = v + p.dc_shift;
+            if (p.scale != 1.0f) v = v * p.scale;
+        }
+        x[k] = v;
+    }
+    if (p.z_mean_source || p.preem_coef != 0.0f) {
+        // rarely used; done through LDS by lane 0 in the reference's sequential order
+#pragma unroll
+        for (int k = 0; k < FFT / 64; k++) d[lane + 64 * k] = x[k];
+        __syncthreads();
+        if (lane == 0 && live) {
+            if (p.z_mean_source) {              // sSubtractAverage dspc.h:64-75
+                float avg = 0.0f;
+                for (int i = 0; i < vs; i++) avg += d[i];
+                avg /= (float)vs;
+                for (int i = 0; i < vs; i++) d[i] -= avg;
+            }
+            if (p.preem_coef != 0.0f) {         // sPreemphasisBW dspc.h:77-84
+                for (int n = vs - 1; n > 0; --n) d[n] -= p.preem_coef * d[n - 1];
+                d[0] *= (1.0f - p.preem_coef);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FFT / 64; k++) x[k] = d[lane + 64 * k];
+        __syncthreads();
+    }
+    // ---- window, bit-reversed placement ----
+#pragma unroll
+    for (int k = 0; k < FFT / 64; k++) {
+        const int i = lane + 64 * k;
+        const float v = i < vs ? x[k] * p.hamming[i] : 0.0f;
+        const int r = (int)(__brev((unsigned)i) >> (32 - LOG2));
+        d[2 * r] = v;
+        d[2 * r + 1] = 0.0f;
+    }
+    __syncthreads();
+    // ---- Danielson-Lanczos stages; twiddle (stage, k) = entry h - 1 + k of the host-built table ----
+#pragma unroll 1
+    for (int h = 1; h < FFT; h <<= 1) {
+#pragma unroll
+        for (int q = 0; q < FFT / 128; q++) {
+            const int bidx = lane + 64 * q;          // butterfly index 0 .. FFT/2-1
+            const int k = bidx & (h - 1);
+            const int i = ((bidx & ~(h - 1)) << 1) + k;
+            const int j = i + h;
+            const double wr = p.twiddle[2 * (h - 1 + k)], wi = p.twiddle[2 * (h - 1 + k) + 1];
+            const float jr = d[2 * j], ji = d[2 * j + 1];
+            const float tr = (float)(wr * jr - wi * ji);
+            const float ti = (float)(wr * ji + wi * jr);
+            const float ir = d[2 * i], ii = d[2 * i + 1];
+            d[2 * j] = ir - tr;
+            d[2 * j + 1] = ii - ti;
+            d[2 * i] = ir + tr;
+            d[2 * i + 1] = ii + ti;
+        }
+        __syncthreads();
+    }
+    // ---- power spectrum, mel filters, ln ----
+#pragma unroll
+    for (int k = 0; k < FFT / 128; k++) {
+        const int i = lane + 64 * k;
+        const float re = d[2 * i], im = d[2 * i + 1];
+        pw[wave][i] = re * re + im * im;
+    }
+    __syncthreads();
+    if (live && lane < p.nbanks) {
+        // bank b: bins whose falling edge is b (Banks == b) contribute p - v, then bins whose rising
+        // edge... i.e. Banks == b + 1 contribute v; both runs are contiguous and in ascending order
+        const int b = lane;
+        float e = 0.0f;
+        for (int i = p.run_begin[2 * b]; i < p.run_end[2 * b]; i++) {
+            const float pp = pw[wave][i], v = p.coeffs[i] * pp;
+            e += (pp - v);
+        }
+        for (int i = p.run_begin[2 * b + 1]; i < p.run_end[2 * b + 1]; i++) e += p.coeffs[i] * pw[wave][i];
+        // ln in double, rounded once: glibc's logf is correctly rounded in all but rare cases, the
+        // device's f32 logf is only good to a few ulp
+        p.mel[(size_t)fr * p.nbanks + b] = e > 0.0f ? (float)log((double)e) : 0.0f;
+    }
+}
+
+// offlinenorm/sent_mean_norm: one thread per (utterance, band), sequential f32 sum over the frames,
+// mean = sum * (1.0f / rows), x += -mean  (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116)
+__global__ void meannorm_kernel(float *mel, const int *frame_off, int n_utts, int nbanks)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_utts * nbanks) return;
+    const int u = id / nbanks, b = id - u * nbanks;
+    const int a = frame_off[u], e = frame_off[u + 1];
+    if (e <= a) return;
+    float sum = 0.0f;
+    for (int r = a; r < e; r++) sum += mel[(size_t)r * nbanks + b];
+    const float mean = sum * (1.0f / (float)(e - a));
+    for (int r = a; r < e; r++) mel[(size_t)r * nbanks + b] += -mean;
+}
+
+hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
+{
+    if (p.n_frames <= 0) return hipSuccess;
+    const dim3 grid((p.n_frames + 3) / 4), block(256);
+    if (p.fft == 256) melbank_kernel<256><<<grid, block, 0, stream>>>(p);
+    else if (p.fft == 512) melbank_kernel<512><<<grid, block, 0, stream>>>(p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int nbanks, hipStream_t stream)
+{
+    const int n = n_utts * nbanks;
+    if (n <= 0) return hipSuccess;
+    meannorm_kernel<<<(n + 127) / 128, 128, 0, stream>>>(mel, frame_off, n_utts, nbanks);
+    return hipGetLastError();
+}
+
+}  // namespace phnrec

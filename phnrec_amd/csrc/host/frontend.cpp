@@ -1,6 +1,8 @@
 // frontend.cpp -- see frontend.h
 #include "frontend.h"
 
+#include "../meltables.h"
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -60,47 +62,18 @@ void MelBanks::Configure(int nbanks, int nbanks_full, int sample_freq, int vecto
 
 int MelBanks::NumFrames(int n) const { return n > vs_ ? (n - vs_) / step_ + 1 : 1; }
 
-static inline float MelOf(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }   // dspc.h:174-177
-
-// Filter-bank design (dspc.cpp:80-197): `count` triangular filters equally spaced on the
-// mel scale between lo and hi; every FFT bin i in [fftlo, ffthi] belongs to the falling
-// edge of filter bank_of[i]-1 with weight coeffs[i] and to the rising edge of filter
-// bank_of[i] with 1-coeffs[i].  Centres are accumulated by repeated f32 addition.
+// Filter-bank design, window: shared with the GPU front-end (../meltables.cpp)
 void MelBanks::Init()
 {
-    fft_ = 1;
-    while (fft_ < vs_) fft_ *= 2;
-    hamming_.resize(vs_);
-    for (int i = 0; i < vs_; i++)                // sWindow_Hamming dspc.h:162-167
-        hamming_[i] = 1.0f * (0.54f - 0.46f * cosf(2.0f * (float)M_PI * i / (vs_ - 1)));
+    fft_ = FftSizeFor(vs_);
+    BuildHamming(vs_, hamming_);
     if (nbanks_full_ == -1) nbanks_full_ = nbanks_;
-    const int count = nbanks_full_, half = fft_ / 2;
-    float fmin = lo_ < 0.0f ? 0.0f : lo_;
-    float fmax = hi_ > (float)fs_ / 2.0f ? (float)fs_ / 2.0f : hi_;
-    coeffs_.assign(half, 0.0f);
-    bank_of_.assign(half, -1);
-    const float bf = (float)fs_ / (float)fft_;
-    const float mlo = MelOf(fmin), mhi = MelOf(fmax);
-    fftlo_ = (int)(fmin / bf + 1.5f);
-    ffthi_ = (int)(fmax / bf - 0.5f);
-    if (fftlo_ < 1) fftlo_ = 1;
-    if (ffthi_ >= half) ffthi_ = half - 1;
-    const float delta = (mhi - mlo) / (count + 1);
-    std::vector<float> centre(count + 1);
-    float m = mlo;
-    for (int i = 0; i <= count; i++) { m = m + delta; centre[i] = m; }
-    int ch = 0;
-    for (int i = 0; i < half; i++) {
-        if (i < fftlo_ || i > ffthi_) continue;
-        const float mf = MelOf((float)i * bf);
-        while (mf > centre[ch] && ch <= count) ++ch;
-        bank_of_[i] = (short)ch;
-    }
-    for (int i = fftlo_; i <= ffthi_; i++) {
-        const int c = bank_of_[i];
-        const float mf = MelOf((float)i * bf);
-        coeffs_[i] = c == 0 ? (centre[0] - mf) / (centre[0] - mlo) : (centre[c] - mf) / (centre[c] - centre[c - 1]);
-    }
+    MelFilters f;
+    BuildMelFilters(nbanks_full_, fft_, fs_, lo_, hi_, f);
+    coeffs_ = f.coeffs;
+    bank_of_ = f.bank_of;
+    fftlo_ = f.fftlo;
+    ffthi_ = f.ffthi;
     fft_buf_.assign(2 * (size_t)fft_ + 1, 0.0f);
     init_ = true;
 }

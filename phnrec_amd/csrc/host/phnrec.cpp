@@ -1,7 +1,7 @@
 // phnrec.cpp -- the drop-in command line.  Flags, their meaning, the order of checks and the
 // error texts follow the reference's phnrec.cpp:113-299; its private getopt() variant
 // (getopt.cpp:22-41: "-xVALUE" or "-x VALUE", bare words skipped) is restated below.
-// Additions (letters the reference does not use): -g, -b, -j.
+// Additions (letters the reference does not use): -g, -b, -j, -F.
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +29,8 @@ static void Help()
     puts(" -v                 verbose");
     puts(" -g num [1]         number of GPUs to spread a file list over (MI355X build)");
     puts(" -b num [32768]     frames per GPU launch when batching a file list");
-    puts(" -j num [all]       host threads for the front-end and the decoder\n");
+    puts(" -j num [all]       host threads for the front-end and the decoder");
+    puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)\n");
 }
 
 struct Opt {
@@ -70,7 +71,7 @@ int main(int argc, char **argv)
 {
     const char *config_dir = nullptr, *file_list = nullptr, *input_file = nullptr, *output_file = nullptr;
     const char *output_mlf = nullptr, *wpenalty = nullptr;
-    bool live = false, verbose = false;
+    bool live = false, verbose = false, gpu_fe = false;
     int gpus = 1, batch = 0, threads = 0;
     DataFormat iformat = dfWaveform, oformat = dfStrings;
     WaveFormat wformat = WF_UNKNOWN;
@@ -79,7 +80,7 @@ int main(int argc, char **argv)
     int ind = 0;
     for (;;) {
         const char *arg = nullptr;
-        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:", ind, arg);
+        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:F", ind, arg);
         if (c == -1) break;
         switch (c) {
         case 'c': config_dir = arg; break;
@@ -109,6 +110,7 @@ int main(int argc, char **argv)
         case 'g': gpus = atoi(arg); break;
         case 'b': batch = atoi(arg); break;
         case 'j': threads = atoi(arg); break;
+        case 'F': gpu_fe = true; break;
         case '?': Die("Error during command line parsing\n");
         default: break;                       // bare words are skipped, as in the reference
         }
@@ -120,6 +122,7 @@ int main(int argc, char **argv)
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
     if (threads > 0) SR.SetHostThreads(threads);
+    SR.SetGpuFrontend(gpu_fe);
     if (!SR.Init(std::string(config_dir) + "/config")) Die(SR.LastError());
 
     if (wpenalty) {

@@ -267,6 +267,25 @@ bool SpeechRec::EnsureGpus()
         t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
         t->SetDevice(d);
         if (!t->Init(config_dir_.c_str())) return Fail(t->LastError() + "\n");
+        if (gpu_frontend_) {
+            if (wave_.noise_level != 0.0f) return Fail("source/noise_level needs the host front-end (libc rand()); drop -F\n");
+            lcrc_frontend fe;
+            fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
+            fe.sample_freq = C.GetInt("source", "sample_freq");
+            fe.vector_size = C.GetInt("melbanks", "vector_size");
+            fe.vector_step = C.GetInt("melbanks", "vector_step");
+            fe.nbanks_full = C.GetInt("melbanks", "nbanks_full");
+            fe.lower_freq = C.GetFloat("melbanks", "lower_freq");
+            fe.higher_freq = C.GetFloat("melbanks", "higher_freq");
+            fe.preem_coef = C.GetFloat("melbanks", "preem_coef");
+            fe.scale = wave_.scale;
+            fe.dc_shift = wave_.dc_shift;
+            fe.z_mean_source = C.GetBool("melbanks", "z_mean_source") ? 1 : 0;
+            fe.sent_mean_norm = sent_mean_norm_ ? 1 : 0;
+            if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
+                return Fail("framenorm/* needs the host front-end; drop -F\n");
+            if (!t->ConfigureFrontend(fe)) return Fail(t->LastError() + "\n");
+        }
         gpus_.push_back(std::move(t));
     }
     return true;
@@ -290,6 +309,16 @@ static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
 void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
 {
     char msg[1200];
+    if (in == dfWaveform && gpu_frontend_ && out != dfParams) {
+        if (!ReadFile(job.src, job.bytes)) {
+            snprintf(msg, sizeof msg, "Can not open waveform file: %s\n", job.src.c_str());
+            job.ok = false; job.err = msg;
+            return;
+        }
+        job.frames = gpus_[0]->FrontendFrames((long long)job.bytes.size());
+        job.cols = nbanks_;
+        return;
+    }
     if (in == dfWaveform) {
         std::vector<unsigned char> bytes;
         if (!ReadFile(job.src, bytes)) {
@@ -460,6 +489,35 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                 const int first = batches[b].first, cnt = batches[b].second - first;
                 off.assign(1, 0);
                 for (int k = 0; k < cnt; k++) off.push_back(off.back() + jobs[first + k].frames);
+                if (gpu_frontend_ && in == dfWaveform) {
+                    // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the
+                    // three nets all run on the device
+                    std::vector<unsigned char> raw;
+                    std::vector<long long> boff(1, 0);
+                    for (int k = 0; k < cnt; k++) {
+                        Job &j = jobs[first + k];
+                        raw.insert(raw.end(), j.bytes.begin(), j.bytes.end());
+                        boff.push_back((long long)raw.size());
+                        std::vector<unsigned char>().swap(j.bytes);
+                    }
+                    std::vector<float> post((size_t)off.back() * n_out_);
+                    std::vector<int> foff(cnt + 1);
+                    raw.push_back(0);
+                    if (!tr.WaveToPosteriors(raw.data(), boff.data(), cnt, post.data(), foff.data())) {
+                        errs[g] = tr.LastError(); failed = true; return;
+                    }
+                    if (off.back() > 0) kms[g] += tr.LastKernelMs();
+                    float *hp = post.data();
+                    pool_->ParallelFor(cnt, [&](int k) {
+                        Job &j = jobs[first + k];
+                        float *pp = hp + (size_t)foff[k] * n_out_;
+                        j.cols = n_out_;
+                        if (soften_post)
+                            for (size_t i = 0; i < (size_t)j.frames * n_out_; i++) pp[i] = Soften(post_soft_, pp[i], post_soft_arg_);
+                        Stage3(out, j, mlf != nullptr, pp, n_out_);
+                    });
+                    continue;
+                }
                 float *h_mel = nullptr, *h_post = nullptr;
                 if (!tr.StageBuffers(off.back(), &h_mel, &h_post)) { errs[g] = tr.LastError(); failed = true; return; }
                 pool_->ParallelFor(cnt, [&](int k) {

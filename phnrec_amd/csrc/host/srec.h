@@ -65,6 +65,7 @@ public:
     void SetGpus(int n) { n_gpus_ = n; }
     void SetBatchFrames(int n) { batch_frames_ = n; }
     void SetHostThreads(int n) { host_threads_ = n; }
+    void SetGpuFrontend(bool v) { gpu_frontend_ = v; }   // -F: waveform -> posteriors without the host front-end
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
     bool ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf);
@@ -77,6 +78,7 @@ private:
         std::string src, tgt;
         std::vector<float> mel;            // [frames][nbanks] (par) or posteriors when in == post
         std::vector<float> post;
+        std::vector<unsigned char> bytes;  // raw file (GPU front-end mode)
         int frames = 0, cols = 0;
         std::string labels;                // formatted label / MLF text
         bool ok = true;
@@ -93,7 +95,7 @@ private:
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
 
     std::string config_dir_, err_;
-    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false;
+    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     float wpenalty_ = -2.0f;

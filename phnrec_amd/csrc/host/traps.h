@@ -80,6 +80,20 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // waveform entry: mel-bank front-end on the GPU (lcrc_frontend_configure / lcrc_wave_to_posteriors)
+    bool ConfigureFrontend(const lcrc_frontend &fe)
+    {
+        if (lcrc_frontend_configure(ctx_, &fe) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    int FrontendFrames(long long n_bytes) const { return lcrc_frontend_frames(ctx_, n_bytes); }
+    bool WaveToPosteriors(const unsigned char *bytes, const long long *byte_off, int n_utts, float *post, int *frame_off)
+    {
+        if (lcrc_wave_to_posteriors(ctx_, bytes, byte_off, n_utts, post, frame_off) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

@@ -16,7 +16,9 @@
 #include <string>
 #include <vector>
 
+#include "frontend_dev.h"
 #include "lcrc_dev.h"
+#include "meltables.h"
 #include "nnet_io.h"
 
 using namespace phnrec;
@@ -38,6 +40,17 @@ struct lcrc_ctx {
     size_t cap_rows = 0, cap_utts = 0;
     float *d_dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg = 0;
+    // GPU front-end ("next" row f1): configuration, device tables, staging for raw bytes
+    bool fe_ready = false;
+    lcrc_frontend fe = {};
+    int fe_fft = 0;
+    float *d_hamming = nullptr, *d_coeffs = nullptr;
+    double *d_twiddle = nullptr;
+    int *d_runs = nullptr;               // [4*nbanks_full]: run_begin[2*nbf], run_end[2*nbf]
+    unsigned char *d_bytes = nullptr, *h_bytes = nullptr;
+    long long *d_soff = nullptr, *h_soff = nullptr;
+    int *d_foff = nullptr, *h_foff = nullptr;
+    size_t cap_bytes = 0, cap_fe_utts = 0;
     // streaming state: the 30 most recent frames (Traps::be_mat minus its newest slot)
     std::vector<float> hist;
     bool hist_init = false;
@@ -353,6 +366,16 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->h_post) (void)hipHostFree(c->h_post);
     if (c->h_off) (void)hipHostFree(c->h_off);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
+    if (c->d_hamming) (void)hipFree(c->d_hamming);
+    if (c->d_coeffs) (void)hipFree(c->d_coeffs);
+    if (c->d_twiddle) (void)hipFree(c->d_twiddle);
+    if (c->d_runs) (void)hipFree(c->d_runs);
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
+    if (c->h_bytes) (void)hipHostFree(c->h_bytes);
+    if (c->d_soff) (void)hipFree(c->d_soff);
+    if (c->h_soff) (void)hipHostFree(c->h_soff);
+    if (c->d_foff) (void)hipFree(c->d_foff);
+    if (c->h_foff) (void)hipHostFree(c->h_foff);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -457,6 +480,167 @@ int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, in
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's default stream
     return launch(c, d_mel, d_off, n_utts, n_rows, d_post, s, nullptr);
+}
+
+// ---- waveform entry: GPU mel-bank front-end ------------------------------------------------
+
+int lcrc_frontend_configure(lcrc_ctx *c, const lcrc_frontend *cfg)
+{
+    if (!c || !cfg) return LCRC_E_ARG;
+    if ((cfg->wave_format != 1 && cfg->wave_format != 2) || cfg->vector_size < 2 || cfg->vector_size > 512 ||
+        cfg->vector_step < 1 || cfg->sample_freq < 1)
+        return fail(c, LCRC_E_ARG, "lcrc_frontend_configure: bad wave_format / vector_size (2..512) / vector_step / sample_freq");
+    const int nbf = cfg->nbanks_full == -1 ? c->nbanks : cfg->nbanks_full;
+    if (nbf < 3 || nbf < c->nbanks || nbf > 64)
+        return fail(c, LCRC_E_ARG, "lcrc_frontend_configure: nbanks_full must be >= max(3, nbanks) and <= 64");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int fft = FftSizeFor(cfg->vector_size);
+    if (fft != 256 && fft != 512) return fail(c, LCRC_E_UNSUPPORTED, "lcrc_frontend_configure: frames of 129..512 samples only (FFT 256 / 512)");
+    std::vector<float> ham;
+    BuildHamming(cfg->vector_size, ham);
+    MelFilters mf;
+    BuildMelFilters(nbf, fft, cfg->sample_freq, cfg->lower_freq, cfg->higher_freq, mf);
+    std::vector<double> tw;
+    BuildTwiddles(fft, tw);
+    // contiguous runs of bins per bank: run 2b = bins with bank_of == b, run 2b+1 = bank_of == b+1
+    std::vector<int> runs(4 * (size_t)nbf, 0);
+    for (int b = 0; b < nbf; b++)
+        for (int k = 0; k < 2; k++) {
+            int lo = -1, hi = -1;
+            for (int i = mf.fftlo; i <= mf.ffthi; i++)
+                if (mf.bank_of[i] == b + k) { if (lo < 0) lo = i; hi = i + 1; }
+            runs[2 * b + k] = lo < 0 ? 0 : lo;
+            runs[2 * nbf + 2 * b + k] = lo < 0 ? 0 : hi;
+        }
+    for (void *p : {(void *)c->d_hamming, (void *)c->d_coeffs, (void *)c->d_twiddle, (void *)c->d_runs})
+        if (p) (void)hipFree(p);
+    c->d_hamming = c->d_coeffs = nullptr; c->d_twiddle = nullptr; c->d_runs = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_hamming, ham.size() * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_coeffs, mf.coeffs.size() * sizeof(float)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_twiddle, tw.size() * sizeof(double)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_runs, runs.size() * sizeof(int)));
+    HIP_TRY(c, hipMemcpy(c->d_hamming, ham.data(), ham.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_coeffs, mf.coeffs.data(), mf.coeffs.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_runs, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->fe = *cfg;
+    c->fe.nbanks_full = nbf;
+    c->fe_fft = fft;
+    c->fe_ready = true;
+    return LCRC_OK;
+}
+
+static long long fe_samples(const lcrc_ctx *c, long long n_bytes)
+{
+    return c->fe.wave_format == 1 ? n_bytes / 2 : n_bytes;
+}
+
+int lcrc_frontend_frames(const lcrc_ctx *c, long long n_bytes)
+{
+    if (!c || !c->fe_ready || n_bytes < 0) return LCRC_E_ARG;
+    const long long len = fe_samples(c, n_bytes);
+    return len > c->fe.vector_size ? (int)((len - c->fe.vector_size) / c->fe.vector_step + 1) : 1;
+}
+
+// Shared by the two waveform entry points: stage the bytes (each utterance at an even offset),
+// run the front-end into d_mel; on return *rows = total frames.
+static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                        int *frame_off, int *rows)
+{
+    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
+    if (n_utts < 0 || (n_utts > 0 && (!bytes || !byte_off || !frame_off)) || (n_utts > 0 && byte_off[0] != 0))
+        return fail(c, LCRC_E_ARG, "waveform entry: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long total_bytes = 0, total_frames = 0;
+    for (int u = 0; u < n_utts; u++) {
+        const long long nb = byte_off[u + 1] - byte_off[u];
+        if (nb < 0) return fail(c, LCRC_E_ARG, "waveform entry: offsets must be non-decreasing");
+        total_bytes += nb + (nb & 1);
+        total_frames += lcrc_frontend_frames(c, nb);
+    }
+    if (total_frames > 0x7fffffffLL / 256) return fail(c, LCRC_E_ARG, "waveform entry: too many frames for one call");
+    if ((size_t)total_bytes + 16 > c->cap_bytes) {
+        if (c->d_bytes) { (void)hipFree(c->d_bytes); (void)hipHostFree(c->h_bytes); }
+        c->d_bytes = c->h_bytes = nullptr; c->cap_bytes = 0;
+        const size_t cap = (size_t)total_bytes + total_bytes / 4 + 4096;
+        HIP_TRY(c, hipMalloc((void **)&c->d_bytes, cap));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, hipHostMallocDefault));
+        c->cap_bytes = cap;
+    }
+    if (2 * (size_t)n_utts + 2 > c->cap_fe_utts) {
+        if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); }
+        c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->cap_fe_utts = 0;
+        const size_t cap = 2 * (size_t)n_utts + n_utts / 2 + 64;
+        HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), hipHostMallocDefault));
+        c->cap_fe_utts = cap;
+    }
+    const int unit = c->fe.wave_format == 1 ? 2 : 1;
+    long long pos = 0;
+    c->h_foff[0] = 0;
+    for (int u = 0; u < n_utts; u++) {               // h_soff: [start of u ...][sample count of u ...]
+        const long long nb = byte_off[u + 1] - byte_off[u];
+        memcpy(c->h_bytes + pos, bytes + byte_off[u], (size_t)nb);
+        c->h_soff[u] = pos / unit;
+        c->h_soff[n_utts + u] = fe_samples(c, nb);
+        c->h_foff[u + 1] = c->h_foff[u] + lcrc_frontend_frames(c, nb);
+        pos += nb + (nb & 1);                        // keep lin16 utterances 2-byte aligned
+    }
+    for (int u = 0; u < n_utts; u++) frame_off[u] = c->h_foff[u];
+    if (n_utts >= 0) frame_off[n_utts] = c->h_foff[n_utts];
+    *rows = (int)total_frames;
+    if (total_frames == 0) return LCRC_OK;
+    int rc = ensure_staging(c, (size_t)total_frames, (size_t)n_utts);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)pos, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_soff, c->h_soff, (size_t)(2 * n_utts) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    FrontendParams p;
+    memset(&p, 0, sizeof p);
+    p.bytes = c->d_bytes; p.sample_start = c->d_soff; p.frame_off = c->d_foff; p.mel = c->d_mel;
+    p.hamming = c->d_hamming; p.twiddle = c->d_twiddle; p.coeffs = c->d_coeffs;
+    p.run_begin = c->d_runs; p.run_end = c->d_runs + 2 * c->fe.nbanks_full;
+    p.n_utts = n_utts; p.n_frames = (int)total_frames; p.nbanks = c->nbanks; p.fft = c->fe_fft;
+    p.wave_format = c->fe.wave_format; p.vector_size = c->fe.vector_size; p.vector_step = c->fe.vector_step;
+    p.dc_shift = c->fe.dc_shift; p.scale = c->fe.scale; p.preem_coef = c->fe.preem_coef;
+    p.z_mean_source = c->fe.z_mean_source;
+    HIP_TRY(c, frontend_launch(p, c->stream));
+    return LCRC_OK;
+}
+
+int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                     float *mel, int *frame_off)
+{
+    if (!c) return LCRC_E_ARG;
+    int rows = 0;
+    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
+    if (rc || rows == 0) return rc;
+    if (!mel) return fail(c, LCRC_E_ARG, "lcrc_wave_to_mel: NULL output");
+    const size_t nbytes = (size_t)rows * c->nbanks * sizeof(float);
+    HIP_TRY(c, hipMemcpyAsync(c->h_mel, c->d_mel, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(mel, c->h_mel, nbytes);
+    return LCRC_OK;
+}
+
+int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                            float *post, int *frame_off)
+{
+    if (!c) return LCRC_E_ARG;
+    int rows = 0;
+    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
+    if (rc || rows == 0) return rc;
+    if (!post) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
+    if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, c->nbanks, c->stream));
+    rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
+    if (rc) return rc;
+    const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
+    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(post, c->h_post, nbytes);
+    return LCRC_OK;
 }
 
 int lcrc_reset(lcrc_ctx *c)

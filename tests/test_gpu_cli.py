@@ -74,3 +74,17 @@ def test_file_list_batched_over_the_gpu(tmp_path):
         got = read_htk(str(data / (n + ".lop")))
         want = read_htk(os.path.join(GOLD, "cli", n + ".lop"))
         assert np.abs(got - want).max() < 1e-4, n
+
+
+def test_gpu_front_end_flag(tmp_path):
+    """-F: waveform -> posteriors entirely on the device; labels still equal the reference's"""
+    out = tmp_path / "t.rec"
+    run("-c", model_dir(CZ), "-F", "-i", os.path.join(GOLD, "test.raw"), "-o", out)
+    _labels_match(out, os.path.join(GOLD, "rec", CZ + ".rec"))
+    lop = tmp_path / "t.lop"
+    run("-c", model_dir(EN), "-F", "-i", os.path.join(GOLD, "test.raw"), "-t", "post", "-o", lop)
+    assert np.abs(read_htk(str(lop)) - read_htk(os.path.join(GOLD, EN, "test.lop"))).max() < 1e-4
+    # -t par keeps the host front-end (its dump is bit-identical to the reference's)
+    mel = tmp_path / "t.mel"
+    run("-c", model_dir(CZ), "-F", "-i", os.path.join(GOLD, "test.raw"), "-t", "par", "-o", mel)
+    assert open(mel, "rb").read() == open(os.path.join(GOLD, CZ, "test.mel"), "rb").read()

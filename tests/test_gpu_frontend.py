@@ -1,0 +1,111 @@
+"""GPU mel-bank front-end ("next" row f1): raw samples -> log mel energies -> posteriors, all on the
+device, against the reference CLI's own `-t par` / `-t post` dumps (tests/golden)."""
+import os
+
+import numpy as np
+import pytest
+
+from phnrec_amd import modelgen
+from tests.util import GOLD, model_dir, read_htk
+
+pytestmark = pytest.mark.gpu
+CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
+# the FFT, window, power and mel sums follow the reference operation by operation; ln() is computed in
+# double and rounded once, glibc's logf is correctly rounded except in rare cases: <= 1 ulp (1.9e-6 at ~20)
+TOL_MEL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from phnrec_amd import capi
+    capi.load()
+    return capi
+
+
+def _ctx(capi, system, **over):
+    spec = modelgen.SYSTEMS[system]
+    ctx = capi.Lcrc(model_dir(system), spec["nbanks"])
+    cfg = dict(wave_format="lin16", sample_freq=spec["sample_freq"], vector_size=spec["vector_size"],
+               vector_step=spec["vector_step"], lower_freq=float(spec["lower"]), higher_freq=float(spec["higher"]),
+               sent_mean_norm=spec["sent_mean_norm"])
+    cfg.update(over)
+    ctx.configure_frontend(**cfg)
+    return ctx
+
+
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_mel_matches_reference_dump(capi, system):
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ctx = _ctx(capi, system)
+    mel, foff = ctx.wave_to_mel([raw])
+    want = read_htk(os.path.join(GOLD, system, "test.mel"))
+    assert mel.shape == want.shape and list(foff) == [0, want.shape[0]]
+    assert np.abs(mel - want).max() <= TOL_MEL
+    assert (mel == want).mean() > 0.999, "identical up to the rare last-bit difference of logf"
+
+
+def test_alaw_and_short_files(capi):
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ctx = _ctx(capi, CZ, wave_format="alaw")
+    mel, _ = ctx.wave_to_mel([raw])
+    want = read_htk(os.path.join(GOLD, "cli", "test_alaw.mel"))
+    assert mel.shape == want.shape and np.abs(mel - want).max() <= TOL_MEL
+    ctx = _ctx(capi, CZ)
+    # several utterances in one call, incl. a 17-frame one, an odd byte count and one shorter than a frame
+    blobs = [raw[:3000], raw[:20001], raw[:100], raw]
+    mel, foff = ctx.wave_to_mel(blobs)
+    assert list(foff) == [0, 17, 17 + 123, 17 + 123 + 1, 17 + 123 + 1 + 747]
+    assert np.abs(mel[:17] - read_htk(os.path.join(GOLD, "cli", "utt_c.mel"))).max() <= TOL_MEL
+    assert np.abs(mel[-747:] - read_htk(os.path.join(GOLD, CZ, "test.mel"))).max() <= TOL_MEL
+    one, _ = ctx.wave_to_mel([raw[:20001]])
+    assert np.array_equal(one, mel[17:17 + 123])
+    assert np.isfinite(mel).all()
+
+
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_wave_to_posteriors(capi, system):
+    """waveform -> posteriors without leaving the GPU vs the reference's -t post dump"""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ctx = _ctx(capi, system)
+    post, foff = ctx.wave_to_posteriors([raw])
+    want = read_htk(os.path.join(GOLD, system, "test.lop"))
+    assert post.shape == want.shape
+    assert np.abs(post - want).max() < 1e-4
+    if system == CZ:                                   # a list: the three pieces of the CLI goldens
+        blobs = [raw, raw[:20000], raw[:3000]]
+        post, foff = ctx.wave_to_posteriors(blobs)
+        for k, name in enumerate(("utt_a", "utt_b", "utt_c")):
+            w = read_htk(os.path.join(GOLD, "cli", name + ".lop"))
+            assert np.abs(post[foff[k]:foff[k + 1]] - w).max() < 1e-4, name
+
+
+def test_front_end_options_vs_host_front_end(capi, tmp_path):
+    """pre-emphasis, z_mean_source, dc_shift, scale: the host CLI's front-end (itself bit-identical to the
+    reference's) is the comparison"""
+    import subprocess
+    from tests.util import ROOT
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()[:16000]
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 32, 12, seed=1)
+    cfg = open(os.path.join(d, "config")).read()
+    cfg = cfg.replace("preem_coef=0.0", "preem_coef=0.97\nz_mean_source=true")
+    cfg = cfg.replace("sample_freq=8000", "sample_freq=8000\nscale=0.5\ndc_shift=3.0")
+    open(os.path.join(d, "config"), "w").write(cfg)
+    (tmp_path / "x.raw").write_bytes(raw)
+    subprocess.check_call([os.path.join(ROOT, "phnrec_amd", "bin", "phnrec"), "-c", d, "-i", str(tmp_path / "x.raw"),
+                           "-t", "par", "-o", str(tmp_path / "x.mel")])
+    want = read_htk(str(tmp_path / "x.mel"))
+    ctx = capi.Lcrc(d, 15)
+    ctx.configure_frontend(preem_coef=0.97, z_mean_source=True, scale=0.5, dc_shift=3.0)
+    mel, _ = ctx.wave_to_mel([raw])
+    assert mel.shape == want.shape and np.abs(mel - want).max() <= TOL_MEL
+
+
+def test_frontend_errors(capi):
+    ctx = capi.Lcrc(model_dir(CZ), 15)
+    with pytest.raises(capi.LcrcError):
+        ctx.wave_to_mel([b"\0" * 1000])                # not configured
+    with pytest.raises(capi.LcrcError):
+        ctx.configure_frontend(vector_size=1000)
+    ctx.configure_frontend()
+    assert ctx.frontend_frames(119846) == 747 and ctx.frontend_frames(10) == 1

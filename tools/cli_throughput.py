@@ -36,7 +36,7 @@ def main():
         open(lst, "w").write("".join(n + "\n" for n in names))
         print("files %d, frames %d (%.1f h of audio)" % (n_files, total, total / 360000.0), flush=True)
         env = dict(os.environ, PHNREC_STATS="1")
-        for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"),
+        for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
             t0 = time.time()
             p = subprocess.run([BIN, "-c", mdir, "-l", lst] + extra, env=env, capture_output=True, text=True)
