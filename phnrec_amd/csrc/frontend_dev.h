@@ -24,7 +24,9 @@ struct FrontendParams {
 };
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
-hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int nbanks, hipStream_t stream);
+// means: device scratch [n_utts][nbanks]
+hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks, float *means,
+                           hipStream_t stream);
 
 }  // namespace phnrec
 #endif

@@ -151,19 +151,59 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
     }
 }
 
-// offlinenorm/sent_mean_norm: one thread per (utterance, band), sequential f32 sum over the frames,
-// mean = sum * (1.0f / rows), x += -mean  (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116)
-__global__ void meannorm_kernel(float *mel, const int *frame_off, int n_utts, int nbanks)
+// offlinenorm/sent_mean_norm (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116): column sums are
+// SEQUENTIAL f32 sums over the frames (the order is part of the result), mean = sum * (1.0f / rows),
+// x += -mean.  colmean_kernel: one workgroup per utterance streams the rows through LDS with coalesced
+// loads and lane b adds column b in frame order; submean_kernel: one thread per row subtracts.
+constexpr int kNormLdsFloats = 15360;           // 60 KiB of rows per LDS chunk (1024 rows of 15 banks)
+__global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
+                                                      float *means)
 {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_utts * nbanks) return;
-    const int u = id / nbanks, b = id - u * nbanks;
-    const int a = frame_off[u], e = frame_off[u + 1];
-    if (e <= a) return;
+    extern __shared__ float chunk[];            // [chunk_rows][nbanks]
+    const int chunk_rows = kNormLdsFloats / nbanks;
+    const int u = blockIdx.x;
+    const int a = frame_off[u], rows = frame_off[u + 1] - a;
+    if (rows <= 0) return;
+    const float *x = mel + (size_t)a * nbanks;
     float sum = 0.0f;
-    for (int r = a; r < e; r++) sum += mel[(size_t)r * nbanks + b];
-    const float mean = sum * (1.0f / (float)(e - a));
-    for (int r = a; r < e; r++) mel[(size_t)r * nbanks + b] += -mean;
+    for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
+        const int n = min(chunk_rows, rows - r0) * nbanks;
+        const float *src = x + (size_t)r0 * nbanks;
+#pragma unroll 8
+        for (int i = threadIdx.x; i < n; i += 256) chunk[i] = src[i];
+        __syncthreads();
+        if ((int)threadIdx.x < nbanks) {
+            // 16 independent LDS reads in flight, then the 16 adds in frame order (the add chain is the
+            // only dependent part)
+            const int nr = n / nbanks;
+            int r = 0;
+            for (; r + 16 <= nr; r += 16) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = chunk[(r + q) * nbanks + threadIdx.x];
+#pragma unroll
+                for (int q = 0; q < 16; q++) sum += v[q];
+            }
+            for (; r < nr; r++) sum += chunk[r * nbanks + threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nbanks) means[(size_t)u * nbanks + threadIdx.x] = sum * (1.0f / (float)rows);
+}
+
+__global__ void submean_kernel(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks,
+                               const float *means)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int lo = 0, hi = n_utts;                    // largest u with frame_off[u] <= r
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    float *x = mel + (size_t)r * nbanks;
+    const float *m = means + (size_t)lo * nbanks;
+    for (int b = 0; b < nbanks; b++) x[b] += -m[b];
 }
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
@@ -176,11 +216,13 @@ hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int nbanks, hipStream_t stream)
+hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks, float *means,
+                           hipStream_t stream)
 {
-    const int n = n_utts * nbanks;
-    if (n <= 0) return hipSuccess;
-    meannorm_kernel<<<(n + 127) / 128, 128, 0, stream>>>(mel, frame_off, n_utts, nbanks);
+    if (n_utts <= 0 || n_rows <= 0) return hipSuccess;
+    const size_t lds = (size_t)(kNormLdsFloats / nbanks) * nbanks * sizeof(float);
+    colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
+    submean_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, frame_off, n_utts, n_rows, nbanks, means);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ struct lcrc_ctx {
     unsigned char *d_bytes = nullptr, *h_bytes = nullptr;
     long long *d_soff = nullptr, *h_soff = nullptr;
     int *d_foff = nullptr, *h_foff = nullptr;
+    float *d_means = nullptr;
     size_t cap_bytes = 0, cap_fe_utts = 0;
     // streaming state: the 30 most recent frames (Traps::be_mat minus its newest slot)
     std::vector<float> hist;
@@ -376,6 +377,7 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->h_soff) (void)hipHostFree(c->h_soff);
     if (c->d_foff) (void)hipFree(c->d_foff);
     if (c->h_foff) (void)hipHostFree(c->h_foff);
+    if (c->d_means) (void)hipFree(c->d_means);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -568,13 +570,14 @@ static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long
         c->cap_bytes = cap;
     }
     if (2 * (size_t)n_utts + 2 > c->cap_fe_utts) {
-        if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); }
-        c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->cap_fe_utts = 0;
+        if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
+        c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
         const size_t cap = 2 * (size_t)n_utts + n_utts / 2 + 64;
         HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
         HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), hipHostMallocDefault));
         HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
         HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(c, hipMalloc((void **)&c->d_means, cap * 64 * sizeof(float)));
         c->cap_fe_utts = cap;
     }
     const int unit = c->fe.wave_format == 1 ? 2 : 1;
@@ -633,7 +636,7 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
     if (rc || rows == 0) return rc;
     if (!post) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
-    if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, c->nbanks, c->stream));
+    if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, rows, c->nbanks, c->d_means, c->stream));
     rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);

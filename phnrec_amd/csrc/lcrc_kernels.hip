@@ -715,9 +715,17 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     if (lp.total > 160u * 1024u) return hipErrorInvalidValue;
     if (variant_name) *variant_name = v->name;
     if (p.n_rows <= 0) return hipSuccess;
-    // > 64 KiB of dynamic LDS has to be granted per function (and per device)
-    hipError_t e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // > 64 KiB of dynamic LDS has to be granted per function and per device: once, not per launch
+    static bool granted[sizeof kVariants / sizeof kVariants[0]][64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const int vi = (int)(v - kVariants);
+    if (dev < 0 || dev >= 64 || !granted[vi][dev]) {
+        e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) granted[vi][dev] = true;
+    }
     const dim3 grid((p.n_rows + kBM - 1) / kBM), block(kNW * 64);
     LcrcParams args = p;
     args.n_ot_slab = lcrc_n_ot_slab(p.net);
