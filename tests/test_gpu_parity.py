@@ -273,3 +273,26 @@ def test_staged_zero_copy_entry_equals_batch(capi, tmp_path):
         mel = modelgen.synth_mel(int(off[-1]), 15, seed=len(lens))
         assert np.array_equal(ctx.posteriors_staged(mel, off), ctx.posteriors_batch(mel, off))
     assert ctx.posteriors_staged(np.zeros((0, 15), np.float32), np.array([0, 0], np.int32)).shape == (0, 27)
+
+
+def test_generic_kernel_shape_sweep(capi, oracle_mod, tmp_path):
+    """the generic variant over awkward shapes: hidden sizes that leave waves without tiles or with a
+    partial last tile, band/merger nets with different hidden sizes, every ksteps % 4, 1..23 banks,
+    output counts around the 16-tile boundaries -- each against the oracle on ragged batches"""
+    rng = np.random.default_rng(2024)
+    cases = [(3, 5, 6), (4, 16, 16), (5, 17, 15), (7, 33, 17), (9, 48, 31), (11, 64, 32), (13, 70, 33),
+             (15, 100, 47), (16, 130, 48), (19, 40, 49), (21, 250, 90), (23, 96, 120), (15, 1, 3), (8, 15, 208)]
+    for idx, (nb, hid, nout) in enumerate(cases):
+        d = str(tmp_path / ("m%d" % idx))
+        modelgen.write_model_dir(d, nb, hid, nout, seed=100 + idx, hidden_merger=hid + 7 * (idx % 3))
+        ctx = capi.Lcrc(d, nb)
+        # (23 banks, 120 outputs) has the k-steps / output tiles of the EN variant: hidden size is a run-time value there
+        assert ctx.kernel_name == ("en_64_60_8" if (nb, nout) == (23, 120) else "generic")
+        o = oracle_mod.Oracle(d, nb)
+        lens = [int(v) for v in rng.integers(0, 45, size=5)] + [33]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), nb, seed=idx, mean_norm=bool(idx & 1))
+        got = ctx.posteriors_batch(mel, off)
+        want = o.posteriors_batch(mel, off)
+        assert np.abs(got - want).max() < TOL, (nb, hid, nout, np.abs(got - want).max())
+        ctx.close()
