@@ -267,6 +267,18 @@ __device__ __forceinline__ void gemm2(f4 (&acc)[NOT][2], const f4 (&w)[NOT], con
         if (EXACT || ot < n_ot) gemm2_group(acc[ot][0], acc[ot][1], w[ot], s0, s1);
 }
 
+// All-reduce over aligned groups of 8 lanes with DPP (no LDS traffic, unlike __shfl_xor which is a
+// ds_bpermute): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i, i.e. the
+// other quad of the 8-lane half row, which by then holds that quad's result).
+template <typename Op>
+__device__ __forceinline__ float allreduce8(float v, Op op)
+{
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    return v;
+}
+
 // Compiler fences (no instruction).  hipcc otherwise SINKS read-only prefetch loads down
 // to their first use (IR level) or hoists the register-only MFMA/VALU work of the next
 // phase above them (machine scheduler); either way the prefetch becomes a just-in-time
@@ -284,8 +296,9 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
     img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
 }
 
-// Runs one net.  On return `epi(frame, o, posterior)` has been called once for every
-// (frame, output) of the tile by SOME thread, and a __syncthreads() has been passed.
+// Runs one net.  On return `epi(frame, o, posterior, valid)` has been called with valid == true once
+// for every (frame, output) of the tile by SOME thread (calls with valid == false carry a clamped
+// output index and must not store), and a __syncthreads() has been passed.
 template <int KS, int NOT, int NW, bool EXACT, typename Epi>
 __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const NetDev &nd,
                                         const f4 *__restrict__ XF, f4 *__restrict__ slab,
@@ -442,6 +455,7 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
         }
         __syncthreads();
     }
+    LCRC_STAMP(prm, wave, lane, 12 + (stamp0 == 8 ? 0 : 0));   // fold done (last net's value survives)
     // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a frame, each
     // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
     // frame = 16f + c  ->  float index ((2ot + f)*64 + 16g + c)*4 + rr.
@@ -459,28 +473,30 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
+            // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
+            // unconditionally so the 2*NV LDS reads are issued back to back, select afterwards
             const int idx = fbase + (o >> 4) * 512 + ((o >> 2) & 3) * 64 + (o & 3);
-            v[j] = o < O ? sa[idx] + sb[idx] : -FLT_MAX;
+            const float t = sa[idx] + sb[idx];
+            v[j] = o < O ? t : -FLT_MAX;
             m = fmaxf(m, v[j]);
         }
-#pragma unroll
-        for (int d = 1; d < LPF; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        static_assert(LPF == 8, "softmax lane groups are 8 wide (4 waves x 64 lanes over 32 frames)");
+        m = allreduce8(m, [](float a, float b) { return fmaxf(a, b); });
         float sum = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
-            if (part + LPF * j < O) {
-                v[j] = fexp_f(v[j] - m);
-                sum += v[j];
-            }
+            const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
+            v[j] = part + LPF * j < O ? e : 0.0f;
+            sum += v[j];
         }
-#pragma unroll
-        for (int d = 1; d < LPF; d <<= 1) sum += __shfl_xor(sum, d);
+        sum = allreduce8(sum, [](float a, float b) { return a + b; });
         const float scale = 1.0f / sum;
         __syncthreads();                          // slabs are free again (the epilogue may reuse them)
+        LCRC_STAMP(prm, wave, lane, 13);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
-            if (o < O) epi(frame, o, v[j] * scale);
+            epi(frame, min(o, O - 1), v[j] * scale, o < O);   // loads inside stay unconditional
         }
     }
     __syncthreads();
@@ -575,35 +591,54 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             basis[s4] = c == 0 ? 1.0f : (c < kNCoef ? costab[(c - 1) * 16 + tap] : 0.0f);
         }
         const int items = 2 * nb;                // (net, band) pairs, dealt to the waves
+        // per-lane constants of both frame tiles: clamp bounds and centre row
+        int rr[2], lo[2], hi[2];
+#pragma unroll
+        for (int f = 0; f < 2; f++) {
+            const int i = 16 * f + c;            // this lane's frame as an A-operand row
+            rr[f] = min(r0 + i, p.n_rows - 1) - kShift;
+            lo[f] = rowlo[i];
+            hi[f] = rowhi[i];
+        }
+        const int cc = min(c, kNCoef - 1);       // loads below stay unconditional (clamped index)
         for (int it = wave; it < items; it += NW) {
             const int n = it / nb, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (2 * nkq1 * 256);
             float *dbg = n == 0 ? p.dbg_in0 : p.dbg_in1;
+            // all eight operand values first (independent LDS reads), then the eight MFMAs
+            float xw[2][4];
 #pragma unroll
-            for (int f = 0; f < 2; f++) {
-                const int i = 16 * f + c;        // this lane's frame as an A-operand row
-                const int r = min(r0 + i, p.n_rows - 1);
-                const int lo = rowlo[i], hi = rowhi[i];
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int tap = 4 * s4 + g;
+                const float w = win[n * kHalf + tap];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const int tap = 4 * s4 + g;
-                    const int srow = max(lo, min(hi, r - kShift + n * kShift + tap));
-                    const float xw = melT[(srow - tbase) * nb + b] * win[n * kHalf + tap];
-                    acc = mfma16x16x4(xw, basis[s4], acc);
+                for (int f = 0; f < 2; f++) {
+                    const int srow = max(lo[f], min(hi[f], rr[f] + n * kShift + tap));
+                    xw[f][s4] = melT[(srow - tbase) * nb + b] * w;
                 }
-                if (c < kNCoef) {                // D layout: row = frame 16f + 4g + reg, col = c
-                    const int k = b * kNCoef + c;
-                    const float mk = mean[k], dk = dev[k];
+            }
+            const int k = b * kNCoef + cc;
+            const float mk = mean[k], dk = dev[k];
+            f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                acc[0] = mfma16x16x4(xw[0][s4], basis[s4], acc[0]);
+                acc[1] = mfma16x16x4(xw[1][s4], basis[s4], acc[1]);
+            }
+            if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
+                // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
+                const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const int fr = 16 * f + 4 * g + reg;
-                        const float val = acc[reg] * p.normc;            // CalcC0 / sDCT scaling
+                        const float val = acc[f][reg] * p.normc;         // CalcC0 / sDCT scaling
                         if (dbg && r0 + fr < p.n_rows) dbg[(size_t)(r0 + fr) * K + k] = val;
                         float v = val - mk;                              // Normalize nn.cpp:702-716
                         v *= dk;
-                        xf_store(img, nkq1, fr, k, v);
+                        img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                     }
                 }
             }
@@ -622,15 +657,15 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         const int O = nd.n_out;
         const int kofs = n * p.net[0].n_out;
         float *dp = n == 0 ? p.dbg_p0 : p.dbg_p1;
-        auto epi = [&](int i, int o, float q) {
+        auto epi = [&](int i, int o, float q, bool valid) {
             const float gl = q > 0.0f ? logf(q) : 0.0f;             // sLn dspc.h:155-160
-            if ((dp || p.dbg_g) && r0 + i < p.n_rows) {
+            if (valid && (dp || p.dbg_g) && r0 + i < p.n_rows) {
                 if (dp) dp[(size_t)(r0 + i) * O + o] = q;
                 if (p.dbg_g) p.dbg_g[(size_t)(r0 + i) * nm.n_inp + kofs + o] = gl;
             }
             float v = gl - mmean[kofs + o];                          // Normalize nn.cpp:702-716
             v *= mdev[kofs + o];
-            xf_store(gf, nkqm, i, kofs + o, v);
+            if (valid) xf_store(gf, nkqm, i, kofs + o, v);
         };
         run_net<KS1, NOT, NW, EXACT>(p, 2 + 3 * n, nd,
                                      reinterpret_cast<const f4 *>(xf) + (size_t)n * (2 * nkq1 * 64), slab,
@@ -644,7 +679,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     {
         const int O = nm.n_out;
         float *outbuf = reinterpret_cast<float *>(slab);
-        auto epi = [&](int i, int o, float q) { outbuf[i * O + o] = q; };
+        auto epi = [&](int i, int o, float q, bool valid) { if (valid) outbuf[i * O + o] = q; };
         run_net<KSM, NOT, NW, EXACT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(kBM, p.n_rows - r0);

@@ -62,6 +62,11 @@ def main():
         print("%-46s %10.0f %10.0f %6.1f%%" % (name, np.median(d[:, :, i]), np.median(per_wg),
                                               100.0 * np.median(per_wg) / total_med))
     print("%-46s %10.0f" % ("workgroup total (median of slowest wave)", total_med))
+    # finer split of the LAST net's tail: loop end (8) -> fold done (12) -> softmax math done (13) -> epilogue done (9)
+    fine = st[:, :, [8, 12, 13, 9]]
+    df = np.diff(fine, axis=2)
+    for i, name in enumerate(("merger: fold (barriers + slab traffic)", "merger: softmax math", "merger: epilogue + barrier")):
+        print("%-46s %10.0f %10.0f" % (name, np.median(df[:, :, i]), np.median(df[:, :, i].max(axis=1))))
     print("kernel ms (events, stamped build): %.4f" % ctx.last_kernel_ms())
     span = seq[:, :, -1].max() - seq[:, :, 0].min()
     print("first stamp -> last stamp over the whole grid: %d cycles" % span)
