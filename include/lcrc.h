@@ -150,6 +150,23 @@ int lcrc_wave_to_mel(lcrc_ctx *ctx, const unsigned char *bytes, const long long 
 int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const long long *byte_off,
                             int n_utts, float *post, int *frame_off);
 
+/* ---- posterior writer path ("next" row f2) ---------------------------------------------
+ * The softening functions SpeechRec applies to every posterior after the nets
+ * (posteriors/softening_func, srec.cpp:1062-1070; decoder/softening_func, srec.cpp:1089-1097;
+ * functions srec.cpp:164-176, srec.h:192-194) evaluated on the device in the merger's
+ * epilogue, and optionally the byte order of HTK dumps (matrix.h:2506-2544 writes big-endian
+ * floats), so that the host writes a file with one fwrite and feeds the decoder without
+ * another pass.  Up to two stages are applied in order (posterior softening, then decoder
+ * softening, as `-t str` does).  The setting holds for every later posterior call on this
+ * context (host-pointer, staged, device-pointer, waveform and streaming forms); n_stages = 0
+ * and big_endian = 0 restore plain posteriors. */
+enum { LCRC_SOFT_NONE = 0, LCRC_SOFT_LOG = 1, LCRC_SOFT_IGOR = 2, LCRC_SOFT_GMM_BYPASS = 3 };
+typedef struct lcrc_softening {
+    int func;                /* LCRC_SOFT_*                                                               */
+    float arg1, arg2, arg3;  /* igor: middle point, right log base, left log base (srec.cpp:166-171)      */
+} lcrc_softening;
+int lcrc_output_configure(lcrc_ctx *ctx, const lcrc_softening *stages, int n_stages, int big_endian);
+
 /* ---- streaming form (Traps semantics) -----------------------------------------
  * lcrc_reset == Traps::Reset (traps.cpp:174-177).
  * lcrc_push  == Traps::CalcFeaturesBunched(mel, post, n, needed)

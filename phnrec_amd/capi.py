@@ -19,6 +19,7 @@ SYMBOLS = [
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
+    "lcrc_output_configure",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_kernel_name",
 ]
@@ -28,6 +29,14 @@ LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class Softening(C.Structure):
+    """struct lcrc_softening (include/lcrc.h)"""
+    _fields_ = [("func", C.c_int), ("arg1", C.c_float), ("arg2", C.c_float), ("arg3", C.c_float)]
+
+
+SOFT_FUNCS = {"none": 0, "log": 1, "igor": 2, "gmm_bypass": 3}
 
 
 class Frontend(C.Structure):
@@ -107,6 +116,7 @@ def load():
     L.lcrc_stage_buffers.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
     L.lcrc_stage_run.argtypes = [vp, _i32p, C.c_int]
     L.lcrc_frontend_configure.argtypes = [vp, C.POINTER(Frontend)]
+    L.lcrc_output_configure.argtypes = [vp, C.POINTER(Softening), C.c_int, C.c_int]
     L.lcrc_frontend_frames.argtypes = [vp, C.c_longlong]
     _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -197,6 +207,16 @@ class Lcrc:
             np.ctypeslib.as_array(pm, shape=(n, self.nbanks))[:] = mel
         self._check(self.L.lcrc_stage_run(self.h, off, len(off) - 1))
         return np.ctypeslib.as_array(pp, shape=(n, self.n_out)).copy() if n else np.zeros((0, self.n_out), np.float32)
+
+    # -- posterior writer path: softening functions and HTK byte order on the device --
+    def configure_output(self, stages=(), big_endian=False):
+        """stages: up to two of "none" | "log" | "gmm_bypass" | ("igor", middle, right_base, left_base)"""
+        arr = (Softening * max(1, len(stages)))()
+        for i, st in enumerate(stages):
+            name, args = (st, ()) if isinstance(st, str) else (st[0], st[1:])
+            args = list(args) + [0.0] * (3 - len(args))
+            arr[i] = Softening(SOFT_FUNCS[name], *args)
+        self._check(self.L.lcrc_output_configure(self.h, arr, len(stages), int(big_endian)))
 
     # -- waveform entry (GPU mel-bank front-end) --
     def configure_frontend(self, wave_format="lin16", sample_freq=8000, vector_size=200, vector_step=80,

@@ -12,15 +12,31 @@ inline uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 inline uint16_t bswap16(uint16_t v) { return __builtin_bswap16(v); }
 }  // namespace
 
-bool SaveHTK(const std::string &path, const float *data, int rows, int cols)
+namespace {
+bool write_header(FILE *f, int rows, int cols)
 {
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) return false;
     unsigned char hdr[12];
     const uint32_t n = bswap32((uint32_t)rows), per = bswap32(100000u);   // defaults matrix.h:411-423
     const uint16_t sz = bswap16((uint16_t)(cols * 4)), kind = bswap16(6);
     memcpy(hdr, &n, 4); memcpy(hdr + 4, &per, 4); memcpy(hdr + 8, &sz, 2); memcpy(hdr + 10, &kind, 2);
-    bool ok = fwrite(hdr, 1, 12, f) == 12;
+    return fwrite(hdr, 1, 12, f) == 12;
+}
+}  // namespace
+
+bool SaveHTKRaw(const std::string &path, const void *be_words, int rows, int cols)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const size_t n = (size_t)rows * cols;
+    const bool ok = write_header(f, rows, cols) && fwrite(be_words, 4, n, f) == n;
+    return fclose(f) == 0 && ok;
+}
+
+bool SaveHTK(const std::string &path, const float *data, int rows, int cols)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    bool ok = write_header(f, rows, cols);
     std::vector<uint32_t> buf((size_t)rows * cols);
     for (size_t i = 0; i < buf.size(); i++) {
         uint32_t v;

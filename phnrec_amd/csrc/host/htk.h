@@ -10,6 +10,8 @@
 namespace phnrec {
 
 bool SaveHTK(const std::string &path, const float *data, int rows, int cols);
+// `be_words` already holds big-endian 32-bit words (the device wrote them that way)
+bool SaveHTKRaw(const std::string &path, const void *be_words, int rows, int cols);
 bool LoadHTK(const std::string &path, std::vector<float> &data, int *rows, int *cols);
 
 }  // namespace phnrec

@@ -360,7 +360,16 @@ void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
         SentenceMeanNorm(job.mel.data(), job.frames, nbanks_);
 }
 
-void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols)
+static lcrc_softening DeviceSoftening(const std::string &f, const float *a)
+{
+    lcrc_softening s = {LCRC_SOFT_NONE, a[0], a[1], a[2]};
+    if (f == "log") s.func = LCRC_SOFT_LOG;
+    else if (f == "igor") s.func = LCRC_SOFT_IGOR;
+    else if (f == "gmm_bypass") s.func = LCRC_SOFT_GMM_BYPASS;
+    return s;
+}
+
+void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done)
 {
     char msg[1200];
     if (out == dfParams) {
@@ -371,7 +380,7 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
         return;
     }
     if (out == dfPosteriors) {
-        if (!SaveHTK(job.tgt, post, job.frames, cols)) {
+        if (!(device_done ? SaveHTKRaw(job.tgt, post, job.frames, cols) : SaveHTK(job.tgt, post, job.frames, cols))) {
             snprintf(msg, sizeof msg, "Can not create file: %s\n", job.tgt.c_str());
             job.ok = false; job.err = msg;
         }
@@ -379,7 +388,8 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
     }
     // strings: decoder softening (log), Viterbi, labels
     const size_t nvals = (size_t)job.frames * cols;
-    if (dec_soft_ == "log") for (size_t i = 0; i < nvals; i++) post[i] = logf(post[i]);
+    if (device_done) { }
+    else if (dec_soft_ == "log") for (size_t i = 0; i < nvals; i++) post[i] = logf(post[i]);
     else for (size_t i = 0; i < nvals; i++) post[i] = Soften(dec_soft_, post[i], dec_soft_arg_);
     PhnDec dec;
     dec.LoadPhnList(phoneme_list_);
@@ -481,7 +491,13 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
         std::atomic<bool> failed(false);
         std::vector<std::string> errs(gpus_.size());
         std::vector<double> kms(gpus_.size(), 0.0);
-        const bool soften_post = post_soft_ != "none";
+        // posterior writer path: both softening functions and the dump's byte order run in the
+        // posterior kernel's epilogue; the host only decodes or writes
+        {
+            lcrc_softening st[2] = {DeviceSoftening(post_soft_, post_soft_arg_), DeviceSoftening(dec_soft_, dec_soft_arg_)};
+            for (auto &g : gpus_)
+                if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
+        }
         auto worker = [&](int g) {
             Traps &tr = *gpus_[g];
             std::vector<int> off;
@@ -512,9 +528,7 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                         Job &j = jobs[first + k];
                         float *pp = hp + (size_t)foff[k] * n_out_;
                         j.cols = n_out_;
-                        if (soften_post)
-                            for (size_t i = 0; i < (size_t)j.frames * n_out_; i++) pp[i] = Soften(post_soft_, pp[i], post_soft_arg_);
-                        Stage3(out, j, mlf != nullptr, pp, n_out_);
+                        Stage3(out, j, mlf != nullptr, pp, n_out_, true);
                     });
                     continue;
                 }
@@ -531,9 +545,7 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                     Job &j = jobs[first + k];
                     float *post = h_post + (size_t)off[k] * n_out_;
                     j.cols = n_out_;
-                    if (soften_post)
-                        for (size_t i = 0; i < (size_t)j.frames * n_out_; i++) post[i] = Soften(post_soft_, post[i], post_soft_arg_);
-                    Stage3(out, j, mlf != nullptr, post, n_out_);
+                    Stage3(out, j, mlf != nullptr, post, n_out_, true);
                 });
             }
         };

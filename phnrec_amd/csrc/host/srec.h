@@ -88,7 +88,8 @@ private:
     bool RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf);
     void Stage1(DataFormat in, DataFormat out, Job &job);              // load [+ front-end] [+ sentence norm]
     // soft funcs, decode / dump; `post` = job.frames x cols posteriors (writable)
-    void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols);
+    // device_done: softening (and, for dumps, the big-endian byte order) already applied by the GPU
+    void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done = false);
     bool EnsureGpus();
     void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
     bool Fail(const std::string &msg) { err_ = msg; return false; }

@@ -94,6 +94,13 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // posterior writer path (lcrc_output_configure): softening and byte order on the device
+    bool ConfigureOutput(const lcrc_softening *stages, int n_stages, bool big_endian)
+    {
+        if (lcrc_output_configure(ctx_, stages, n_stages, big_endian ? 1 : 0) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

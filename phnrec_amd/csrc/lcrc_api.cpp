@@ -59,6 +59,9 @@ struct lcrc_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = true, timed = false;
+    // posterior writer path
+    lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    int out_be = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     int dbg_flags = 0;
     std::string err;
@@ -176,6 +179,18 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     p.mel = d_mel; p.off = d_off; p.post = d_post;
     p.win = c->d_win; p.costab = c->d_costab; p.normc = c->normc;
     p.n_utts = n_utts; p.n_rows = n_rows; p.nbanks = c->nbanks;
+    for (int i = 0; i < 2; i++) {
+        const lcrc_softening &sf = c->soft[i];
+        p.out_func[i] = sf.func;
+        if (sf.func == LCRC_SOFT_IGOR) {         // SoftIgor's sub-expressions, srec.cpp:166-171
+            p.out_c[i][0] = sf.arg1;
+            p.out_c[i][1] = 1.0f / sf.arg1;
+            p.out_c[i][2] = 1.0f / (1.0f - sf.arg1);
+            p.out_l[i][0] = logf(sf.arg3);
+            p.out_l[i][1] = logf(sf.arg2);
+        }
+    }
+    p.out_be = c->out_be;
     p.stamps = c->d_stamps;
     p.dbg_flags = c->dbg_flags;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
@@ -643,6 +658,18 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(post, c->h_post, nbytes);
+    return LCRC_OK;
+}
+
+int lcrc_output_configure(lcrc_ctx *c, const lcrc_softening *stages, int n_stages, int big_endian)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n_stages < 0 || n_stages > 2 || (n_stages > 0 && !stages)) return fail(c, LCRC_E_ARG, "lcrc_output_configure: 0..2 stages");
+    for (int i = 0; i < n_stages; i++)
+        if (stages[i].func < LCRC_SOFT_NONE || stages[i].func > LCRC_SOFT_GMM_BYPASS)
+            return fail(c, LCRC_E_ARG, "lcrc_output_configure: unknown softening function");
+    for (int i = 0; i < 2; i++) c->soft[i] = i < n_stages ? stages[i] : lcrc_softening{0, 0, 0, 0};
+    c->out_be = big_endian ? 1 : 0;
     return LCRC_OK;
 }
 

@@ -39,6 +39,11 @@ struct LcrcParams {
     float normc;         // sqrtf(2/16)
     int n_utts, n_rows, nbanks;
     int n_ot_slab;       // max n_ot over the three nets (set by lcrc_launch)
+    // posterior writer path (lcrc_output_configure): softening stages and byte order of `post`
+    int out_func[2];     // LCRC_SOFT_* per stage (0 = none)
+    float out_c[2][4];   // igor: {middle, 1/middle, 1/(1-middle), -} ; out_l: {ln left base, ln right base}
+    float out_l[2][2];
+    int out_be;          // store big-endian words
     // optional stage outputs (NULL in production)
     float *dbg_in0, *dbg_in1, *dbg_p0, *dbg_p1, *dbg_g;
     // [grid][8 waves][16] s_memtime stamps; only written by the diagnostic build (-DLCRC_STAMPS)

@@ -289,6 +289,19 @@ __device__ __forceinline__ float allreduce8(float v, Op op)
         __builtin_amdgcn_sched_barrier(0);  \
     } while (0)
 
+// Softening functions of srec.cpp:164-176 (lcrc_output_configure); constants are formed on the
+// host with the reference's f32 expressions.
+__device__ __forceinline__ float soften(int func, const float *c, const float *l, float v)
+{
+    if (func == 1) return logf(v);
+    if (func == 2) {
+        if (v < c[0]) return logf(v * c[1]) / l[0];
+        return -1.0f * logf((1.0f + (-1.0f * v)) * c[2]) / l[1];
+    }
+    if (func == 3) return sqrtf(-2.0f * logf(v));
+    return v;
+}
+
 // Scatter one value of a net-input row into the MFMA B image.
 __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, float v)
 {
@@ -679,7 +692,15 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     {
         const int O = nm.n_out;
         float *outbuf = reinterpret_cast<float *>(slab);
-        auto epi = [&](int i, int o, float q, bool valid) { if (valid) outbuf[i * O + o] = q; };
+        const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
+        auto epi = [&](int i, int o, float q, bool valid) {
+            if (transform) {                     // posterior writer path: softening, byte order
+                q = soften(p.out_func[0], p.out_c[0], p.out_l[0], q);
+                q = soften(p.out_func[1], p.out_c[1], p.out_l[1], q);
+                if (p.out_be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
+            }
+            if (valid) outbuf[i * O + o] = q;
+        };
         run_net<KSM, NOT, NW, EXACT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(kBM, p.n_rows - r0);

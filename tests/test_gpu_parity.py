@@ -296,3 +296,47 @@ def test_generic_kernel_shape_sweep(capi, oracle_mod, tmp_path):
         want = o.posteriors_batch(mel, off)
         assert np.abs(got - want).max() < TOL, (nb, hid, nout, np.abs(got - want).max())
         ctx.close()
+
+
+def test_posterior_writer_path_on_device(capi, tmp_path):
+    """lcrc_output_configure ("next" row f2): the softening functions of srec.cpp:164-176 and the HTK byte
+    order applied in the kernel's epilogue, against the same f32 expressions evaluated by numpy on the plain
+    posteriors of the same context (log-domain tolerance 2e-6 = a few ulp of logf at |ln p| <= 20)"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 90, 45, seed=11)
+    ctx = capi.Lcrc(d, 15)
+    off = np.array([0, 37, 37, 150], np.int32)
+    mel = modelgen.synth_mel(150, 15, seed=3)
+    plain = ctx.posteriors_batch(mel, off)
+    f32 = np.float32
+
+    def igor(v, mid, right, left):
+        lo = np.log(v * (f32(1) / f32(mid))) / np.log(f32(left))
+        hi = f32(-1) * np.log((f32(1) + f32(-1) * v) * (f32(1) / (f32(1) - f32(mid)))) / np.log(f32(right))
+        return np.where(v < f32(mid), lo, hi).astype(np.float32)
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cases = [
+            ((), plain),
+            (("log",), np.log(plain)),
+            (("none", "log"), np.log(plain)),
+            (("gmm_bypass",), np.sqrt(f32(-2) * np.log(plain))),
+            ((("igor", 0.5, 10.0, 10.0),), igor(plain, 0.5, 10.0, 10.0)),
+            (("log", "none"), np.log(plain)),
+        ]
+        for stages, want in cases:
+            for be in (False, True):
+                ctx.configure_output(stages, big_endian=be)
+                got = ctx.posteriors_batch(mel, off)
+                if be:
+                    got = got.view(">f4").astype(np.float32)
+                ok = np.isfinite(want)
+                assert np.array_equal(np.isfinite(got), ok), stages
+                assert np.abs(got[ok] - want[ok]).max() <= 2e-6 * max(1.0, np.abs(want[ok]).max()), (stages, be)
+                # the staged entry (what the CLI uses) goes through the same epilogue
+                st = ctx.posteriors_staged(mel, off)
+                assert np.array_equal(st.view(np.uint32), ctx.posteriors_batch(mel, off).view(np.uint32))
+    ctx.configure_output((), big_endian=False)
+    assert np.array_equal(ctx.posteriors_batch(mel, off), plain)
+    with pytest.raises(capi.LcrcError):
+        ctx.configure_output(("log", "log", "log"))

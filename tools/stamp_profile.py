@@ -42,7 +42,8 @@ def main():
     print("ablation build LCRC_DBG =", dbg)
     mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
     post = torch.empty((n, ctx.n_out), device="cuda")
-    grid = (n + 31) // 32
+    bm = int(os.environ.get("LCRC_BM", "16"))
+    grid = (n + bm - 1) // bm
     stamps = torch.zeros((grid, 8, 16), dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
     for it in range(5):
@@ -68,8 +69,25 @@ def main():
     for i, name in enumerate(("merger: fold (barriers + slab traffic)", "merger: softmax math", "merger: epilogue + barrier")):
         print("%-46s %10.0f %10.0f" % (name, np.median(df[:, :, i]), np.median(df[:, :, i].max(axis=1))))
     print("kernel ms (events, stamped build): %.4f" % ctx.last_kernel_ms())
-    span = seq[:, :, -1].max() - seq[:, :, 0].min()
-    print("first stamp -> last stamp over the whole grid: %d cycles" % span)
+    # residency: workgroups grouped by the CU they ran on (slot 14 = XCC_ID << 32 | HW_ID; HW_ID bits:
+    # simd 5:4, cu 11:8, sh 12, se 15:13); one clock per CU group is assumed
+    hw = stamps.cpu().numpy()[:, 0, 14].astype(np.int64)
+    cu = ((hw >> 32) & 0xF) * 4096 + ((hw >> 8) & 0xFF)
+    b = seq[:, :, 0].min(axis=1)
+    e = seq[:, :, -1].max(axis=1)
+    ids = np.unique(cu)
+    per_cu = np.array([(cu == c).sum() for c in ids])
+    print("CUs used: %d; workgroups per CU: min %d max %d" % (len(ids), per_cu.min(), per_cu.max()))
+    ov, spans = [], []
+    for c in ids:
+        bb, ee = b[cu == c], e[cu == c]
+        spans.append(ee.max() - bb.min())
+        if len(bb) == 2:
+            ov.append((min(ee) - max(bb)) / float(max(ee) - min(bb)))
+    print("busy span per CU (first start -> last end): median %d max %d" % (np.median(spans), np.max(spans)))
+    if ov:
+        print("CUs with two workgroups: %d; overlap of their lifetimes: median %.2f min %.2f" % (len(ov), np.median(ov), np.min(ov)))
+    print("XCC ids seen:", sorted(set(((hw >> 32) & 0xF).tolist())), " sample HW_ID:", [hex(int(x & 0xFFFFFFFF)) for x in hw[:4]])
 
 
 if __name__ == "__main__":
