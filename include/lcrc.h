@@ -187,6 +187,9 @@ int lcrc_delay(const lcrc_ctx *ctx);
 int lcrc_last_kernel_ms(lcrc_ctx *ctx, float *ms);
 /* Enable/disable the event pair (default on; costs two hipEventRecord per launch) */
 int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
+/* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
+ * (tuning and test hook; results are bit-identical either way) */
+int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
 /* Name of the kernel variant selected for this model ("cz_11_18_9", "generic", ...) */
 const char *lcrc_kernel_name(const lcrc_ctx *ctx);
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_output_configure",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
@@ -126,6 +126,7 @@ def load():
                                   C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.lcrc_set_timing.argtypes = [vp, C.c_int]
+    L.lcrc_set_tile_frames.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -284,6 +285,10 @@ class Lcrc:
         ms = C.c_float()
         self._check(self.L.lcrc_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def set_tile_frames(self, frames):
+        """0 = per launch (default), 16 or 32 = forced frames per workgroup"""
+        self._check(self.L.lcrc_set_tile_frames(self.h, frames))
 
     def set_timing(self, on):
         self._check(self.L.lcrc_set_timing(self.h, int(on)))

@@ -62,6 +62,7 @@ struct lcrc_ctx {
     // posterior writer path
     lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     int out_be = 0;
+    int tile_frames = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     int dbg_flags = 0;
     std::string err;
@@ -191,6 +192,7 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
         }
     }
     p.out_be = c->out_be;
+    p.tile_frames = c->tile_frames;
     p.stamps = c->d_stamps;
     p.dbg_flags = c->dbg_flags;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
@@ -658,6 +660,14 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(post, c->h_post, nbytes);
+    return LCRC_OK;
+}
+
+int lcrc_set_tile_frames(lcrc_ctx *c, int frames)
+{
+    if (!c) return LCRC_E_ARG;
+    if (frames != 0 && frames != 16 && frames != 32) return fail(c, LCRC_E_ARG, "lcrc_set_tile_frames: 0, 16 or 32");
+    c->tile_frames = frames;
     return LCRC_OK;
 }
 

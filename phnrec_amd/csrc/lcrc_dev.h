@@ -7,12 +7,12 @@
 
 namespace phnrec {
 
-constexpr int kBM = 32;        // frames per workgroup (two 16-frame MFMA column tiles)
+// A workgroup owns 16*FT consecutive frames (FT 16-frame MFMA column tiles): FT = 2 for launches that
+// fill the GPU with 32-frame workgroups, FT = 1 for smaller ones (twice the workgroups).
 constexpr int kTrapLen = 31;   // posteriors/length
 constexpr int kHalf = 16;      // taps per half context
 constexpr int kShift = 15;     // Traps::GetTrapShift
 constexpr int kNCoef = 11;     // C0 + 10 DCT coefficients
-constexpr int kTileRows = kBM + 2 * kShift;   // mel rows staged per workgroup (62)
 
 // One MLP in MFMA fragment order (see lcrc_pack.cpp for the element maps).
 struct NetDev {
@@ -39,6 +39,7 @@ struct LcrcParams {
     float normc;         // sqrtf(2/16)
     int n_utts, n_rows, nbanks;
     int n_ot_slab;       // max n_ot over the three nets (set by lcrc_launch)
+    int tile_frames;     // 0 = choose by launch size, 16 or 32 = forced (lcrc_set_tile_frames)
     // posterior writer path (lcrc_output_configure): softening stages and byte order of `post`
     int out_func[2];     // LCRC_SOFT_* per stage (0 = none)
     float out_c[2][4];   // igor: {middle, 1/middle, 1/(1-middle), -} ; out_l: {ln left base, ln right base}
@@ -58,17 +59,18 @@ struct LdsPlan {
 
 __host__ __device__ inline unsigned lcrc_round16(unsigned v) { return (v + 15u) & ~15u; }
 
-__host__ __device__ inline LdsPlan lcrc_lds_plan(int nbanks, int nkq_band, int nkq_merger, int n_ot)
+__host__ __device__ inline LdsPlan lcrc_lds_plan(int ft, int nbanks, int nkq_band, int nkq_merger, int n_ot)
 {
     LdsPlan p;
     unsigned o = 0;
-    p.mel = o;      o += lcrc_round16((unsigned)kTileRows * nbanks * 4u);
-    p.rowinfo = o;  o += 2u * kBM * 4u;
+    const unsigned uft = (unsigned)ft, bm = 16u * uft;
+    p.mel = o;      o += lcrc_round16((bm + 2u * kShift) * nbanks * 4u);
+    p.rowinfo = o;  o += 2u * bm * 4u;
     p.tabs = o;     o += (10u * 16u + 2u * 16u) * 4u;
     p.norms = o;    o += (4u * 16u * nkq_band + 2u * 16u * nkq_merger) * 4u;   // mean|dev of the 3 nets
-    p.xf = o;       o += 2u * 2u * nkq_band * 1024u;     // [net][f][kq][64] float4
-    p.gf = o;       o += 2u * nkq_merger * 1024u;        // [f][kq][64] float4
-    p.slab = o;     o += 2u * (2u * n_ot * 1024u);       // two slabs of [ot][f][64] float4
+    p.xf = o;       o += 2u * uft * nkq_band * 1024u;    // [net][f][kq][64] float4
+    p.gf = o;       o += uft * nkq_merger * 1024u;       // [f][kq][64] float4
+    p.slab = o;     o += 2u * (uft * n_ot * 1024u);      // two slabs of [ot][f][64] float4
     p.total = o;
     return p;
 }

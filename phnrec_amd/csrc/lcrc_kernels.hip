@@ -10,8 +10,9 @@
 //   CalcInputFeaturesForMerger    traps.cpp:435-461  -> ln() + merger normalisation straight into the
 //                                                       merger's operand image in LDS
 //
-// Geometry.  A workgroup owns kBM = 32 consecutive frames (two 16-frame MFMA
-// column tiles) and runs the three nets one after the other; its NW waves split
+// Geometry.  A workgroup owns 16*FT consecutive frames (FT = 2 16-frame MFMA column
+// tiles when the launch fills the GPU that way, FT = 1 for smaller launches) and
+// runs the three nets one after the other; its NW = 4 waves (one per SIMD) split
 // the HIDDEN dimension of each net.  Both products are computed transposed so
 // that no data has to change lanes between them:
 //   layer 1:  S^T[16 hidden x 16 frames] = W1[16 x K] . X^T          A = W1 fragment (HBM/L2, pre-packed)
@@ -160,28 +161,29 @@ __device__ __forceinline__ void load_w1(f4 (&a)[NKQ], f4 &bias, const f4 *w1, co
 
 // layer 1 of one hidden tile, bias first (nn.cpp:883-884):
 // p[f][r] = S^T[16ht + 4g + r][16f + (lane&15)]
-template <int KS, bool EXACT>
-__device__ __forceinline__ void gemm1_group(f4 &p0, f4 &p1, const f4 &akq, const f4 *__restrict__ XF,
+template <int KS, bool EXACT, int FT>
+__device__ __forceinline__ void gemm1_group(f4 (&p)[FT], const f4 &akq, const f4 *__restrict__ XF,
                                             int kq, int nkq, int ks, int lane)
 {
-    const f4 x0 = XF[kq * 64 + lane];
-    const f4 x1 = XF[(nkq + kq) * 64 + lane];
+    f4 x[FT];
+#pragma unroll
+    for (int f = 0; f < FT; f++) x[f] = XF[(f * nkq + kq) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
-            p0 = mfma16x16x4(akq[j], x0[j], p0);
-            p1 = mfma16x16x4(akq[j], x1[j], p1);
+#pragma unroll
+            for (int f = 0; f < FT; f++) p[f] = mfma16x16x4(akq[j], x[f][j], p[f]);
         }
     }
 }
 
-template <int KS, int NKQ, bool EXACT>
-__device__ __forceinline__ void gemm1(f4 &p0, f4 &p1, const f4 (&a)[NKQ], const f4 *__restrict__ XF,
+template <int KS, int NKQ, bool EXACT, int FT>
+__device__ __forceinline__ void gemm1(f4 (&p)[FT], const f4 (&a)[NKQ], const f4 *__restrict__ XF,
                                       int nkq, int ks, int lane)
 {
 #pragma unroll
     for (int kq = 0; kq < NKQ; kq++)
-        if (EXACT || kq < nkq) gemm1_group<KS, EXACT>(p0, p1, a[kq], XF, kq, nkq, ks, lane);
+        if (EXACT || kq < nkq) gemm1_group<KS, EXACT, FT>(p, a[kq], XF, kq, nkq, ks, lane);
 }
 
 // Sigmoid (nn.cpp:796-820) of the 8 pre-activations a lane holds, as a sequence of
@@ -200,22 +202,26 @@ __device__ __forceinline__ void gemm1(f4 &p0, f4 &p1, const f4 (&a)[NKQ], const 
 //     within 2 ulp (2.4e-7 relative) of it, an order of magnitude below the effect of the
 //     products' summation order, and costs ~40 instead of ~90 issue cycles per value.
 // Pad hidden units (>= n_hid) need no zeroing: their layer-2 weights are packed as zeros.
-struct Sig8 {
-    float x[8];      // -x, then e, 1+e, and finally the sigmoid
-    double t[8];
-    float r[8];
-    static constexpr int kStages = 8;
+template <int FT>
+struct SigTile {
+    static constexpr int kN = 4 * FT;
+    float x[kN];     // -x, then e, 1+e, and finally the sigmoid
+    double t[kN];
+    float r[kN];
+    static constexpr int kStages = 6;
 
-    __device__ __forceinline__ void begin(const f4 &p0, const f4 &p1)
+    __device__ __forceinline__ void begin(const f4 (&p)[FT])
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { x[i] = -p0[i]; x[4 + i] = -p1[i]; }
+        for (int f = 0; f < FT; f++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[4 * f + i] = -p[f][i];
     }
     __device__ __forceinline__ void stage(int k)
     {
         const double a = 1048576.0 / 0.69314718055994530942;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < kN; i++) {
             switch (k) {
             case 0: t[i] = a * (double)x[i]; break;
             case 1: {                                   // FEXP's integer hi word (see fexp_d)
@@ -232,50 +238,55 @@ struct Sig8 {
             }
         }
     }
-    __device__ __forceinline__ void finish(f4 &s0, f4 &s1) const
+    __device__ __forceinline__ void finish(f4 (&s)[FT]) const
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { s0[i] = x[i]; s1[i] = x[4 + i]; }
+        for (int f = 0; f < FT; f++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[f][i] = x[4 * f + i];
     }
 };
 
-__device__ __forceinline__ void sigmoid8(f4 &s0, f4 &s1, const f4 &p0, const f4 &p1)
+template <int FT>
+__device__ __forceinline__ void sigmoid_tile(f4 (&s)[FT], const f4 (&p)[FT])
 {
-    Sig8 sg;
-    sg.begin(p0, p1);
+    SigTile<FT> sg;
+    sg.begin(p);
 #pragma unroll
-    for (int k = 0; k < Sig8::kStages; k++) sg.stage(k);
-    sg.finish(s0, s1);
+    for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
+    sg.finish(s);
 }
 
 // layer 2: k-slot g of step r is hidden unit 16ht + 4g + r on both operands
-__device__ __forceinline__ void gemm2_group(f4 &acc0, f4 &acc1, const f4 &wot, const f4 &s0, const f4 &s1)
+template <int FT>
+__device__ __forceinline__ void gemm2_group(f4 (&acc)[FT], const f4 &wot, const f4 (&s)[FT])
 {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        acc0 = mfma16x16x4(wot[r], s0[r], acc0);
-        acc1 = mfma16x16x4(wot[r], s1[r], acc1);
-    }
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(wot[r], s[f][r], acc[f]);
 }
 
-template <int NOT, bool EXACT>
-__device__ __forceinline__ void gemm2(f4 (&acc)[NOT][2], const f4 (&w)[NOT], const f4 &s0, const f4 &s1,
-                                      int n_ot)
+template <int NOT, bool EXACT, int FT>
+__device__ __forceinline__ void gemm2(f4 (&acc)[NOT][FT], const f4 (&w)[NOT], const f4 (&s)[FT], int n_ot)
 {
 #pragma unroll
     for (int ot = 0; ot < NOT; ot++)
-        if (EXACT || ot < n_ot) gemm2_group(acc[ot][0], acc[ot][1], w[ot], s0, s1);
+        if (EXACT || ot < n_ot) gemm2_group<FT>(acc[ot], w[ot], s);
 }
 
 // All-reduce over aligned groups of 8 lanes with DPP (no LDS traffic, unlike __shfl_xor which is a
 // ds_bpermute): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i, i.e. the
 // other quad of the 8-lane half row, which by then holds that quad's result).
-template <typename Op>
-__device__ __forceinline__ float allreduce8(float v, Op op)
+// For 16 lanes one more step: row_mirror (lane i <-> 15-i).
+template <int LANES, typename Op>
+__device__ __forceinline__ float allreduce(float v, Op op)
 {
     v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
     v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
     v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    if constexpr (LANES == 16)
+        v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
     return v;
 }
 
@@ -309,29 +320,212 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
     img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
 }
 
+// compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
+// weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads
+#ifndef LCRC_DBG
+#define LCRC_DBG 0
+#endif
+
+// ---- hidden loop, ring form (shipped shapes, 8 waves per workgroup) -----------------------
+// Two waves share a SIMD (512 threads, <= 256 registers per lane): while one issues loads,
+// LDS reads or VALU work, or waits, the other keeps the MFMA pipe busy
+// (tools/ubench/cross_wave.hip).  To fit the register budget the weight fragments stream
+// through a RING of R registers-quads instead of one buffer per layer.  Per hidden tile t the
+// fragments are consumed in the fixed order
+//     entry e <  NOT         W2(t)[e]         layer 2 of tile t      (8 MFMAs)
+//     entry e <  NOT + NKQ   W1(t+1)[e-NOT]   layer 1 of tile t+1    (8 MFMAs)
+//     entry e <  FP          (padding so that FP % R == 0: ring slots are compile-time)
+// and entry e lives in slot e % R.  Right after the MFMAs of entry i are issued, the fragment
+// of entry i + R (possibly of the next tile) is requested into the slot just consumed: every
+// fragment is requested R groups (>= R * 256 cycles) before its use, and at most R requests
+// are in flight, so the in-order vmcnt waits never drain more than the one fragment needed.
+constexpr int lcrc_ring_size(int f)
+{
+    int best = 8, pad = 1 << 30;
+    for (int r = 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
+        const int p = (f + r - 1) / r * r - f;
+        if (p < pad) { pad = p; best = r; }
+    }
+    return best;
+}
+
+template <int KS, int NOT, int FT>
+struct RingLoop {
+    static constexpr int NKQ = (KS + 3) / 4;
+    static constexpr int F = NOT + NKQ;
+    static constexpr int R = lcrc_ring_size(F);
+    static constexpr int FP = (F + R - 1) / R * R;
+    enum { PRO = 0, MID = 1, LAST = 2 };
+
+    const f4 *w1, *w2;
+    const float *b1;
+    const f4 *XF;
+    int hlast, lane;
+    f4 ring[R];
+
+    // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling
+    __device__ __forceinline__ void request(int slot, int e, int t)
+    {
+        if (e < NOT) {
+            ring[slot] = w2[((size_t)max(0, min(t, hlast)) * NOT + e) * 64 + lane];
+        } else if (e - NOT < NKQ) {
+            const f4 *tb = w1 + (size_t)min(t + 1, hlast) * NKQ * 64;
+            ring[slot] = load_w1_frag<KS, NKQ, true>(tb, e - NOT, lane);
+        }
+    }
+
+    // one pass over the entries of tile t.  PRO: t = first tile - 1, layer-2 entries are skipped
+    // (this computes layer 1 of the first tile); LAST: layer 2 only, nothing new is requested
+    // beyond this tile's own W2 fragments.
+    template <int MODE>
+    __device__ __forceinline__ void pass(f4 (&acc)[NOT][FT], f4 (&pre)[FT], f4 &bias, int t)
+    {
+        constexpr bool kSkipSig = (LCRC_DBG & 2) != 0;
+        constexpr bool kSkipLd = (LCRC_DBG & 4) != 0;
+        const int g = lane >> 4;
+        f4 s[FT], nxt[FT];
+        if (MODE != PRO) {
+            SigTile<FT> sg;
+            sg.begin(pre);
+            if (!kSkipSig) {
+#pragma unroll
+                for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
+            }
+            sg.finish(s);
+        }
+#pragma unroll
+        for (int f = 0; f < FT; f++) nxt[f] = bias;
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE != LAST && !kSkipLd)              // bias of the tile after next: requested first, so
+            bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
+        f4 xb[2][FT];
+        if (MODE != LAST) {
+#pragma unroll
+            for (int f = 0; f < FT; f++) xb[0][f] = XF[f * NKQ * 64 + lane];
+        }
+#pragma unroll
+        for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
+            if (i < NOT) {
+                gemm2_group<FT>(acc[i], ring[i % R], s);
+            } else if (i - NOT < NKQ) {
+                const int kq = i - NOT;
+                if (kq + 1 < NKQ) {                // B fragments of the next group, ahead of the MFMAs
+#pragma unroll
+                    for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * NKQ + kq + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * kq + j < KS) {
+#pragma unroll
+                        for (int f = 0; f < FT; f++) nxt[f] = mfma16x16x4(ring[i % R][j], xb[kq & 1][f][j], nxt[f]);
+                    }
+            }
+            const int e = (i + R) % FP, dt = (i + R) / FP;
+            if (!kSkipLd && (MODE != LAST || (dt == 0 && e < NOT))) request(i % R, e, t + dt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE != LAST) {
+#pragma unroll
+            for (int f = 0; f < FT; f++) pre[f] = nxt[f];
+        }
+        LCRC_FENCE();
+    }
+
+    __device__ __forceinline__ void run(f4 (&acc)[NOT][FT], int ht0, int ht1)
+    {
+        const int g = lane >> 4;
+        f4 bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(ht0, hlast) + 4 * g);
+        // ring fill for the prologue pass: entries NOT .. NOT+R-1 of pseudo tile ht0 - 1
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int e = NOT + k;
+            request(e % R, e % FP, ht0 - 1 + e / FP);
+        }
+        LCRC_FENCE();
+        f4 pre[FT];
+        pass<PRO>(acc, pre, bias, ht0 - 1);       // (a wave without tiles computes a dummy)
+        for (int ht = ht0; ht < ht1 - 1; ht++) pass<MID>(acc, pre, bias, ht);
+        if (ht0 < ht1) pass<LAST>(acc, pre, bias, ht1 - 1);
+    }
+};
+
+// ---- hidden loop, phased form (generic shapes, 4 waves per workgroup, one wave per SIMD) ----
+//   prologue   W1(t0) -> layer 1 of tile t0 -> pre, W1(t0+1)
+//   per tile t    issue W2(t) | sigmoid(pre) , layer 1 of tile t+1 | issue W1(t+2) | layer 2 of tile t
+//   last tile     sigmoid + layer 2 only
+// All prefetches are UNCONDITIONAL (indices clamped instead): a load under a branch makes the
+// compiler fall back to s_waitcnt vmcnt(0) at the join.
+template <int KS, int NOT, int FT>
+__device__ __forceinline__ void hidden_loop_phased(f4 (&acc)[NOT][FT], const f4 *w1, const f4 *w2, const float *b1,
+                                                   const f4 *__restrict__ XF, const NetDev &nd, int ht0, int ht1,
+                                                   int hlast, int lane)
+{
+    constexpr int NKQ = (KS + 3) / 4;
+    constexpr bool EXACT = false;
+    const int ks = nd.ksteps, nkq = nd.nkq, n_ot = nd.n_ot;
+    constexpr int wsel = (LCRC_DBG & 1) ? 0 : 1;
+    f4 a[NKQ];
+    f4 bias;
+    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0, hlast), nkq, lane);
+    LCRC_FENCE();
+    f4 pre[FT];
+#pragma unroll
+    for (int f = 0; f < FT; f++) pre[f] = bias;
+    gemm1<KS, NKQ, EXACT, FT>(pre, a, XF, nkq, ks, lane);  // (a wave without tiles computes a dummy)
+    LCRC_FENCE();
+    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0 + 1, hlast), nkq, lane);
+    LCRC_FENCE();
+    for (int ht = ht0; ht < ht1 - 1; ht++) {
+        f4 w[NOT];
+        f4 nxt[FT], s[FT];
+#pragma unroll
+        for (int f = 0; f < FT; f++) nxt[f] = bias;
+        const f4 *t2 = w2 + (size_t)wsel * ht * n_ot * 64;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ot++)
+            if (ot < n_ot) w[ot] = t2[ot * 64 + lane];
+        LCRC_FENCE();
+        sigmoid_tile<FT>(s, pre);
+        gemm1<KS, NKQ, EXACT, FT>(nxt, a, XF, nkq, ks, lane);
+        LCRC_FENCE();
+        load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht + 2, hlast), nkq, lane);
+        LCRC_FENCE();
+        gemm2<NOT, EXACT, FT>(acc, w, s, n_ot);
+#pragma unroll
+        for (int f = 0; f < FT; f++) pre[f] = nxt[f];
+    }
+    if (ht0 < ht1) {                       // last tile of this wave
+        f4 w[NOT];
+        const f4 *t = w2 + (size_t)wsel * (ht1 - 1) * n_ot * 64;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ot++)
+            if (ot < n_ot) w[ot] = t[ot * 64 + lane];
+        f4 s[FT];
+        sigmoid_tile<FT>(s, pre);
+        gemm2<NOT, EXACT, FT>(acc, w, s, n_ot);
+    }
+}
+
 // Runs one net.  On return `epi(frame, o, posterior, valid)` has been called with valid == true once
 // for every (frame, output) of the tile by SOME thread (calls with valid == false carry a clamped
 // output index and must not store), and a __syncthreads() has been passed.
-template <int KS, int NOT, int NW, bool EXACT, typename Epi>
+template <int KS, int NOT, int NW, bool EXACT, int FT, typename Epi>
 __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const NetDev &nd,
                                         const f4 *__restrict__ XF, f4 *__restrict__ slab,
                                         int n_ot_slab, int lane, int wave, Epi epi)
 {
-    constexpr int NKQ = (KS + 3) / 4;
-    const int ks = EXACT ? KS : nd.ksteps;
-    const int nkq = EXACT ? NKQ : nd.nkq;
     const int n_ot = EXACT ? NOT : nd.n_ot;
     const int g = lane >> 4;
 
     // layer-2 accumulators: acc[ot][f][rr] = O^T[16ot + 4g + rr][16f + (lane&15)]
-    f4 acc[NOT][2];
+    f4 acc[NOT][FT];
 #pragma unroll
     for (int ot = 0; ot < NOT; ot++) {
         f4 b = {0.f, 0.f, 0.f, 0.f};
         if (wave == 0 && (EXACT || ot < n_ot))
             b = *reinterpret_cast<const f4 *>(nd.b2 + 16 * ot + 4 * g);   // PrepareBiases nn.cpp:857
-        acc[ot][0] = b;
-        acc[ot][1] = b;
+#pragma unroll
+        for (int f = 0; f < FT; f++) acc[ot][f] = b;
     }
 
     const int tpw = (nd.nht + NW - 1) / NW;
@@ -341,105 +535,20 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
     const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
     const f4 *const w2 = reinterpret_cast<const f4 *>(nd.w2p);
     const float *const b1 = nd.b1;
-    // compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
-    // weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads
-#ifndef LCRC_DBG
-#define LCRC_DBG 0
-#endif
-    constexpr int dbg_skip_sig = LCRC_DBG & 2;
-    constexpr int dbg_skip_ld = LCRC_DBG & 4;
     const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
-    constexpr int wsel = (LCRC_DBG & 1) ? 0 : 1;
 
-    // All prefetches are UNCONDITIONAL (indices clamped instead): a load under a branch
-    // makes the compiler fall back to s_waitcnt vmcnt(0) at the join.
-    f4 a[NKQ];
-    f4 bias;
-    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0, hlast), nkq, lane);
-    LCRC_FENCE();
-    f4 p0 = bias, p1 = bias;
-    gemm1<KS, NKQ, EXACT>(p0, p1, a, XF, nkq, ks, lane);   // (a wave without tiles computes a dummy)
-    LCRC_FENCE();
-    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0 + 1, hlast), nkq, lane);
-    LCRC_FENCE();
-
-    for (int ht = ht0; ht < ht1 - 1; ht++) {
-        f4 w[NOT];
-        f4 q0 = bias, q1 = bias, s0, s1;
-        if constexpr (EXACT) {
-            // ---- region A: sigmoid(t) as ONE block of VALU work, then layer 1 of tile t+1 in
-            //      8-MFMA groups with the requests for W2(t) spread behind them.
-            //      v_mfma_f32_16x16x4_f32 executes on the SIMD's f32 FMA lanes: VALU work
-            //      does not overlap with it, and every MFMA<->VALU switch costs ~3 idle cycles
-            //      on top (tools/ubench/valu_overlap.hip: MFMA 32.1, +6.4 for one v_fma_f32
-            //      behind it, +2.5..3 for each further one).  So VALU instructions are kept
-            //      together, not interleaved, and their number is what is optimised. ----
-            constexpr int WPG = (NOT + NKQ - 1) / NKQ;      // W2 fragments per layer-1 group
-            const f4 *t2 = w2 + (size_t)wsel * ht * NOT * 64;
-            Sig8 sg;
-            sg.begin(p0, p1);
-            if (!dbg_skip_sig) {
-#pragma unroll
-                for (int k = 0; k < Sig8::kStages; k++) sg.stage(k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kq = 0; kq < NKQ; kq++) {
-#pragma unroll
-                for (int i = 0; i < WPG; i++)
-                    if (kq * WPG + i < NOT && (!dbg_skip_ld || ht == ht0)) w[kq * WPG + i] = t2[(kq * WPG + i) * 64 + lane];
-                gemm1_group<KS, EXACT>(q0, q1, a[kq], XF, kq, nkq, ks, lane);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            sg.finish(s0, s1);
-            LCRC_FENCE();
-            // ---- region B: layer 2 of tile t; behind group ot go the requests for
-            //      W1(t+2) fragments (and the bias) ----
-            const int hn = min(ht + 2, hlast);
-            const f4 *t1 = w1 + (size_t)hn * NKQ * 64;
-            constexpr int LPG = (NKQ + NOT - 1) / NOT;      // W1 fragments per layer-2 group
-#pragma unroll
-            for (int ot = 0; ot < NOT; ot++) {
-#pragma unroll
-                for (int i = 0; i < LPG; i++)
-                    if (ot * LPG + i < NKQ && !dbg_skip_ld) a[ot * LPG + i] = load_w1_frag<KS, NKQ, EXACT>(t1, ot * LPG + i, lane);
-                if (ot == NOT - 1 && !dbg_skip_ld) bias = *reinterpret_cast<const f4 *>(b1 + 16 * hn + 4 * g);
-                gemm2_group(acc[ot][0], acc[ot][1], w[ot], s0, s1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            LCRC_FENCE();
-        } else {
-            // generic shapes: same phases, no hand-placed interleave
-            const f4 *t2 = w2 + (size_t)wsel * ht * n_ot * 64;
-#pragma unroll
-            for (int ot = 0; ot < NOT; ot++)
-                if (ot < n_ot) w[ot] = t2[ot * 64 + lane];
-            LCRC_FENCE();
-            sigmoid8(s0, s1, p0, p1);
-            gemm1<KS, NKQ, EXACT>(q0, q1, a, XF, nkq, ks, lane);
-            LCRC_FENCE();
-            load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht + 2, hlast), nkq, lane);
-            LCRC_FENCE();
-            gemm2<NOT, EXACT>(acc, w, s0, s1, n_ot);
-        }
-        p0 = q0;
-        p1 = q1;
-    }
-    if (ht0 < ht1) {                       // last tile of this wave
-        f4 w[NOT];
-        const f4 *t = w2 + (size_t)wsel * (ht1 - 1) * n_ot * 64;
-#pragma unroll
-        for (int ot = 0; ot < NOT; ot++)
-            if (EXACT || ot < n_ot) w[ot] = t[ot * 64 + lane];
-        f4 s0, s1;
-        sigmoid8(s0, s1, p0, p1);
-        gemm2<NOT, EXACT>(acc, w, s0, s1, n_ot);
+    if constexpr (EXACT) {
+        RingLoop<KS, NOT, FT> loop;
+        loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
+        loop.run(acc, ht0, ht1);
+    } else {
+        hidden_loop_phased<KS, NOT, FT>(acc, w1, w2, b1, XF, nd, ht0, ht1, hlast, lane);
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
     // ---- fold the NW partial tiles down to TWO slabs, then every thread sums the two while
     //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
-    const int slab_f4 = 2 * n_ot_slab * 64;     // float4 per slab
+    const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
 #pragma unroll
     for (int top = NW; top > 2; top -= 2) {      // waves [top-2, top) fold into [top-4, top-2)
         if (wave >= top - 2 && wave < top) {
@@ -447,8 +556,8 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
 #pragma unroll
             for (int ot = 0; ot < NOT; ot++)
                 if (EXACT || ot < n_ot) {
-                    s[(ot * 2 + 0) * 64] = acc[ot][0];
-                    s[(ot * 2 + 1) * 64] = acc[ot][1];
+#pragma unroll
+                    for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
                 }
         }
         __syncthreads();
@@ -458,11 +567,10 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
 #pragma unroll
             for (int ot = 0; ot < NOT; ot++)
                 if (EXACT || ot < n_ot) {
-                    acc[ot][0] += s[(ot * 2 + 0) * 64];
-                    acc[ot][1] += s[(ot * 2 + 1) * 64];
-                    if (last) {
-                        s[(ot * 2 + 0) * 64] = acc[ot][0];
-                        s[(ot * 2 + 1) * 64] = acc[ot][1];
+#pragma unroll
+                    for (int f = 0; f < FT; f++) {
+                        acc[ot][f] += s[(ot * FT + f) * 64];
+                        if (last) s[(ot * FT + f) * 64] = acc[ot][f];
                     }
                 }
         }
@@ -471,9 +579,9 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
     LCRC_STAMP(prm, wave, lane, 12 + (stamp0 == 8 ? 0 : 0));   // fold done (last net's value survives)
     // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a frame, each
     // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
-    // frame = 16f + c  ->  float index ((2ot + f)*64 + 16g + c)*4 + rr.
+    // frame = 16f + c  ->  float index ((FT*ot + f)*64 + 16g + c)*4 + rr.
     {
-        constexpr int LPF = NW * 64 / kBM;       // lanes cooperating on one frame
+        constexpr int LPF = NW * 64 / (16 * FT); // lanes cooperating on one frame
         constexpr int NV = 16 * NOT / LPF;       // values per lane
         const int tid = wave * 64 + lane;
         const int frame = tid / LPF, part = tid % LPF;
@@ -488,21 +596,31 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
             const int o = part + LPF * j;
             // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
             // unconditionally so the 2*NV LDS reads are issued back to back, select afterwards
-            const int idx = fbase + (o >> 4) * 512 + ((o >> 2) & 3) * 64 + (o & 3);
+            const int idx = fbase + (o >> 4) * (256 * FT) + ((o >> 2) & 3) * 64 + (o & 3);
             const float t = sa[idx] + sb[idx];
             v[j] = o < O ? t : -FLT_MAX;
             m = fmaxf(m, v[j]);
         }
-        static_assert(LPF == 8, "softmax lane groups are 8 wide (4 waves x 64 lanes over 32 frames)");
-        m = allreduce8(m, [](float a, float b) { return fmaxf(a, b); });
-        float sum = 0.0f;
+        static_assert(LPF == 8 || LPF == 16, "softmax lane groups are 8 (4 waves) or 16 (8 waves) wide");
+        m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
+        // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly, whatever
+        // the workgroup's frame count: with 8 lanes per frame a lane carries two of the 16 partials
+        // (even / odd j) and the last butterfly step becomes a plain add, so 16- and 32-frame
+        // workgroups produce the same bits.
+        float sum = 0.0f, sum_hi = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
             v[j] = part + LPF * j < O ? e : 0.0f;
-            sum += v[j];
+            if (LPF == 8 && (j & 1)) sum_hi += v[j]; else sum += v[j];
         }
-        sum = allreduce8(sum, [](float a, float b) { return a + b; });
+        if constexpr (LPF == 8) {
+            sum = allreduce<8>(sum, [](float a, float b) { return a + b; });
+            sum_hi = allreduce<8>(sum_hi, [](float a, float b) { return a + b; });
+            sum += sum_hi;
+        } else {
+            sum = allreduce<16>(sum, [](float a, float b) { return a + b; });
+        }
         const float scale = 1.0f / sum;
         __syncthreads();                          // slabs are free again (the epilogue may reuse them)
         LCRC_STAMP(prm, wave, lane, 13);
@@ -515,9 +633,11 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
     __syncthreads();
 }
 
-template <int KS1, int KSM, int NOT, int NW, bool EXACT>
+template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT>
 __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
+    constexpr int BM = 16 * FT;                 // frames per workgroup
+    constexpr int kTileRows = BM + 2 * kShift;  // mel rows staged
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = NW * 64;
     const int tid = threadIdx.x;
@@ -527,11 +647,11 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int nkq1 = EXACT ? (KS1 + 3) / 4 : p.net[0].nkq;
     const int nkqm = EXACT ? (KSM + 3) / 4 : p.net[2].nkq;
     const int n_ot = EXACT ? NOT : p.n_ot_slab;
-    const LdsPlan lp = lcrc_lds_plan(nb, nkq1, nkqm, n_ot);
+    const LdsPlan lp = lcrc_lds_plan(FT, nb, nkq1, nkqm, n_ot);
 
     float *melT = reinterpret_cast<float *>(smem + lp.mel);
     int *rowlo = reinterpret_cast<int *>(smem + lp.rowinfo);
-    int *rowhi = rowlo + kBM;
+    int *rowhi = rowlo + BM;
     float *costab = reinterpret_cast<float *>(smem + lp.tabs);
     float *win = costab + 10 * 16;
     // normalisation vectors of the three nets: [mean | dev] per net
@@ -541,12 +661,12 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     float *gf = reinterpret_cast<float *>(smem + lp.gf);
     f4 *slab = reinterpret_cast<f4 *>(smem + lp.slab);
 
-    const int r0 = blockIdx.x * kBM;
+    const int r0 = blockIdx.x * BM;
     const int tbase = r0 - kShift;
 
     LCRC_STAMP(p, wave, lane, 0);
     // ---- stage 0: utterance bounds per frame, mel tile, tables, zeroed operand images ----
-    if (tid < kBM) {
+    if (tid < BM) {
         const int r = min(r0 + tid, p.n_rows - 1);
         if (p.off == nullptr) {                 // one utterance of n_rows frames
             rowlo[tid] = 0;
@@ -605,9 +725,9 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         }
         const int items = 2 * nb;                // (net, band) pairs, dealt to the waves
         // per-lane constants of both frame tiles: clamp bounds and centre row
-        int rr[2], lo[2], hi[2];
+        int rr[FT], lo[FT], hi[FT];
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
+        for (int f = 0; f < FT; f++) {
             const int i = 16 * f + c;            // this lane's frame as an A-operand row
             rr[f] = min(r0 + i, p.n_rows - 1) - kShift;
             lo[f] = rowlo[i];
@@ -617,33 +737,34 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         for (int it = wave; it < items; it += NW) {
             const int n = it / nb, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
-            float *img = xf + (size_t)n * (2 * nkq1 * 256);
+            float *img = xf + (size_t)n * (FT * nkq1 * 256);
             float *dbg = n == 0 ? p.dbg_in0 : p.dbg_in1;
             // all eight operand values first (independent LDS reads), then the eight MFMAs
-            float xw[2][4];
+            float xw[FT][4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
                 const int tap = 4 * s4 + g;
                 const float w = win[n * kHalf + tap];
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < FT; f++) {
                     const int srow = max(lo[f], min(hi[f], rr[f] + n * kShift + tap));
                     xw[f][s4] = melT[(srow - tbase) * nb + b] * w;
                 }
             }
             const int k = b * kNCoef + cc;
             const float mk = mean[k], dk = dev[k];
-            f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f4 acc[FT];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                acc[0] = mfma16x16x4(xw[0][s4], basis[s4], acc[0]);
-                acc[1] = mfma16x16x4(xw[1][s4], basis[s4], acc[1]);
-            }
+            for (int f = 0; f < FT; f++) acc[f] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(xw[f][s4], basis[s4], acc[f]);
             if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
                 // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
                 const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
+                for (int f = 0; f < FT; f++) {
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const int fr = 16 * f + 4 * g + reg;
@@ -680,9 +801,9 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             v *= mdev[kofs + o];
             if (valid) xf_store(gf, nkqm, i, kofs + o, v);
         };
-        run_net<KS1, NOT, NW, EXACT>(p, 2 + 3 * n, nd,
-                                     reinterpret_cast<const f4 *>(xf) + (size_t)n * (2 * nkq1 * 64), slab,
-                                     n_ot, lane, wave, epi);
+        run_net<KS1, NOT, NW, EXACT, FT>(p, 2 + 3 * n, nd,
+                                         reinterpret_cast<const f4 *>(xf) + (size_t)n * (FT * nkq1 * 64), slab,
+                                         n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 3 + 3 * n);   // fold + softmax + ln() done
         LCRC_STAMP(p, wave, lane, 4 + 3 * n);
     }
@@ -701,11 +822,11 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
             if (valid) outbuf[i * O + o] = q;
         };
-        run_net<KSM, NOT, NW, EXACT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
+        run_net<KSM, NOT, NW, EXACT, FT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
-        const int rows = min(kBM, p.n_rows - r0);
+        const int rows = min(BM, p.n_rows - r0);
         const int total = rows * O;
-        float *dst = p.post + (size_t)r0 * O;      // 32*O*4 bytes per tile: 16-byte aligned
+        float *dst = p.post + (size_t)r0 * O;      // 16*O*4 bytes per frame tile: 16-byte aligned
         const int n4 = total >> 2;
         for (int i = tid; i < n4; i += NT)
             reinterpret_cast<f4 *>(dst)[i] = reinterpret_cast<const f4 *>(outbuf)[i];
@@ -719,17 +840,18 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 // CZ 165->1500->138 / 276  HU ..->186 / 372  RU 165->1400->159 / 318  EN 253->500->120 / 240
 namespace {
 
-constexpr int kNW = 4;
+constexpr int kNW = 4;   // waves per workgroup: one per SIMD (two per SIMD do not pay)
 constexpr int kGenKS1 = 64, kGenKSM = 104, kGenNOT = 13;   // generic: <= 23 banks, <= 208 outputs
 
 struct Variant {
     const char *name;
     int ks1, ksm, n_ot;    // 0,0,0 = generic
-    const void *fn;
+    const void *fn[2];     // [FT - 1]: 16- and 32-frame workgroups
 };
 
 #define LCRC_KERNEL(KS1, KSM, NOT, EX) \
-    reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX>)
+    {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1>), \
+     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 2>)}
 
 const Variant kVariants[] = {
     {"cz_42_69_9", 42, 69, 9, LCRC_KERNEL(42, 69, 9, true)},
@@ -757,7 +879,7 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
 {
     const Variant *v = pick(nets);
     if (!v) return nullptr;
-    const LdsPlan lp = lcrc_lds_plan(nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets));
+    const LdsPlan lp = lcrc_lds_plan(2, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets));
     if (lds_bytes) *lds_bytes = lp.total;
     if (lp.total > 160u * 1024u) return nullptr;
     return v->name;
@@ -767,26 +889,41 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
 {
     const Variant *v = pick(p.net);
     if (!v) return hipErrorInvalidValue;
-    const LdsPlan lp = lcrc_lds_plan(p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
-    if (lp.total > 160u * 1024u) return hipErrorInvalidValue;
+    if (lcrc_lds_plan(2, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
+        return hipErrorInvalidValue;
     if (variant_name) *variant_name = v->name;
     if (p.n_rows <= 0) return hipSuccess;
     // > 64 KiB of dynamic LDS has to be granted per function and per device: once, not per launch
-    static bool granted[sizeof kVariants / sizeof kVariants[0]][64] = {};
+    static bool granted[sizeof kVariants / sizeof kVariants[0]][2][64] = {};
+    static int cus[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const int vi = (int)(v - kVariants);
-    if (dev < 0 || dev >= 64 || !granted[vi][dev]) {
-        e = hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const bool cached = dev >= 0 && dev < 64;
+    int n_cu = cached ? cus[dev] : 0;
+    if (n_cu == 0) {
+        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) granted[vi][dev] = true;
+        if (cached) cus[dev] = n_cu;
     }
-    const dim3 grid((p.n_rows + kBM - 1) / kBM), block(kNW * 64);
+    // 32-frame workgroups load every weight fragment once per 32 frames; 16-frame workgroups twice as
+    // often, but there are twice as many of them: they win while the 32-frame grid would leave at
+    // least half of the CUs without work.
+    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
+    const int vi = (int)(v - kVariants);
+    const void *fn = v->fn[ft - 1];
+    if (!cached || !granted[vi][ft - 1][dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (cached) granted[vi][ft - 1][dev] = true;
+    }
+    const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
+    const int bm = 16 * ft;
+    const dim3 grid((p.n_rows + bm - 1) / bm), block(kNW * 64);
     LcrcParams args = p;
     args.n_ot_slab = lcrc_n_ot_slab(p.net);
     void *kargs[] = {&args};
-    return hipLaunchKernel(v->fn, grid, block, kargs, lp.total, stream);
+    return hipLaunchKernel(fn, grid, block, kargs, lp.total, stream);
 }
 
 }  // namespace phnrec

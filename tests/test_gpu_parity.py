@@ -340,3 +340,29 @@ def test_posterior_writer_path_on_device(capi, tmp_path):
     assert np.array_equal(ctx.posteriors_batch(mel, off), plain)
     with pytest.raises(capi.LcrcError):
         ctx.configure_output(("log", "log", "log"))
+
+
+def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
+    """16- and 32-frame workgroups (lcrc_set_tile_frames; the launcher picks by launch size) on the same
+    ragged batches, shipped-shape (ring loop) and generic kernels: both within the bar of the oracle and
+    bit-identical to each other (the softmax sums are grouped the same way in both)"""
+    for nb, hid, nout, name in ((15, 200, 138, "cz_42_69_9"), (23, 96, 120, "en_64_60_8"), (11, 70, 33, "generic")):
+        d = str(tmp_path / name)
+        modelgen.write_model_dir(d, nb, hid, nout, seed=21)
+        ctx = capi.Lcrc(d, nb)
+        assert ctx.kernel_name == name
+        o = oracle_mod.Oracle(d, nb)
+        lens = [1, 15, 16, 17, 31, 32, 33, 0, 47, 100]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), nb, seed=9)
+        want = o.posteriors_batch(mel, off)
+        got = {}
+        for frames in (16, 32, 0):
+            ctx.set_tile_frames(frames)
+            got[frames] = ctx.posteriors_batch(mel, off)
+            assert np.abs(got[frames] - want).max() < TOL, (name, frames)
+        assert np.array_equal(got[16], got[32])
+        assert np.array_equal(got[0], got[16])
+        with pytest.raises(capi.LcrcError):
+            ctx.set_tile_frames(24)
+        ctx.close()
