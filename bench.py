@@ -46,6 +46,25 @@ def model_directory(tmp):
     return d, "seeded random weights of the %s shape" % SYSTEM
 
 
+def usable_cpus():
+    """CPUs this process may use: the affinity mask capped by the cgroup quota (the GPU boxes show all
+    host cores but grant a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     """The reference CPU path on this host, bounded to ~budget_s seconds per variant."""
     os.environ.setdefault("MKL_NUM_THREADS", "1")
@@ -83,7 +102,7 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     t0 = time.perf_counter()
     p1 = o.posteriors(mel[:n1 + 15])[:n1]
     dt1 = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     nall, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < min(budget_s, 5.0):
         o.posteriors(mel, threads=cores)
@@ -92,7 +111,7 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     port = {"value": round(n1 / dt1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "first %d frames, %.1f s" % (n1, dt1),
             "parity_max_abs_vs_gpu": float(np.abs(p1 - gpu_post[:n1]).max()),
-            "all_cores": {"value": round(nall / dta, 1), "cores": cores,
+            "all_cores": {"value": round(nall / dta, 1), "cores": cores, "cores_visible": os.cpu_count(),
                           "sample": "%d frames, %.1f s" % (nall, dta)}}
     if out is None:
         return port

@@ -1,6 +1,7 @@
 // srec.cpp -- see srec.h
 #include "srec.h"
 
+#include <sched.h>
 #include <sys/stat.h>
 
 #include <atomic>
@@ -61,6 +62,30 @@ struct Group {
     std::condition_variable cv;
     int pending = 0;
 };
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (containers
+// commonly show all of the host's cores but grant a fraction; a pool sized to the former is throttled).
+int UsableCpus()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+        fclose(f1);
+        if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f2, "%lld", &period) != 1) period = 0;
+            fclose(f2);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1LL, (quota + period - 1) / period));
+    return n;
+}
 
 ThreadPool::ThreadPool(int n)
 {
@@ -450,11 +475,15 @@ bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job
     return true;
 }
 
+// File lists run as a two-stage pipeline over chunks of kChunkFiles files: while the GPU contexts and
+// the decoder / writers work on chunk c, the pool already reads (and, without -F, front-ends) the
+// files of chunk c + 1.  Outputs appear in list order; a failing file stops the run like the
+// reference's sequential loop does (files before it have been written).
 bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf)
 {
     const auto t0 = std::chrono::steady_clock::now();
     if (!pool_) {
-        const int threads = host_threads_ > 0 ? host_threads_ : (int)std::max(1u, std::thread::hardware_concurrency());
+        const int threads = host_threads_ > 0 ? host_threads_ : UsableCpus();
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
     }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
@@ -466,24 +495,34 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
     stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
     const int n = (int)jobs.size();
     for (const Job &j : jobs) Log(j.tgt.empty() ? j.src + "\n" : j.src + " -> " + j.tgt + "\n");
-    pool_->ParallelFor(n, [&](int i) { Stage1(in, out, jobs[i]); });
-    for (const Job &j : jobs) if (!j.ok) return Fail(j.err);
-    stats_.stage1_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 
-    if (!need_gpu) {
-        pool_->ParallelFor(n, [&](int i) {
-            Job &j = jobs[i];
-            Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
-        });
-    } else {
+    constexpr int kChunkFiles = 512;
+    std::atomic<long long> stage1_us(0);
+    auto stage1 = [&](int lo, int hi) {
+        const auto s0 = std::chrono::steady_clock::now();
+        pool_->ParallelFor(hi - lo, [&](int i) { Stage1(in, out, jobs[lo + i]); });
+        stage1_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - s0).count();
+    };
+    auto first_error = [&](int lo, int hi) -> const Job * {
+        for (int i = lo; i < hi; i++) if (!jobs[i].ok) return &jobs[i];
+        return nullptr;
+    };
+    auto stage23 = [&](int lo, int hi) -> bool {
+        if (!need_gpu) {
+            pool_->ParallelFor(hi - lo, [&](int i) {
+                Job &j = jobs[lo + i];
+                Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
+            });
+            return true;
+        }
         // Consecutive utterances are packed into launches of <= batch_frames_ frames.  The GPU
         // contexts pull launches from one queue (no exchange between GPUs: every context holds all
         // weights).  Per launch: features are gathered straight into the context's pinned staging
         // buffer, and the decoder / HTK writer read the posteriors straight out of it.
         std::vector<std::pair<int, int>> batches;      // [first, last) job index
-        for (int i = 0; i < n;) {
+        for (int i = lo; i < hi;) {
             int j = i, frames = 0;
-            while (j < n && (j == i || frames + jobs[j].frames <= batch_frames_)) frames += jobs[j++].frames;
+            while (j < hi && (j == i || frames + jobs[j].frames <= batch_frames_)) frames += jobs[j++].frames;
             batches.emplace_back(i, j);
             i = j;
         }
@@ -556,12 +595,29 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
             if (!errs[g].empty()) return Fail(errs[g] + "\n");
             stats_.gpu_kernel_ms += kms[g];
         }
-        for (const Job &j : jobs) stats_.frames += j.frames;
+        for (int i = lo; i < hi; i++) stats_.frames += jobs[i].frames;
+        return true;
+    };
+
+    bool ok = true;
+    stage1(0, std::min(n, kChunkFiles));
+    for (int lo = 0; lo < n && ok; lo += kChunkFiles) {
+        const int hi = std::min(n, lo + kChunkFiles), nhi = std::min(n, hi + kChunkFiles);
+        if (const Job *bad = first_error(lo, hi)) { ok = Fail(bad->err); break; }
+        std::thread ahead;
+        if (hi < n) ahead = std::thread([&, hi, nhi] { stage1(hi, nhi); });
+        ok = stage23(lo, hi);
+        if (ahead.joinable()) ahead.join();
+        if (!ok) break;
+        for (int i = lo; i < hi; i++) {
+            Job &j = jobs[i];
+            if (!j.ok) { ok = Fail(j.err); break; }
+            if (mlf) fputs(j.labels.c_str(), mlf);
+            j = Job();                               // results are out: release the buffers
+        }
     }
-    for (Job &j : jobs) {
-        if (!j.ok) return Fail(j.err);
-        if (mlf) fputs(j.labels.c_str(), mlf);
-    }
+    stats_.stage1_seconds += stage1_us.load() * 1e-6;
+    if (!ok) return false;
     stats_.files += n;
     stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     return true;

@@ -39,6 +39,8 @@ struct RunStats {
 
 // Persistent worker pool; ParallelFor may be called from several threads at once (each GPU
 // worker farms its gather / decode loops out to the same pool).
+int UsableCpus();   // affinity mask capped by the cgroup CPU quota
+
 class ThreadPool {
 public:
     explicit ThreadPool(int n);

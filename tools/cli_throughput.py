@@ -35,6 +35,19 @@ def main():
         lst = os.path.join(td, "list.scp")
         open(lst, "w").write("".join(n + "\n" for n in names))
         print("files %d, frames %d (%.1f h of audio)" % (n_files, total, total / 360000.0), flush=True)
+        # how fast can this box read the list at all?  (16 reader threads, page cache)
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.time()
+        with ThreadPoolExecutor(16) as ex:
+            nbytes = sum(ex.map(lambda p: len(open(p, "rb").read()), names))
+        dt = time.time() - t0
+        print("plain read of the list: %.1f MB in %.3f s (%.2f GB/s); usable cores: %d" %
+              (nbytes / 1e6, dt, nbytes / dt / 1e9, len(os.sched_getaffinity(0))), flush=True)
+        try:
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            print("cgroup cpu.max:", q, flush=True)
+        except OSError:
+            pass
         env = dict(os.environ, PHNREC_STATS="1")
         for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
