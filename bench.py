@@ -65,6 +65,29 @@ def usable_cpus():
     return n
 
 
+def reference_scaling(mdir, nbanks, seconds):
+    """The reference code in its sgemm regime (bunch_size=512), on one core and on every usable core
+    (one process per core, each on its own utterance: the reference is not thread-safe)."""
+    import subprocess
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    res = {}
+    for label, procs in (("sgemm_1core", 1), ("sgemm_all_cores", usable_cpus())):
+        cmd = lambda i: [sys.executable, worker, mdir, str(nbanks), "512", "1", str(seconds), str(100 + i), "2048"]
+        try:
+            ps = [subprocess.Popen(cmd(i), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                  for i in range(procs)]
+            outs = [json.loads(p.communicate(timeout=120)[0].strip().splitlines()[-1]) for p in ps]
+        except Exception as e:      # the baseline is reported when it can be measured, never fatal
+            res[label] = {"error": repr(e)}
+            continue
+        res[label] = {"value": round(sum(o["frames"] for o in outs) / max(o["seconds"] for o in outs), 1),
+                      "unit": "frames/s", "cores": procs, "kind": "reference",
+                      "variant": "USE_BLAS (MKL cblas_sgemm), bunch_size=512, %d process(es)" % procs,
+                      "sample": "%d frames in %.1f s" % (sum(o["frames"] for o in outs),
+                                                        max(o["seconds"] for o in outs))}
+    return res
+
+
 def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     """The reference CPU path on this host, bounded to ~budget_s seconds per variant."""
     os.environ.setdefault("MKL_NUM_THREADS", "1")
@@ -95,6 +118,8 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
                            else "naive loop (no BLAS), bunch_size=5"),
                "sample": "%d frames of the bench batch (512-frame chunks + 15-frame halos), %.1f s" % (work, dt),
                "parity_max_abs_vs_gpu": worst}
+        if blas:
+            out.update(reference_scaling(mdir, nbanks, min(budget_s, 4.0)))
         break
     # this repo's port, single thread and all cores (frames split over threads)
     o = ob.Oracle(mdir, nbanks)

@@ -665,6 +665,14 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int tbase = r0 - kShift;
 
     LCRC_STAMP(p, wave, lane, 0);
+#ifdef LCRC_STAMPS
+    if (p.stamps && lane == 0) {     // where this wave runs: XCC_ID << 32 | HW_ID (SE, CU, SIMD bits)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.stamps[((size_t)blockIdx.x * 8 + wave) * 16 + 14] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // ---- stage 0: utterance bounds per frame, mel tile, tables, zeroed operand images ----
     if (tid < BM) {
         const int r = min(r0 + tid, p.n_rows - 1);

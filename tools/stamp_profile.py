@@ -42,7 +42,8 @@ def main():
     print("ablation build LCRC_DBG =", dbg)
     mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
     post = torch.empty((n, ctx.n_out), device="cuda")
-    bm = int(os.environ.get("LCRC_BM", "32"))
+    bm = int(os.environ.get("LCRC_BM", "32"))                 # frames per workgroup (forced below)
+    ctx.set_tile_frames(bm)
     grid = (n + bm - 1) // bm
     stamps = torch.zeros((grid, 8, 16), dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
@@ -51,7 +52,7 @@ def main():
             L.lcrc_debug_set_stamps(ctx.h, stamps.data_ptr())
         ctx.posteriors_device(mel.data_ptr(), n, post.data_ptr(), stream=s.cuda_stream)
     s.synchronize()
-    nw = 4 if ctx.kernel_name == "generic" else 8             # waves per workgroup
+    nw = 4                                                    # waves per workgroup
     st = stamps.cpu().numpy()[:, :nw, :].astype(np.int64)
     seq = st[:, :, ORDER]
     d = np.diff(seq, axis=2)                                   # [grid][wave][phase]
