@@ -222,6 +222,42 @@ class Oracle:
         return post
 
 
+class TrapsOracle:
+    """traps_oracle.c: the 1BT_DCT / 1BT / 3BT variants of Traps (stateless whole-utterance form)."""
+
+    def __init__(self, model_dir, system, nbanks, add_c0=True, hamming=False):
+        L = lib()
+        L.orc_traps_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_traps_destroy.argtypes = [C.c_void_p]
+        L.orc_traps_num_outputs.argtypes = [C.c_void_p]
+        L.orc_traps_num_band_nets.argtypes = [C.c_void_p]
+        L.orc_traps_posteriors_batch.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int, _f32p, C.c_void_p]
+        self.L = L
+        self.h = C.c_void_p()
+        rc = L.orc_traps_create(C.byref(self.h), model_dir.encode(), system.encode(), nbanks, int(add_c0), int(hamming))
+        if rc:
+            raise OSError("orc_traps_create(%s, %s) -> %d" % (model_dir, system, rc))
+        self.nbanks = nbanks
+        self.n_out = L.orc_traps_num_outputs(self.h)
+        self.n_band_nets = L.orc_traps_num_band_nets(self.h)
+
+    def __del__(self):
+        try:
+            self.L.orc_traps_destroy(self.h)
+        except Exception:
+            pass
+
+    def posteriors_batch(self, mel, off):
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        post = np.zeros((mel.shape[0], self.n_out), np.float32)
+        self.L.orc_traps_posteriors_batch(self.h, mel, off, len(off) - 1, post, None)
+        return post
+
+    def posteriors(self, mel):
+        return self.posteriors_batch(mel, np.array([0, len(mel)], np.int32))
+
+
 def ref_lib_path(blas=False):
     p = os.path.join(REF_DIR, "libphnrec_ref_blas.so" if blas else "libphnrec_ref.so")
     return p if os.path.exists(p) else None
@@ -249,6 +285,8 @@ def _ref(blas):
         L = C.CDLL(p)
         L.refshim_traps_create.restype = C.c_void_p
         L.refshim_traps_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.refshim_traps_create_system.restype = C.c_void_p
+        L.refshim_traps_create_system.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.refshim_traps_destroy.argtypes = [C.c_void_p]
         L.refshim_traps_reset.argtypes = [C.c_void_p]
         L.refshim_traps_num_outs.argtypes = [C.c_void_p]
@@ -268,11 +306,15 @@ def _ref(blas):
 class RefTraps:
     """The reference's own Traps object (traps.h:59-75) via ref_shim.cpp."""
 
-    def __init__(self, model_dir, nbanks, bunch=5, blas=False):
+    def __init__(self, model_dir, nbanks, bunch=5, blas=False, system="LCRC", add_c0=True, hamming=False):
         self.L = _ref(blas)
         self.nbanks = nbanks
         self.bunch = bunch
-        self.h = self.L.refshim_traps_create(model_dir.encode(), nbanks, bunch)
+        d = model_dir if model_dir.endswith("/") else model_dir + "/"     # Traps::Init concatenates dir + "weights/..."
+        self.h = self.L.refshim_traps_create_system(d.encode(), system.encode(), nbanks, bunch,
+                                                    int(add_c0), int(hamming))
+        if not self.h:
+            raise ValueError("unknown posteriors/system " + system)
         self.n_out = self.L.refshim_traps_num_outs(self.h)
 
     def __del__(self):

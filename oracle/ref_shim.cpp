@@ -34,20 +34,28 @@ extern "C" {
 
 // SpeechRec::Init's setter sequence for system=LCRC (srec.cpp:605-624), then
 // Traps::Init(dir).  Init exit(1)s on a bad model directory (traps.cpp:141-145).
-void *refshim_traps_create(const char *dir, int nbanks, int bunch)
+void *refshim_traps_create_system(const char *dir, const char *system, int nbanks, int bunch, int add_c0,
+                                  int hamming)
 {
     TrapsProbe *t = new TrapsProbe;
-    char sys[] = "LCRC";
-    t->SetSystem(sys);
+    char *sys = strdup(system);
+    const bool known = t->SetSystem(sys);
+    free(sys);
+    if (!known) { delete t; return 0; }
     t->SetTrapLen(31);
-    t->SetHamming(false);
+    t->SetHamming(hamming != 0);
     t->SetNBanks(nbanks);
-    t->SetAddC0(true);
+    t->SetAddC0(add_c0 != 0);
     t->SetBunchSize(bunch);
     char *d = strdup(dir);
     t->Init(d);
     free(d);
     return t;
+}
+
+void *refshim_traps_create(const char *dir, int nbanks, int bunch)
+{
+    return refshim_traps_create_system(dir, "LCRC", nbanks, bunch, 1, 0);
 }
 
 void refshim_traps_destroy(void *h) { delete static_cast<TrapsProbe *>(h); }

@@ -85,22 +85,6 @@ __device__ __forceinline__ double fexp_d(float y)
 
 __device__ __forceinline__ float fexp_f(float y) { return (float)fexp_d(y); }
 
-// fexp_sigmoid (fexp.h:33-38): the macro yields a double, so 1.0f + .. and 1.0f / ..
-// are double operations; one rounding to float.  The quotient only has to be good
-// for a correct ROUNDING TO FLOAT, so the full IEEE f64 division sequence is replaced
-// by v_rcp_f64 + one Newton step (relative error ~2^-50, i.e. the float result differs
-// from the correctly rounded one with probability ~2^-26) + v_div_fixup_f64, which
-// restores 1/inf = 0 and 1/0 = inf for FEXP's out-of-range garbage.
-__device__ __forceinline__ float fexp_sigmoid(float x)
-{
-    const double s = 1.0 + fexp_d(-x);
-    double r = __builtin_amdgcn_rcp(s);
-    const double e = __builtin_fma(-s, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    r = __builtin_amdgcn_div_fixup(r, s, 1.0);
-    return (float)r;
-}
-
 // Loads the first N (1..4) components of a weight fragment.  The last float4 group of
 // layer 1 is only partly used when ksteps % 4 != 0; loading all four components would
 // leave the unused ones as dead registers with a load in flight, and the first reuse
@@ -125,22 +109,9 @@ __device__ __forceinline__ f4 load_frag(const f4 *p)
     return v;
 }
 
-// ---- one MLP on the workgroup's 32 frames ------------------------------------------
+// ---- one MLP on the workgroup's frames -----------------------------------------------
 // XF: LDS image of the normalised input, [f][kq][lane] float4 where element j of
 //     lane l holds X[frame 16f + (l&15)][k = 16kq + 4j + (l>>4)].
-//
-// Hidden-loop schedule per wave (one wave per SIMD, so nothing else hides latency):
-//
-//   prologue   W1(t0) -> layer 1 of tile t0 -> pre
-//   per tile t    issue W2(t)                                         | fence
-//       block A   sig(pre(t)) on the VALU  ||  layer 1 of tile t+1 on the MFMA pipe
-//                 issue W1(t+2), bias(t+2)                             | fence
-//       block B   layer 2 of tile t (72 MFMAs, operands all ready)
-//   last tile     sigmoid + layer 2 only
-//
-// i.e. the sigmoid of a tile never sits between two dependent MFMA phases: it runs in the
-// issue shadow of the NEXT tile's layer 1, and every weight fragment is requested one
-// whole phase before it is used.
 template <int KS, int NKQ, bool EXACT>
 __device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
 {
@@ -148,48 +119,10 @@ __device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
     return (EXACT && kq == NKQ - 1) ? load_frag<KS - 4 * (NKQ - 1)>(t + kq * 64 + lane) : t[kq * 64 + lane];
 }
 
-template <int KS, int NKQ, bool EXACT>
-__device__ __forceinline__ void load_w1(f4 (&a)[NKQ], f4 &bias, const f4 *w1, const float *b1,
-                                        int h, int nkq, int lane)
-{
-    const f4 *t = w1 + (size_t)h * nkq * 64;
-#pragma unroll
-    for (int kq = 0; kq < NKQ; kq++)
-        if (EXACT || kq < nkq) a[kq] = load_w1_frag<KS, NKQ, EXACT>(t, kq, lane);
-    bias = *reinterpret_cast<const f4 *>(b1 + 16 * h + 4 * (lane >> 4));
-}
-
-// layer 1 of one hidden tile, bias first (nn.cpp:883-884):
-// p[f][r] = S^T[16ht + 4g + r][16f + (lane&15)]
-template <int KS, bool EXACT, int FT>
-__device__ __forceinline__ void gemm1_group(f4 (&p)[FT], const f4 &akq, const f4 *__restrict__ XF,
-                                            int kq, int nkq, int ks, int lane)
-{
-    f4 x[FT];
-#pragma unroll
-    for (int f = 0; f < FT; f++) x[f] = XF[(f * nkq + kq) * 64 + lane];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
-#pragma unroll
-            for (int f = 0; f < FT; f++) p[f] = mfma16x16x4(akq[j], x[f][j], p[f]);
-        }
-    }
-}
-
-template <int KS, int NKQ, bool EXACT, int FT>
-__device__ __forceinline__ void gemm1(f4 (&p)[FT], const f4 (&a)[NKQ], const f4 *__restrict__ XF,
-                                      int nkq, int ks, int lane)
-{
-#pragma unroll
-    for (int kq = 0; kq < NKQ; kq++)
-        if (EXACT || kq < nkq) gemm1_group<KS, EXACT, FT>(p, a[kq], XF, kq, nkq, ks, lane);
-}
-
-// Sigmoid (nn.cpp:796-820) of the 8 pre-activations a lane holds, as a sequence of
-// STAGES: stage k applies step k to all eight values, so the eight dependency chains
-// advance together and consecutive VALU instructions are independent.  The hidden loop
-// issues one stage behind each 8-MFMA group of the next tile's layer 1.
+// Sigmoid (nn.cpp:796-820) of the 4*FT pre-activations a lane holds, as a sequence of
+// STAGES: stage k applies step k to all values, so the dependency chains advance together
+// and consecutive VALU instructions are independent.  The hidden loop runs it as one block
+// of VALU work in front of a tile's MFMA groups.
 //
 // Cost matters here: v_mfma_f32_16x16x4_f32 runs on the SIMD's f32 FMA lanes, so VALU
 // work does NOT hide behind it (measured, tools/ubench/valu_overlap.hip: every VALU
@@ -247,16 +180,6 @@ struct SigTile {
     }
 };
 
-template <int FT>
-__device__ __forceinline__ void sigmoid_tile(f4 (&s)[FT], const f4 (&p)[FT])
-{
-    SigTile<FT> sg;
-    sg.begin(p);
-#pragma unroll
-    for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
-    sg.finish(s);
-}
-
 // layer 2: k-slot g of step r is hidden unit 16ht + 4g + r on both operands
 template <int FT>
 __device__ __forceinline__ void gemm2_group(f4 (&acc)[FT], const f4 &wot, const f4 (&s)[FT])
@@ -265,14 +188,6 @@ __device__ __forceinline__ void gemm2_group(f4 (&acc)[FT], const f4 &wot, const 
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(wot[r], s[f][r], acc[f]);
-}
-
-template <int NOT, bool EXACT, int FT>
-__device__ __forceinline__ void gemm2(f4 (&acc)[NOT][FT], const f4 (&w)[NOT], const f4 (&s)[FT], int n_ot)
-{
-#pragma unroll
-    for (int ot = 0; ot < NOT; ot++)
-        if (EXACT || ot < n_ot) gemm2_group<FT>(acc[ot], w[ot], s);
 }
 
 // All-reduce over aligned groups of 8 lanes with DPP (no LDS traffic, unlike __shfl_xor which is a
@@ -349,7 +264,7 @@ constexpr int lcrc_ring_size(int f)
     return best;
 }
 
-template <int KS, int NOT, int FT>
+template <int KS, int NOT, int FT, bool EXACT>
 struct RingLoop {
     static constexpr int NKQ = (KS + 3) / 4;
     static constexpr int F = NOT + NKQ;
@@ -361,16 +276,21 @@ struct RingLoop {
     const float *b1;
     const f4 *XF;
     int hlast, lane;
+    int ks, nkq, n_ot;          // run-time sizes (generic shapes); KS / NKQ / NOT when EXACT
     f4 ring[R];
 
-    // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling
+    // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling.
+    // Generic shapes: entries beyond the run-time sizes re-request the last valid fragment (a load
+    // under a branch would make the compiler drain all requests at the join); they are never consumed.
     __device__ __forceinline__ void request(int slot, int e, int t)
     {
         if (e < NOT) {
-            ring[slot] = w2[((size_t)max(0, min(t, hlast)) * NOT + e) * 64 + lane];
+            const int ot = EXACT ? e : min(e, n_ot - 1);
+            ring[slot] = w2[((size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) + ot) * 64 + lane];
         } else if (e - NOT < NKQ) {
-            const f4 *tb = w1 + (size_t)min(t + 1, hlast) * NKQ * 64;
-            ring[slot] = load_w1_frag<KS, NKQ, true>(tb, e - NOT, lane);
+            const f4 *tb = w1 + (size_t)min(t + 1, hlast) * (EXACT ? NKQ : nkq) * 64;
+            if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(tb, e - NOT, lane);
+            else ring[slot] = tb[min(e - NOT, nkq - 1) * 64 + lane];
         }
     }
 
@@ -399,23 +319,25 @@ struct RingLoop {
         if (MODE != LAST && !kSkipLd)              // bias of the tile after next: requested first, so
             bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
         f4 xb[2][FT];
+        const int nkq_x = EXACT ? NKQ : nkq;      // row stride of the B image
         if (MODE != LAST) {
 #pragma unroll
-            for (int f = 0; f < FT; f++) xb[0][f] = XF[f * NKQ * 64 + lane];
+            for (int f = 0; f < FT; f++) xb[0][f] = XF[f * nkq_x * 64 + lane];
         }
 #pragma unroll
         for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
             if (i < NOT) {
-                gemm2_group<FT>(acc[i], ring[i % R], s);
+                if (EXACT || i < n_ot) gemm2_group<FT>(acc[i], ring[i % R], s);
             } else if (i - NOT < NKQ) {
                 const int kq = i - NOT;
                 if (kq + 1 < NKQ) {                // B fragments of the next group, ahead of the MFMAs
+                    const int kn = EXACT ? kq + 1 : min(kq + 1, nkq - 1);
 #pragma unroll
-                    for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * NKQ + kq + 1) * 64 + lane];
+                    for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * nkq_x + kn) * 64 + lane];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (4 * kq + j < KS) {
+                    if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
 #pragma unroll
                         for (int f = 0; f < FT; f++) nxt[f] = mfma16x16x4(ring[i % R][j], xb[kq & 1][f][j], nxt[f]);
                     }
@@ -449,63 +371,6 @@ struct RingLoop {
     }
 };
 
-// ---- hidden loop, phased form (generic shapes, 4 waves per workgroup, one wave per SIMD) ----
-//   prologue   W1(t0) -> layer 1 of tile t0 -> pre, W1(t0+1)
-//   per tile t    issue W2(t) | sigmoid(pre) , layer 1 of tile t+1 | issue W1(t+2) | layer 2 of tile t
-//   last tile     sigmoid + layer 2 only
-// All prefetches are UNCONDITIONAL (indices clamped instead): a load under a branch makes the
-// compiler fall back to s_waitcnt vmcnt(0) at the join.
-template <int KS, int NOT, int FT>
-__device__ __forceinline__ void hidden_loop_phased(f4 (&acc)[NOT][FT], const f4 *w1, const f4 *w2, const float *b1,
-                                                   const f4 *__restrict__ XF, const NetDev &nd, int ht0, int ht1,
-                                                   int hlast, int lane)
-{
-    constexpr int NKQ = (KS + 3) / 4;
-    constexpr bool EXACT = false;
-    const int ks = nd.ksteps, nkq = nd.nkq, n_ot = nd.n_ot;
-    constexpr int wsel = (LCRC_DBG & 1) ? 0 : 1;
-    f4 a[NKQ];
-    f4 bias;
-    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0, hlast), nkq, lane);
-    LCRC_FENCE();
-    f4 pre[FT];
-#pragma unroll
-    for (int f = 0; f < FT; f++) pre[f] = bias;
-    gemm1<KS, NKQ, EXACT, FT>(pre, a, XF, nkq, ks, lane);  // (a wave without tiles computes a dummy)
-    LCRC_FENCE();
-    load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht0 + 1, hlast), nkq, lane);
-    LCRC_FENCE();
-    for (int ht = ht0; ht < ht1 - 1; ht++) {
-        f4 w[NOT];
-        f4 nxt[FT], s[FT];
-#pragma unroll
-        for (int f = 0; f < FT; f++) nxt[f] = bias;
-        const f4 *t2 = w2 + (size_t)wsel * ht * n_ot * 64;
-#pragma unroll
-        for (int ot = 0; ot < NOT; ot++)
-            if (ot < n_ot) w[ot] = t2[ot * 64 + lane];
-        LCRC_FENCE();
-        sigmoid_tile<FT>(s, pre);
-        gemm1<KS, NKQ, EXACT, FT>(nxt, a, XF, nkq, ks, lane);
-        LCRC_FENCE();
-        load_w1<KS, NKQ, EXACT>(a, bias, w1, b1, min(ht + 2, hlast), nkq, lane);
-        LCRC_FENCE();
-        gemm2<NOT, EXACT, FT>(acc, w, s, n_ot);
-#pragma unroll
-        for (int f = 0; f < FT; f++) pre[f] = nxt[f];
-    }
-    if (ht0 < ht1) {                       // last tile of this wave
-        f4 w[NOT];
-        const f4 *t = w2 + (size_t)wsel * (ht1 - 1) * n_ot * 64;
-#pragma unroll
-        for (int ot = 0; ot < NOT; ot++)
-            if (ot < n_ot) w[ot] = t[ot * 64 + lane];
-        f4 s[FT];
-        sigmoid_tile<FT>(s, pre);
-        gemm2<NOT, EXACT, FT>(acc, w, s, n_ot);
-    }
-}
-
 // Runs one net.  On return `epi(frame, o, posterior, valid)` has been called with valid == true once
 // for every (frame, output) of the tile by SOME thread (calls with valid == false carry a clamped
 // output index and must not store), and a __syncthreads() has been passed.
@@ -537,12 +402,11 @@ __device__ __forceinline__ void run_net(const LcrcParams &prm, int stamp0, const
     const float *const b1 = nd.b1;
     const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
 
-    if constexpr (EXACT) {
-        RingLoop<KS, NOT, FT> loop;
+    {
+        RingLoop<KS, NOT, FT, EXACT> loop;
         loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
+        loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
         loop.run(acc, ht0, ht1);
-    } else {
-        hidden_loop_phased<KS, NOT, FT>(acc, w1, w2, b1, XF, nd, ht0, ht1, hlast, lane);
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done

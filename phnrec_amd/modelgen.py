@@ -34,6 +34,7 @@ SYSTEMS = {
 
 N_COEF = 11      # C0 + 10 DCT coefficients per band and half-context
 HALF = 16
+TRAP_LEN = 31
 
 
 def pad4(n):
@@ -56,6 +57,12 @@ def random_net(rng, n_inp, n_hid, n_out, kind):
     if kind == "band":
         mean = rng.standard_normal(n_inp).astype(np.float32) * np.float32(0.5)
         dev = rng.uniform(0.3, 1.5, n_inp).astype(np.float32)
+    elif kind == "dct31":   # C0 / DCT of a 31-point trajectory: a few times larger than the taps
+        mean = rng.standard_normal(n_inp).astype(np.float32)
+        dev = rng.uniform(0.05, 0.25, n_inp).astype(np.float32)
+    elif kind == "neglog":  # 1BT / 3BT merger input = -ln(band posteriors)
+        mean = rng.uniform(3.0, 9.0, n_inp).astype(np.float32)
+        dev = rng.uniform(0.2, 0.5, n_inp).astype(np.float32)
     else:  # merger input = log posteriors
         mean = rng.uniform(-9.0, -3.0, n_inp).astype(np.float32)
         dev = rng.uniform(0.2, 0.5, n_inp).astype(np.float32)
@@ -103,17 +110,18 @@ def write_ascii(weights_path, norms_path, net):
 
 def config_text(nbanks, sample_freq=8000, vector_size=200, vector_step=80, lower=64, higher=4000,
                 sent_mean_norm=True, wpenalty=-4.6875, fmt="lin16", suffix="mel", bunch_size=5,
-                **_unused):
+                system="LCRC", add_c0=True, hamming=False, **_unused):
     b = "true" if sent_mean_norm else "false"
+    c0, hm = ("true" if add_c0 else "false"), ("true" if hamming else "false")
     return f"""[source]
 format={fmt}
 sample_freq={sample_freq}
 
 [posteriors]
-system=LCRC
+system={system}
 length=31
-add_c0=true
-hamming=false
+add_c0={c0}
+hamming={hm}
 suffix=lop
 bunch_size={bunch_size}
 softening_func=none 0 0 0
@@ -201,6 +209,32 @@ def write_model_dir(path, nbanks, hidden, n_out, seed=0, ascii_too=False, nbin=T
         f.write("".join("p%02d\n" % i for i in range(n_phn)))
     with open(os.path.join(path, "config"), "w") as f:
         f.write(config_text(nbanks, **cfg))
+    return nets
+
+
+def write_traps_dir(path, system, nbanks, hidden, n_out, seed=0, band_out=12, band_hidden=40, coefs=6,
+                    add_c0=True, hamming=False, **cfg):
+    """Write a loadable model directory for the non-LCRC `posteriors/system` variants (traps.cpp:88-171):
+    "1BT_DCT": merger over nbanks * coefs DCT features (coefs counts C0 when add_c0);
+    "1BT" / "3BT": nbanks (nbanks - 2) band nets 31 -> band_hidden -> band_out and a merger over their outputs."""
+    rng = np.random.default_rng(seed)
+    nets = {}
+    if system == "1BT_DCT":
+        nets["merger"] = random_net(rng, nbanks * coefs, hidden, n_out, "dct31")
+    else:
+        tb = nbanks - 2 if system == "3BT" else nbanks
+        for i in range(tb):
+            nets["band%d" % i] = random_net(rng, TRAP_LEN, band_hidden + i, band_out, "band")
+        nets["merger"] = random_net(rng, tb * band_out, hidden, n_out, "neglog")
+    for sub in ("weights", "norms", "windows", "dicts", "tmp", "net"):
+        os.makedirs(os.path.join(path, sub), exist_ok=True)
+    for name, net in nets.items():
+        write_nbin(os.path.join(path, "weights", name + ".nbin"), net)
+    n_phn = n_out // 3 - 1
+    with open(os.path.join(path, "dicts", "phonemes"), "w") as f:
+        f.write("".join("p%02d\n" % i for i in range(n_phn)))
+    with open(os.path.join(path, "config"), "w") as f:
+        f.write(config_text(nbanks, system=system, add_c0=add_c0, hamming=hamming, **cfg))
     return nets
 
 
