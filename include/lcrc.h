@@ -58,6 +58,18 @@ typedef struct lcrc_ctx lcrc_ctx;
 int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
                 int add_c0, int device_id);
 
+/* The other values of posteriors/system ("next" row f4): "1BT_DCT" (the schema default, srec.cpp:69: C0 / DCT
+ * of every band's 31-point trajectory into one net), "1BT" (one 31-input net per band, -ln of their outputs
+ * into the merger) and "3BT" (as the reference codes it: 1BT over the first nbanks - 2 bands), with
+ * posteriors/hamming and posteriors/add_c0 (traps.cpp:88-171,220-283,347-358,409-433); "LCRC" forwards to
+ * lcrc_create (which ignores hamming, as the reference does).  All entry points below work on such a
+ * context except lcrc_posteriors_probe and lcrc_model_info.  These systems run as separate feature /
+ * MLP launches, not as one fused kernel.  lcrc_net_dims: band classifiers first, the merger last. */
+int lcrc_create_system(lcrc_ctx **ctx, const char *model_dir, const char *system, int nbanks, int trap_len,
+                       int add_c0, int hamming, int device_id);
+/* Host-only: Traps::GetNumOuts (the merger's output count, traps.h:66) for any system, or a negative
+ * LCRC_E_* code (text in lcrc_last_error(NULL)). */
+int lcrc_model_outputs(const char *model_dir, const char *system);
 void lcrc_destroy(lcrc_ctx *ctx);
 
 /* Message of the last failing call on `ctx`; with ctx == NULL, of the last

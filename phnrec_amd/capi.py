@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 
 # every symbol include/lcrc.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "lcrc_create", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
+    "lcrc_create", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_stage_buffers", "lcrc_stage_run",
@@ -98,6 +98,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lcrc_model_outputs.argtypes = [C.c_char_p, C.c_char_p]
+    L.lcrc_create_system.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcrc_destroy.argtypes = [vp]
     L.lcrc_destroy.restype = None
     L.lcrc_last_error.argtypes = [vp]
@@ -148,11 +150,15 @@ def model_info(model_dir, nbanks):
 class Lcrc:
     """One estimator context on one GPU (mirrors class Traps' public surface)."""
 
-    def __init__(self, model_dir, nbanks, device=0, trap_len=31, add_c0=True):
+    def __init__(self, model_dir, nbanks, device=0, trap_len=31, add_c0=True, system="LCRC", hamming=False):
         self.L = load()
         self.h = C.c_void_p()
-        rc = self.L.lcrc_create(C.byref(self.h), os.fsencode(model_dir), nbanks, trap_len,
-                                int(add_c0), device)
+        if system == "LCRC" and not hamming:
+            rc = self.L.lcrc_create(C.byref(self.h), os.fsencode(model_dir), nbanks, trap_len,
+                                    int(add_c0), device)
+        else:
+            rc = self.L.lcrc_create_system(C.byref(self.h), os.fsencode(model_dir), system.encode(), nbanks,
+                                           trap_len, int(add_c0), int(hamming), device)
         if rc != 0:
             self.h = None
             raise LcrcError(rc, self.L.lcrc_last_error(None).decode())

@@ -227,17 +227,24 @@ bool SpeechRec::Init(const std::string &config_file)
     }
     traps_enabled_ = C.GetBool("posteriors", "enabled");
     if (traps_enabled_) {
-        if (sys != "LCRC" || C.GetBool("posteriors", "hamming") || C.GetInt("posteriors", "length") != 31 ||
-            !C.GetBool("posteriors", "add_c0"))
-            return Fail("only posteriors/system=LCRC, length=31, add_c0=true, hamming=false runs on the GPU path\n");
+        if (C.GetInt("posteriors", "length") != 31 || (sys == "LCRC" && !C.GetBool("posteriors", "add_c0")))
+            return Fail("the GPU path implements posteriors/length=31 (and add_c0=true for system=LCRC)\n");
         // host-only validation of the model directory (the GPU is claimed lazily, when a
         // par -> post conversion is actually requested)
         int dims[9];
-        if (lcrc_model_info(config_dir_.c_str(), nbanks_, dims, nullptr, 0, nullptr) != LCRC_OK) {
-            snprintf(msg, sizeof msg, "%s\n", lcrc_last_error(nullptr));
-            return Fail(msg);
+        if (sys == "LCRC") {
+            if (lcrc_model_info(config_dir_.c_str(), nbanks_, dims, nullptr, 0, nullptr) != LCRC_OK) {
+                snprintf(msg, sizeof msg, "%s\n", lcrc_last_error(nullptr));
+                return Fail(msg);
+            }
+            n_out_ = dims[8];
+        } else {
+            n_out_ = lcrc_model_outputs(config_dir_.c_str(), sys.c_str());
+            if (n_out_ < 0) {
+                snprintf(msg, sizeof msg, "%s\n", lcrc_last_error(nullptr));
+                return Fail(msg);
+            }
         }
-        n_out_ = dims[8];
     }
 
     Log("  - decoder ...\n\n");

@@ -30,13 +30,9 @@ public:
     void SetBunchSize(int v) { bunch_ = v; }        // grouping only; never changes values
     bool Init(const char *dir)
     {
-        if (system_ != "LCRC" || hamming_) {
-            err_ = "posteriors/system=" + system_ + (hamming_ ? " with hamming=true" : "") +
-                   " is not implemented on the GPU path (only LCRC, hamming=false)";
-            return false;
-        }
         if (ctx_) { lcrc_destroy(ctx_); ctx_ = nullptr; }
-        const int rc = lcrc_create(&ctx_, dir, nbanks_, trap_len_, add_c0_ ? 1 : 0, device_);
+        const int rc = lcrc_create_system(&ctx_, dir, system_.c_str(), nbanks_, trap_len_, add_c0_ ? 1 : 0,
+                                          hamming_ ? 1 : 0, device_);
         if (rc != LCRC_OK) { err_ = lcrc_last_error(nullptr); ctx_ = nullptr; return false; }
         return true;
     }

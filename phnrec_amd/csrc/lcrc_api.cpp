@@ -23,6 +23,8 @@
 
 using namespace phnrec;
 
+enum { SYS_LCRC = 0, SYS_1BT_DCT = 1, SYS_1BT = 2, SYS_3BT = 3 };
+
 struct lcrc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,6 +34,14 @@ struct lcrc_ctx {
     std::vector<void *> allocs;
     float *d_win = nullptr, *d_costab = nullptr;
     float normc = 0.f;
+    // the other posteriors/system variants ("next" row f4): nets[2] is the merger in every system
+    int system = SYS_LCRC, trap_bands = 0, shift = 0;
+    bool use_hamming = false, add_c0 = true;
+    std::vector<NetDev> band_nets;       // 1BT / 3BT: trap_bands nets of 31 inputs
+    float *d_hamm31 = nullptr, *d_costab31 = nullptr;
+    float normc31 = 0.f;
+    float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
+    size_t cap_feat_rows = 0;
     // staging for the host-pointer entry points (grown on demand)
     float *d_mel = nullptr, *d_post = nullptr;
     int *d_off = nullptr;
@@ -171,27 +181,89 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
     return LCRC_OK;
 }
 
+void fill_output_transform(const lcrc_ctx *c, int *func, float (*oc)[4], float (*ol)[2], int *be)
+{
+    for (int i = 0; i < 2; i++) {
+        const lcrc_softening &sf = c->soft[i];
+        func[i] = sf.func;
+        if (sf.func == LCRC_SOFT_IGOR) {         // SoftIgor's sub-expressions, srec.cpp:166-171
+            oc[i][0] = sf.arg1;
+            oc[i][1] = 1.0f / sf.arg1;
+            oc[i][2] = 1.0f / (1.0f - sf.arg1);
+            ol[i][0] = logf(sf.arg3);
+            ol[i][1] = logf(sf.arg2);
+        }
+    }
+    *be = c->out_be;
+}
+
+// 1BT_DCT / 1BT / 3BT: features -> [band nets ->] merger, as separate launches on the same stream
+int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
+                 hipStream_t s)
+{
+    if (n_rows <= 0) return LCRC_OK;
+    const size_t Km = c->nets[2].n_inp;
+    if ((size_t)n_rows > c->cap_feat_rows) {
+        const size_t cap = (size_t)n_rows + n_rows / 4 + 64;
+        if (c->d_feat) (void)hipFree(c->d_feat);
+        if (c->d_minp) (void)hipFree(c->d_minp);
+        c->d_feat = c->d_minp = nullptr;
+        c->cap_feat_rows = 0;
+        const size_t feat = c->system == SYS_1BT_DCT ? cap * Km : cap * (size_t)c->trap_bands * kTrapLen;
+        HIP_TRY(c, hipMalloc((void **)&c->d_feat, feat * sizeof(float)));
+        if (c->system != SYS_1BT_DCT) HIP_TRY(c, hipMalloc((void **)&c->d_minp, cap * Km * sizeof(float)));
+        c->cap_feat_rows = cap;
+    }
+    TrapsFeatParams f;
+    memset(&f, 0, sizeof f);
+    f.mel = d_mel; f.off = d_off; f.n_utts = n_utts; f.n_rows = n_rows;
+    f.nbanks = c->nbanks; f.trap_bands = c->trap_bands;
+    f.mode = c->system == SYS_1BT_DCT ? 1 : 0;
+    f.use_hamming = c->use_hamming ? 1 : 0; f.add_c0 = c->add_c0 ? 1 : 0; f.shift = c->shift;
+    f.hamming = c->d_hamm31; f.costab = c->d_costab31; f.normc = c->normc31;
+    f.out = c->d_feat;
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
+    HIP_TRY(c, traps_features_launch(f, s));
+    MlpParams m;
+    memset(&m, 0, sizeof m);
+    m.n_rows = n_rows;
+    const float *merger_in = c->d_feat;
+    if (c->system != SYS_1BT_DCT) {
+        size_t col = 0;
+        for (int b = 0; b < c->trap_bands; b++) {
+            m.net = c->band_nets[b];
+            m.in = c->d_feat + (size_t)b * n_rows * kTrapLen; m.in_ld = kTrapLen;
+            m.out = c->d_minp + col; m.out_ld = (long)Km;
+            m.neg_log = 1;
+            HIP_TRY(c, mlp_launch(m, s));
+            col += c->band_nets[b].n_out;
+        }
+        merger_in = c->d_minp;
+    }
+    m.net = c->nets[2];
+    m.in = merger_in; m.in_ld = (long)Km;
+    m.out = d_post; m.out_ld = c->nets[2].n_out;
+    m.neg_log = 0;
+    fill_output_transform(c, m.out_func, m.out_c, m.out_l, &m.out_be);
+    HIP_TRY(c, mlp_launch(m, s));
+    if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
+    return LCRC_OK;
+}
+
 int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
            hipStream_t s, float *const *dbg)
 {
+    if (c->system != SYS_LCRC) {
+        if (dbg) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
+        return launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
+    }
     LcrcParams p;
     memset(&p, 0, sizeof p);
     for (int i = 0; i < 3; i++) p.net[i] = c->nets[i];
     p.mel = d_mel; p.off = d_off; p.post = d_post;
     p.win = c->d_win; p.costab = c->d_costab; p.normc = c->normc;
     p.n_utts = n_utts; p.n_rows = n_rows; p.nbanks = c->nbanks;
-    for (int i = 0; i < 2; i++) {
-        const lcrc_softening &sf = c->soft[i];
-        p.out_func[i] = sf.func;
-        if (sf.func == LCRC_SOFT_IGOR) {         // SoftIgor's sub-expressions, srec.cpp:166-171
-            p.out_c[i][0] = sf.arg1;
-            p.out_c[i][1] = 1.0f / sf.arg1;
-            p.out_c[i][2] = 1.0f / (1.0f - sf.arg1);
-            p.out_l[i][0] = logf(sf.arg3);
-            p.out_l[i][1] = logf(sf.arg2);
-        }
-    }
-    p.out_be = c->out_be;
+    fill_output_transform(c, p.out_func, p.out_c, p.out_l, &p.out_be);
     p.tile_frames = c->tile_frames;
     p.stamps = c->d_stamps;
     p.dbg_flags = c->dbg_flags;
@@ -308,13 +380,51 @@ int lcrc_model_info(const char *model_dir, int nbanks, int *dims9, char *kernel,
 
 const char *lcrc_last_error(const lcrc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+int lcrc_model_outputs(const char *model_dir, const char *system)
+{
+    if (!model_dir || !system) return fail(nullptr, LCRC_E_ARG, "lcrc_model_outputs: NULL argument");
+    if (strcmp(system, "LCRC") && strcmp(system, "1BT_DCT") && strcmp(system, "1BT") && strcmp(system, "3BT"))
+        return fail(nullptr, LCRC_E_ARG, std::string("Unknown posterior estimator system: ") + system);
+    const std::string dir(model_dir);
+    const std::string w = dir + "/weights/merger.weights", n = dir + "/norms/merger.norms";
+    HostNet merger;
+    NetStatus s = load_net(w, n, merger);
+    if (s != NET_OK)
+        return fail(nullptr, s == NET_NOWEIGHTS || s == NET_NONORMS ? LCRC_E_IO : LCRC_E_MODEL,
+                    "ERROR: Loading neural network: weights " + w + ", norms " + n + " (" + net_status_str(s) + ")");
+    return merger.n_out;
+}
+
+// Device, stream and events of a fresh context (shared by every system)
+static int open_context(lcrc_ctx **out, int nbanks, int device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    lcrc_ctx *c = new lcrc_ctx;
+    c->device = device_id;
+    c->nbanks = nbanks;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        g_create_err = "cannot create HIP stream/events";
+        lcrc_destroy(c);
+        return LCRC_E_DEVICE;
+    }
+    c->hist.assign((size_t)(kTrapLen - 1) * nbanks, 0.f);
+    *out = c;
+    return LCRC_OK;
+}
+
 int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len, int add_c0, int device_id)
 {
     if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");
     *out = nullptr;
     if (nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_create: nbanks must be positive");
     if (trap_len != kTrapLen || !add_c0)
-        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: only posteriors/system=LCRC with length=31, add_c0=true is implemented");
+        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: posteriors/system=LCRC is implemented for length=31, add_c0=true");
 
     // -- files first, so that a bad model directory is reported even without a GPU
     HostNet nets[3];
@@ -323,23 +433,12 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
         int rc = load_model(model_dir, nbanks, nets, win);
         if (rc) return rc;
     }
-
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
-    if (device_id < 0 || device_id >= ndev)
-        return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
-    HIP_TRY(nullptr, hipSetDevice(device_id));
-
-    lcrc_ctx *c = new lcrc_ctx;
-    c->device = device_id;
-    c->nbanks = nbanks;
-    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        c->err = "cannot create HIP stream/events";
-        return bail(LCRC_E_DEVICE);
+    lcrc_ctx *c = nullptr;
+    {
+        int rc = open_context(&c, nbanks, device_id);
+        if (rc) return rc;
     }
+    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
     for (int i = 0; i < 3; i++) {
         c->host[i] = nets[i];
         int rc = pack_net(c, nets[i], c->nets[i]);
@@ -366,7 +465,101 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
         return bail(LCRC_E_UNSUPPORTED);
     }
     c->variant = v;
-    c->hist.assign((size_t)(kTrapLen - 1) * nbanks, 0.f);
+    c->trap_bands = 2;
+    *out = c;
+    return LCRC_OK;
+}
+
+int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system, int nbanks, int trap_len,
+                       int add_c0, int hamming, int device_id)
+{
+    if (!out || !model_dir || !system) return fail(nullptr, LCRC_E_ARG, "lcrc_create_system: NULL argument");
+    // LCRC ignores posteriors/hamming: its half-context windows come from files (traps.cpp:224-243 is skipped)
+    if (!strcmp(system, "LCRC")) return lcrc_create(out, model_dir, nbanks, trap_len, add_c0, device_id);
+    *out = nullptr;
+    int sys;
+    if (!strcmp(system, "1BT_DCT")) sys = SYS_1BT_DCT;
+    else if (!strcmp(system, "1BT")) sys = SYS_1BT;
+    else if (!strcmp(system, "3BT")) sys = SYS_3BT;
+    else return fail(nullptr, LCRC_E_ARG, std::string("Unknown posterior estimator system: ") + system);   // srec.cpp:605-611
+    if (nbanks <= (sys == SYS_3BT ? 2 : 0)) return fail(nullptr, LCRC_E_ARG, "lcrc_create_system: nbanks too small");
+    if (trap_len != kTrapLen) return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create_system: implemented for length=31");
+    const int trap_bands = sys == SYS_3BT ? nbanks - 2 : nbanks;        // traps.cpp:95-97
+
+    // -- files first (traps.cpp:119-166)
+    const std::string dir(model_dir);
+    std::vector<HostNet> band(sys == SYS_1BT_DCT ? 0 : trap_bands);
+    HostNet merger;
+    auto load = [&](const std::string &name, HostNet &net) -> int {
+        const std::string w = dir + "/weights/" + name + ".weights", n = dir + "/norms/" + name + ".norms";
+        NetStatus s = load_net(w, n, net);
+        if (s != NET_OK)
+            return fail(nullptr, s == NET_NOWEIGHTS || s == NET_NONORMS ? LCRC_E_IO : LCRC_E_MODEL,
+                        "ERROR: Loading neural network: weights " + w + ", norms " + n + " (" + net_status_str(s) + ")");
+        return LCRC_OK;
+    };
+    size_t merger_in = 0;
+    for (int i = 0; i < (int)band.size(); i++) {
+        int rc = load("band" + std::to_string(i), band[i]);
+        if (rc) return rc;
+        // the reference hands every band net exactly trap_len values per frame (traps.cpp:253-259)
+        if (band[i].n_inp != kTrapLen)
+            return fail(nullptr, LCRC_E_MODEL, "band classifier " + std::to_string(i) + " takes " +
+                        std::to_string(band[i].n_inp) + " inputs, the trajectory has 31");
+        merger_in += band[i].n_out;
+    }
+    {
+        int rc = load("merger", merger);
+        if (rc) return rc;
+    }
+    const int shift = merger.n_inp / trap_bands;                         // merger_input_shift, traps.cpp:170
+    if (sys == SYS_1BT_DCT) {
+        if (shift * trap_bands != merger.n_inp || shift < 1 || shift - (add_c0 ? 1 : 0) > kTrapLen)
+            return fail(nullptr, LCRC_E_MODEL, "merger input size " + std::to_string(merger.n_inp) +
+                        " is not nbanks x (coefficients per band)");
+    } else if ((int)merger_in != merger.n_inp) {
+        return fail(nullptr, LCRC_E_MODEL, "merger input size does not equal the band classifiers' outputs");
+    }
+
+    lcrc_ctx *c = nullptr;
+    {
+        int rc = open_context(&c, nbanks, device_id);
+        if (rc) return rc;
+    }
+    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
+    c->system = sys;
+    c->trap_bands = trap_bands;
+    c->shift = shift;
+    c->use_hamming = hamming != 0;
+    c->add_c0 = add_c0 != 0;
+    c->band_nets.resize(band.size());
+    for (size_t i = 0; i < band.size(); i++) {
+        int rc = pack_net(c, band[i], c->band_nets[i]);
+        if (rc) return bail(rc);
+        if (!mlp_supports(c->band_nets[i])) { c->err = "band classifier too large (<= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
+    }
+    c->host[2] = merger;
+    {
+        int rc = pack_net(c, merger, c->nets[2]);
+        if (rc) return bail(rc);
+    }
+    if (!mlp_supports(c->nets[2])) { c->err = "merger too large (<= 1024 inputs, <= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
+    // Hamming window over ones (traps.cpp:107-109, dspc.h:162-167) and sDCT's basis for n = 31 (dspc.h:206-221)
+    std::vector<float> hamm(kTrapLen), cosv((size_t)kTrapLen * kTrapLen, 0.f);
+    for (int i = 0; i < kTrapLen; i++)
+        hamm[i] = 1.0f * (0.54f - 0.46f * cosf(2.0f * (float)M_PI * i / (kTrapLen - 1)));
+    const float pibyn = (float)M_PI / (float)kTrapLen;
+    for (int k = 0; k < kTrapLen; k++) {
+        const float v = pibyn * (float)(k + 1);
+        for (int j = 0; j < kTrapLen; j++) cosv[(size_t)k * kTrapLen + j] = cosf(v * ((float)j + 0.5f));
+    }
+    c->normc31 = sqrtf(2.0f / (float)kTrapLen);
+    const float *p = nullptr;
+    if (dev_upload(c, hamm, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_hamm31 = const_cast<float *>(p);
+    if (dev_upload(c, cosv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_costab31 = const_cast<float *>(p);
+    c->variant = sys == SYS_1BT_DCT ? "traps_1bt_dct" : sys == SYS_1BT ? "traps_1bt" : "traps_3bt";
     *out = c;
     return LCRC_OK;
 }
@@ -384,6 +577,8 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->h_post) (void)hipHostFree(c->h_post);
     if (c->h_off) (void)hipHostFree(c->h_off);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
+    if (c->d_feat) (void)hipFree(c->d_feat);
+    if (c->d_minp) (void)hipFree(c->d_minp);
     if (c->d_hamming) (void)hipFree(c->d_hamming);
     if (c->d_coeffs) (void)hipFree(c->d_coeffs);
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
@@ -409,10 +604,14 @@ const char *lcrc_kernel_name(const lcrc_ctx *c) { return c ? c->variant : "none"
 
 int lcrc_net_dims(const lcrc_ctx *c, int which, int *n_inp, int *n_hid, int *n_out)
 {
-    if (!c || which < 0 || which > 2) return LCRC_E_ARG;
-    if (n_inp) *n_inp = c->nets[which].n_inp;
-    if (n_hid) *n_hid = c->nets[which].n_hid;
-    if (n_out) *n_out = c->nets[which].n_out;
+    // band classifiers first (2 for LCRC, trap_bands for 1BT / 3BT, none for 1BT_DCT), then the merger
+    if (!c) return LCRC_E_ARG;
+    const int n_band = c->system == SYS_LCRC ? 2 : (int)c->band_nets.size();
+    if (which < 0 || which > n_band) return LCRC_E_ARG;
+    const NetDev &nd = which == n_band ? c->nets[2] : (c->system == SYS_LCRC ? c->nets[which] : c->band_nets[which]);
+    if (n_inp) *n_inp = nd.n_inp;
+    if (n_hid) *n_hid = nd.n_hid;
+    if (n_out) *n_out = nd.n_out;
     return LCRC_OK;
 }
 
@@ -430,6 +629,7 @@ int lcrc_posteriors_probe(lcrc_ctx *c, const float *mel, int n, float *post, flo
 {
     if (!c) return LCRC_E_ARG;
     if (n < 0 || (n > 0 && (!mel || !post))) return fail(c, LCRC_E_ARG, "lcrc_posteriors_probe: bad argument");
+    if (c->system != SYS_LCRC) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
     if (n == 0) return LCRC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     float *probes[5] = {in0, in1, p0, p1, g};

@@ -83,6 +83,41 @@ inline int lcrc_n_ot_slab(const NetDev *nets)
     return m;
 }
 
+// ---- the other `posteriors/system` variants (traps_kernels.hip; "next" row f4) ----------------------
+// 1BT_DCT: features kernel (C0 / DCT of every band's 31-point trajectory) -> one MLP.
+// 1BT / 3BT: features kernel (the trajectories themselves) -> one small MLP per band, whose epilogue
+// writes -ln(p) into the merger's input matrix -> merger MLP.  (traps.cpp:220-283,347-358,409-433)
+struct TrapsFeatParams {
+    const float *mel;    // [n_rows][nbanks]
+    const int *off;      // [n_utts + 1] or NULL (one utterance)
+    int n_utts, n_rows, nbanks, trap_bands;
+    int mode;            // 0 = trajectories [trap_bands][n_rows][31], 1 = C0/DCT rows [n_rows][trap_bands*shift]
+    int use_hamming, add_c0, shift;
+    const float *hamming;   // [31]  sWindow_Hamming over ones (dspc.h:162-167)
+    const float *costab;    // [shift][31]  cosf(v_k * (j + 0.5f)) as sDCT evaluates it (dspc.h:206-221)
+    float normc;            // sqrtf(2/31)
+    float *out;
+};
+
+struct MlpParams {
+    NetDev net;
+    const float *in;     // row r at in + r*in_ld (n_inp values)
+    float *out;          // row r at out + r*out_ld (n_out values)
+    long in_ld, out_ld;
+    int n_rows;
+    int neg_log;         // 1: store -(x > 0 ? ln x : 0)   (sLn + sMultiplication(-1), traps.cpp:424-425)
+    int out_func[2];     // else: softening stages / byte order of lcrc_output_configure
+    float out_c[2][4];
+    float out_l[2][2];
+    int out_be;
+    unsigned long long *stamps;   // unused (keeps run_net's diagnostic hooks compiling)
+};
+
+constexpr int kMlpKS = 256, kMlpNOT = 13;   // <= 1024 inputs, <= 208 outputs per net
+hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream);
+hipError_t mlp_launch(const MlpParams &p, hipStream_t stream);
+bool mlp_supports(const NetDev &net);
+
 // launcher (lcrc_kernels.hip)
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);
 // variant that WOULD be selected for these nets (no launch); NULL if unsupported

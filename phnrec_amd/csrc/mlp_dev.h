@@ -1,0 +1,469 @@
+// mlp_dev.h -- device code shared by the fused LCRC kernel (lcrc_kernels.hip) and the kernels of the
+// other `posteriors/system` variants (traps_kernels.hip): MFMA wrapper, FEXP, the sigmoid block, the
+// ring-form hidden loop, run_net (one MLP on a workgroup's frames incl. fold, softmax and epilogue),
+// softening functions.  See lcrc_kernels.hip for the geometry and the arithmetic contract.
+#ifndef PHNREC_MLP_DEV_H
+#define PHNREC_MLP_DEV_H
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+
+#include "lcrc_dev.h"
+
+namespace phnrec {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// In-kernel phase stamps exist only in the DIAGNOSTIC build (make stamps ->
+// libphnrec_lcrc_stamps.so, tools/stamp_profile.py); in the product the macro is empty.
+#ifdef LCRC_STAMPS
+#define LCRC_STAMP(p, wave, lane, idx)                                                        \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+        if ((p).stamps && (lane) == 0) (p).stamps[((size_t)blockIdx.x * 8 + (wave)) * 16 + (idx)] = t_; \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#else
+#define LCRC_STAMP(p, wave, lane, idx) do { } while (0)
+#endif
+
+__device__ __forceinline__ f4 mfma16x16x4(float a, float b, f4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- FEXP (fexp.h:14-21) ----------------------------------------------------------
+// hi32 = (int)(2^20/ln2 * y) + (1072693248 - 60801); lo32 = 0; reinterpret as double.
+// (int) is x86 cvttsd2si: INT_MIN when the product is >= 2^31 or NaN.  v_cvt_i32_f64
+// saturates instead, so that one case is patched; the test is made on y itself
+// (0x1.62e43p+10f = 1419.5654296875 is the smallest float whose product reaches 2^31;
+// !(y < T) is also true for NaN).  Below -2^31 both conversions give INT_MIN.
+__device__ __forceinline__ double fexp_d(float y)
+{
+    const double a = 1048576.0 / 0.69314718055994530942;
+    int i = __double2int_rz(a * (double)y);
+    if (!(y < 0x1.62e43p+10f)) i = INT_MIN;
+    unsigned hi = (unsigned)i + 1072632447u;
+    return __hiloint2double((int)hi, 0);
+}
+
+__device__ __forceinline__ float fexp_f(float y) { return (float)fexp_d(y); }
+
+// Loads the first N (1..4) components of a weight fragment.  The last float4 group of
+// layer 1 is only partly used when ksteps % 4 != 0; loading all four components would
+// leave the unused ones as dead registers with a load in flight, and the first reuse
+// of such a register costs an s_waitcnt vmcnt(0) that drains the whole prefetch.
+template <int N>
+__device__ __forceinline__ f4 load_frag(const f4 *p)
+{
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (N >= 4) {
+        v = *p;
+    } else if constexpr (N == 3) {
+        typedef float f3 __attribute__((ext_vector_type(3)));
+        const f3 t = *reinterpret_cast<const f3 *>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2];
+    } else if constexpr (N == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 t = *reinterpret_cast<const f2 *>(p);
+        v[0] = t[0]; v[1] = t[1];
+    } else {
+        v[0] = *reinterpret_cast<const float *>(p);
+    }
+    return v;
+}
+
+// ---- one MLP on the workgroup's frames -----------------------------------------------
+// XF: LDS image of the normalised input, [f][kq][lane] float4 where element j of
+//     lane l holds X[frame 16f + (l&15)][k = 16kq + 4j + (l>>4)].
+template <int KS, int NKQ, bool EXACT>
+__device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
+{
+    // `t` (tile base) stays in SGPRs (saddr addressing); only lane*16 is a vector offset
+    return (EXACT && kq == NKQ - 1) ? load_frag<KS - 4 * (NKQ - 1)>(t + kq * 64 + lane) : t[kq * 64 + lane];
+}
+
+// Sigmoid (nn.cpp:796-820) of the 4*FT pre-activations a lane holds, as a sequence of
+// STAGES: stage k applies step k to all values, so the dependency chains advance together
+// and consecutive VALU instructions are independent.  The hidden loop runs it as one block
+// of VALU work in front of a tile's MFMA groups.
+//
+// Cost matters here: v_mfma_f32_16x16x4_f32 runs on the SIMD's f32 FMA lanes, so VALU
+// work does NOT hide behind it (measured, tools/ubench/valu_overlap.hip: every VALU
+// instruction adds its full issue time to the 32 cycles of an MFMA).  Hence:
+//   * FEXP's integer part stays exact (f64 product, truncation, x86 overflow value);
+//   * FEXP's value is exactly representable in f32 (20 mantissa bits), so one
+//     v_cvt_f32_f64 of {0, hi} yields it without error in the whole normal range;
+//   * 1/(1+e) is evaluated in f32: v_rcp_f32 + one Newton step + v_div_fixup_f32
+//     (1/inf = 0 etc.).  The reference evaluates it in f64 and rounds once; this form is
+//     within 2 ulp (2.4e-7 relative) of it, an order of magnitude below the effect of the
+//     products' summation order, and costs ~40 instead of ~90 issue cycles per value.
+// Pad hidden units (>= n_hid) need no zeroing: their layer-2 weights are packed as zeros.
+template <int FT>
+struct SigTile {
+    static constexpr int kN = 4 * FT;
+    float x[kN];     // -x, then e, 1+e, and finally the sigmoid
+    double t[kN];
+    float r[kN];
+    static constexpr int kStages = 6;
+
+    __device__ __forceinline__ void begin(const f4 (&p)[FT])
+    {
+#pragma unroll
+        for (int f = 0; f < FT; f++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[4 * f + i] = -p[f][i];
+    }
+    __device__ __forceinline__ void stage(int k)
+    {
+        const double a = 1048576.0 / 0.69314718055994530942;
+#pragma unroll
+        for (int i = 0; i < kN; i++) {
+            switch (k) {
+            case 0: t[i] = a * (double)x[i]; break;
+            case 1: {                                   // FEXP's integer hi word (see fexp_d)
+                unsigned hi = (unsigned)__double2int_rz(t[i]) + 1072632447u;
+                if (!(x[i] < 0x1.62e43p+10f)) hi = 0x80000000u + 1072632447u;
+                t[i] = __hiloint2double((int)hi, 0);
+                break;
+            }
+            case 2: x[i] = 1.0f + (float)t[i]; break;
+            case 3: r[i] = __builtin_amdgcn_rcpf(x[i]); break;
+            case 4: { const float e = __builtin_fmaf(-x[i], r[i], 1.0f); r[i] = __builtin_fmaf(r[i], e, r[i]); break; }
+            case 5: x[i] = __builtin_amdgcn_div_fixupf(r[i], x[i], 1.0f); break;
+            default: break;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(f4 (&s)[FT]) const
+    {
+#pragma unroll
+        for (int f = 0; f < FT; f++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[f][i] = x[4 * f + i];
+    }
+};
+
+// layer 2: k-slot g of step r is hidden unit 16ht + 4g + r on both operands
+template <int FT>
+__device__ __forceinline__ void gemm2_group(f4 (&acc)[FT], const f4 &wot, const f4 (&s)[FT])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(wot[r], s[f][r], acc[f]);
+}
+
+// All-reduce over aligned groups of 8 lanes with DPP (no LDS traffic, unlike __shfl_xor which is a
+// ds_bpermute): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i, i.e. the
+// other quad of the 8-lane half row, which by then holds that quad's result).
+// For 16 lanes one more step: row_mirror (lane i <-> 15-i).
+template <int LANES, typename Op>
+__device__ __forceinline__ float allreduce(float v, Op op)
+{
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    if constexpr (LANES == 16)
+        v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+
+// Compiler fences (no instruction).  hipcc otherwise SINKS read-only prefetch loads down
+// to their first use (IR level) or hoists the register-only MFMA/VALU work of the next
+// phase above them (machine scheduler); either way the prefetch becomes a just-in-time
+// load and an L2 round trip per fragment is exposed.
+#define LCRC_FENCE()                        \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+
+// Softening functions of srec.cpp:164-176 (lcrc_output_configure); constants are formed on the
+// host with the reference's f32 expressions.
+__device__ __forceinline__ float soften(int func, const float *c, const float *l, float v)
+{
+    if (func == 1) return logf(v);
+    if (func == 2) {
+        if (v < c[0]) return logf(v * c[1]) / l[0];
+        return -1.0f * logf((1.0f + (-1.0f * v)) * c[2]) / l[1];
+    }
+    if (func == 3) return sqrtf(-2.0f * logf(v));
+    return v;
+}
+
+// Scatter one value of a net-input row into the MFMA B image.
+__device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, float v)
+{
+    const int f = frame >> 4, kq = k >> 4, j = (k >> 2) & 3, l = (frame & 15) + 16 * (k & 3);
+    img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
+}
+
+// compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
+// weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads
+#ifndef LCRC_DBG
+#define LCRC_DBG 0
+#endif
+
+// ---- hidden loop, ring form (shipped shapes, 8 waves per workgroup) -----------------------
+// Two waves share a SIMD (512 threads, <= 256 registers per lane): while one issues loads,
+// LDS reads or VALU work, or waits, the other keeps the MFMA pipe busy
+// (tools/ubench/cross_wave.hip).  To fit the register budget the weight fragments stream
+// through a RING of R registers-quads instead of one buffer per layer.  Per hidden tile t the
+// fragments are consumed in the fixed order
+//     entry e <  NOT         W2(t)[e]         layer 2 of tile t      (8 MFMAs)
+//     entry e <  NOT + NKQ   W1(t+1)[e-NOT]   layer 1 of tile t+1    (8 MFMAs)
+//     entry e <  FP          (padding so that FP % R == 0: ring slots are compile-time)
+// and entry e lives in slot e % R.  Right after the MFMAs of entry i are issued, the fragment
+// of entry i + R (possibly of the next tile) is requested into the slot just consumed: every
+// fragment is requested R groups (>= R * 256 cycles) before its use, and at most R requests
+// are in flight, so the in-order vmcnt waits never drain more than the one fragment needed.
+constexpr int lcrc_ring_size(int f)
+{
+    int best = 8, pad = 1 << 30;
+    for (int r = 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
+        const int p = (f + r - 1) / r * r - f;
+        if (p < pad) { pad = p; best = r; }
+    }
+    return best;
+}
+
+template <int KS, int NOT, int FT, bool EXACT>
+struct RingLoop {
+    static constexpr int NKQ = (KS + 3) / 4;
+    static constexpr int F = NOT + NKQ;
+    static constexpr int R = lcrc_ring_size(F);
+    static constexpr int FP = (F + R - 1) / R * R;
+    enum { PRO = 0, MID = 1, LAST = 2 };
+
+    const f4 *w1, *w2;
+    const float *b1;
+    const f4 *XF;
+    int hlast, lane;
+    int ks, nkq, n_ot;          // run-time sizes (generic shapes); KS / NKQ / NOT when EXACT
+    f4 ring[R];
+
+    // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling.
+    // Generic shapes: entries beyond the run-time sizes re-request the last valid fragment (a load
+    // under a branch would make the compiler drain all requests at the join); they are never consumed.
+    __device__ __forceinline__ void request(int slot, int e, int t)
+    {
+        if (e < NOT) {
+            const int ot = EXACT ? e : min(e, n_ot - 1);
+            ring[slot] = w2[((size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) + ot) * 64 + lane];
+        } else if (e - NOT < NKQ) {
+            const f4 *tb = w1 + (size_t)min(t + 1, hlast) * (EXACT ? NKQ : nkq) * 64;
+            if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(tb, e - NOT, lane);
+            else ring[slot] = tb[min(e - NOT, nkq - 1) * 64 + lane];
+        }
+    }
+
+    // one pass over the entries of tile t.  PRO: t = first tile - 1, layer-2 entries are skipped
+    // (this computes layer 1 of the first tile); LAST: layer 2 only, nothing new is requested
+    // beyond this tile's own W2 fragments.
+    template <int MODE>
+    __device__ __forceinline__ void pass(f4 (&acc)[NOT][FT], f4 (&pre)[FT], f4 &bias, int t)
+    {
+        constexpr bool kSkipSig = (LCRC_DBG & 2) != 0;
+        constexpr bool kSkipLd = (LCRC_DBG & 4) != 0;
+        const int g = lane >> 4;
+        f4 s[FT], nxt[FT];
+        if (MODE != PRO) {
+            SigTile<FT> sg;
+            sg.begin(pre);
+            if (!kSkipSig) {
+#pragma unroll
+                for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
+            }
+            sg.finish(s);
+        }
+#pragma unroll
+        for (int f = 0; f < FT; f++) nxt[f] = bias;
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE != LAST && !kSkipLd)              // bias of the tile after next: requested first, so
+            bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
+        f4 xb[2][FT];
+        const int nkq_x = EXACT ? NKQ : nkq;      // row stride of the B image
+        if (MODE != LAST) {
+#pragma unroll
+            for (int f = 0; f < FT; f++) xb[0][f] = XF[f * nkq_x * 64 + lane];
+        }
+#pragma unroll
+        for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
+            if (i < NOT) {
+                if (EXACT || i < n_ot) gemm2_group<FT>(acc[i], ring[i % R], s);
+            } else if (i - NOT < NKQ) {
+                const int kq = i - NOT;
+                if (kq + 1 < NKQ) {                // B fragments of the next group, ahead of the MFMAs
+                    const int kn = EXACT ? kq + 1 : min(kq + 1, nkq - 1);
+#pragma unroll
+                    for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * nkq_x + kn) * 64 + lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
+#pragma unroll
+                        for (int f = 0; f < FT; f++) nxt[f] = mfma16x16x4(ring[i % R][j], xb[kq & 1][f][j], nxt[f]);
+                    }
+            }
+            const int e = (i + R) % FP, dt = (i + R) / FP;
+            if (!kSkipLd && (MODE != LAST || (dt == 0 && e < NOT))) request(i % R, e, t + dt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE != LAST) {
+#pragma unroll
+            for (int f = 0; f < FT; f++) pre[f] = nxt[f];
+        }
+        LCRC_FENCE();
+    }
+
+    __device__ __forceinline__ void run(f4 (&acc)[NOT][FT], int ht0, int ht1)
+    {
+        const int g = lane >> 4;
+        f4 bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(ht0, hlast) + 4 * g);
+        // ring fill for the prologue pass: entries NOT .. NOT+R-1 of pseudo tile ht0 - 1
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int e = NOT + k;
+            request(e % R, e % FP, ht0 - 1 + e / FP);
+        }
+        LCRC_FENCE();
+        f4 pre[FT];
+        pass<PRO>(acc, pre, bias, ht0 - 1);       // (a wave without tiles computes a dummy)
+        for (int ht = ht0; ht < ht1 - 1; ht++) pass<MID>(acc, pre, bias, ht);
+        if (ht0 < ht1) pass<LAST>(acc, pre, bias, ht1 - 1);
+    }
+};
+
+// Runs one net.  On return `epi(frame, o, posterior, valid)` has been called with valid == true once
+// for every (frame, output) of the tile by SOME thread (calls with valid == false carry a clamped
+// output index and must not store), and a __syncthreads() has been passed.
+template <int KS, int NOT, int NW, bool EXACT, int FT, typename Params, typename Epi>
+__device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev &nd,
+                                        const f4 *__restrict__ XF, f4 *__restrict__ slab,
+                                        int n_ot_slab, int lane, int wave, Epi epi)
+{
+    const int n_ot = EXACT ? NOT : nd.n_ot;
+    const int g = lane >> 4;
+
+    // layer-2 accumulators: acc[ot][f][rr] = O^T[16ot + 4g + rr][16f + (lane&15)]
+    f4 acc[NOT][FT];
+#pragma unroll
+    for (int ot = 0; ot < NOT; ot++) {
+        f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (wave == 0 && (EXACT || ot < n_ot))
+            b = *reinterpret_cast<const f4 *>(nd.b2 + 16 * ot + 4 * g);   // PrepareBiases nn.cpp:857
+#pragma unroll
+        for (int f = 0; f < FT; f++) acc[ot][f] = b;
+    }
+
+    const int tpw = (nd.nht + NW - 1) / NW;
+    const int ht0 = wave * tpw;
+    const int ht1 = min(nd.nht, ht0 + tpw);
+    // pointers into locals: kernarg fields would be re-read behind every memory fence
+    const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
+    const f4 *const w2 = reinterpret_cast<const f4 *>(nd.w2p);
+    const float *const b1 = nd.b1;
+    const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+
+    {
+        RingLoop<KS, NOT, FT, EXACT> loop;
+        loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
+        loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
+        loop.run(acc, ht0, ht1);
+    }
+
+    LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
+    // ---- fold the NW partial tiles down to TWO slabs, then every thread sums the two while
+    //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
+    const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
+#pragma unroll
+    for (int top = NW; top > 2; top -= 2) {      // waves [top-2, top) fold into [top-4, top-2)
+        if (wave >= top - 2 && wave < top) {
+            f4 *s = slab + (wave - (top - 2)) * slab_f4 + lane;
+#pragma unroll
+            for (int ot = 0; ot < NOT; ot++)
+                if (EXACT || ot < n_ot) {
+#pragma unroll
+                    for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
+                }
+        }
+        __syncthreads();
+        if (wave >= top - 4 && wave < top - 2) {
+            f4 *s = slab + (wave - (top - 4)) * slab_f4 + lane;
+            const bool last = top - 4 == 0;     // the two surviving waves publish their sums in place
+#pragma unroll
+            for (int ot = 0; ot < NOT; ot++)
+                if (EXACT || ot < n_ot) {
+#pragma unroll
+                    for (int f = 0; f < FT; f++) {
+                        acc[ot][f] += s[(ot * FT + f) * 64];
+                        if (last) s[(ot * FT + f) * 64] = acc[ot][f];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    LCRC_STAMP(prm, wave, lane, 12 + (stamp0 == 8 ? 0 : 0));   // fold done (last net's value survives)
+    // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a frame, each
+    // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
+    // frame = 16f + c  ->  float index ((FT*ot + f)*64 + 16g + c)*4 + rr.
+    {
+        constexpr int LPF = NW * 64 / (16 * FT); // lanes cooperating on one frame
+        constexpr int NV = 16 * NOT / LPF;       // values per lane
+        const int tid = wave * 64 + lane;
+        const int frame = tid / LPF, part = tid % LPF;
+        const float *sa = reinterpret_cast<const float *>(slab);
+        const float *sb = sa + slab_f4 * 4;
+        const int fbase = ((frame >> 4) * 64 + (frame & 15)) * 4;
+        const int O = nd.n_out;
+        float v[NV];
+        float m = -FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int o = part + LPF * j;
+            // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
+            // unconditionally so the 2*NV LDS reads are issued back to back, select afterwards
+            const int idx = fbase + (o >> 4) * (256 * FT) + ((o >> 2) & 3) * 64 + (o & 3);
+            const float t = sa[idx] + sb[idx];
+            v[j] = o < O ? t : -FLT_MAX;
+            m = fmaxf(m, v[j]);
+        }
+        static_assert(LPF == 8 || LPF == 16, "softmax lane groups are 8 (4 waves) or 16 (8 waves) wide");
+        m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
+        // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly, whatever
+        // the workgroup's frame count: with 8 lanes per frame a lane carries two of the 16 partials
+        // (even / odd j) and the last butterfly step becomes a plain add, so 16- and 32-frame
+        // workgroups produce the same bits.
+        float sum = 0.0f, sum_hi = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
+            v[j] = part + LPF * j < O ? e : 0.0f;
+            if (LPF == 8 && (j & 1)) sum_hi += v[j]; else sum += v[j];
+        }
+        if constexpr (LPF == 8) {
+            sum = allreduce<8>(sum, [](float a, float b) { return a + b; });
+            sum_hi = allreduce<8>(sum_hi, [](float a, float b) { return a + b; });
+            sum += sum_hi;
+        } else {
+            sum = allreduce<16>(sum, [](float a, float b) { return a + b; });
+        }
+        const float scale = 1.0f / sum;
+        __syncthreads();                          // slabs are free again (the epilogue may reuse them)
+        LCRC_STAMP(prm, wave, lane, 13);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int o = part + LPF * j;
+            epi(frame, min(o, O - 1), v[j] * scale, o < O);   // loads inside stay unconditional
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace phnrec
+#endif

@@ -88,3 +88,25 @@ def test_gpu_front_end_flag(tmp_path):
     mel = tmp_path / "t.mel"
     run("-c", model_dir(CZ), "-F", "-i", os.path.join(GOLD, "test.raw"), "-t", "par", "-o", mel)
     assert open(mel, "rb").read() == open(os.path.join(GOLD, CZ, "test.mel"), "rb").read()
+
+
+def test_default_system_1bt_dct_end_to_end(tmp_path):
+    """posteriors/system=1BT_DCT (the schema default, srec.cpp:69) through the CLI on the bundled utterance,
+    against what the reference CLI wrote for the same synthetic model (tools/make_golden_systems.py)"""
+    from phnrec_amd import modelgen
+    from tools.make_golden_systems import CLI_CASE
+    c = dict(CLI_CASE)
+    d = str(tmp_path / "model")
+    modelgen.write_traps_dir(d, c.pop("system"), c.pop("nbanks"), c.pop("hidden"), c.pop("n_out"),
+                             seed=c.pop("seed"), **c)
+    raw = os.path.join(GOLD, "test.raw")
+    lop = tmp_path / "t.lop"
+    run("-c", d, "-i", raw, "-t", "post", "-o", lop)
+    got, want = read_htk(str(lop)), read_htk(os.path.join(GOLD, "systems", "1bt_dct.lop"))
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+    rec = tmp_path / "t.rec"
+    run("-c", d, "-i", raw, "-o", rec)
+    _labels_match(rec, os.path.join(GOLD, "systems", "1bt_dct.rec"))
+    rec2 = tmp_path / "t2.rec"
+    run("-c", d, "-i", raw, "-o", rec2, "-F")           # GPU front-end feeds these systems as well
+    _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))

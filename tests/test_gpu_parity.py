@@ -366,3 +366,58 @@ def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
         with pytest.raises(capi.LcrcError):
             ctx.set_tile_frames(24)
         ctx.close()
+
+
+def test_other_posterior_systems(capi, oracle_mod, tmp_path):
+    """posteriors/system = 1BT_DCT, 1BT, 3BT ("next" row f4) through lcrc_create_system: the feature kernel +
+    MLP kernel composition against the reference's goldens (tests/golden/systems.npz) and the oracle, the
+    streaming form, the device-side writer path, and the calls that exist for LCRC only"""
+    from tools.make_golden_systems import CASES
+    gold = np.load(os.path.join(GOLD, "systems.npz"))
+    for name, system, nb, hid, nout, seed, kw, lens in CASES:
+        d = str(tmp_path / name)
+        modelgen.write_traps_dir(d, system, nb, hid, nout, seed=seed, **kw)
+        add_c0, hamming = kw.get("add_c0", True), kw.get("hamming", False)
+        ctx = capi.Lcrc(d, nb, system=system, add_c0=add_c0, hamming=hamming)
+        assert ctx.kernel_name == "traps_" + system.lower() and ctx.n_out == nout
+        mel, off = gold[name + "/mel"], gold[name + "/off"]
+        got = ctx.posteriors_batch(mel, off)
+        assert np.abs(got - gold[name + "/post"]).max() < TOL, (name, np.abs(got - gold[name + "/post"]).max())
+        assert np.abs(got.sum(axis=1) - 1).max() < 1e-5
+        o = oracle_mod.TrapsOracle(d, system, nb, add_c0, hamming)
+        # a longer ragged batch than the goldens hold, incl. empty utterances and a multi-workgroup one
+        lens2 = [0, 5, 300, 0, 64, 1]
+        off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+        mel2 = modelgen.synth_mel(int(off2[-1]), nb, seed=seed)
+        got2 = ctx.posteriors_batch(mel2, off2)
+        assert np.abs(got2 - o.posteriors_batch(mel2, off2)).max() < TOL, name
+        assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2)                  # deterministic
+        assert np.array_equal(ctx.posteriors_staged(mel2, off2), got2)
+        # streaming form == whole-utterance form (window ending at pushed frame i is centred at i - 15)
+        u = mel2[int(off2[2]):int(off2[3])][:60]
+        whole = ctx.posteriors(u)
+        ctx.reset()
+        pushed = np.concatenate([ctx.push(u[i:i + 7]) for i in range(0, len(u), 7)])
+        tail = ctx.push(np.repeat(u[-1:], 15, axis=0))
+        assert np.abs(np.concatenate([pushed, tail])[15:] - whole).max() < 1e-6
+        # writer path in the merger's epilogue
+        ctx.configure_output(("log",), big_endian=True)
+        with np.errstate(divide="ignore"):
+            want = np.log(got2)
+        be = ctx.posteriors_batch(mel2, off2).view(">f4").astype(np.float32)
+        ok = np.isfinite(want)
+        assert np.abs(be[ok] - want[ok]).max() <= 2e-6 * max(1.0, np.abs(want[ok]).max())
+        ctx.configure_output(())
+        with pytest.raises(capi.LcrcError):
+            ctx.posteriors_probe(u)
+        ctx.close()
+    # what the reference rejects or cannot run is an error here too, with its message
+    d = str(tmp_path / "bad")
+    modelgen.write_traps_dir(d, "1BT", 15, 30, 12, seed=1)
+    with pytest.raises(capi.LcrcError, match="Unknown posterior estimator system"):
+        capi.Lcrc(d, 15, system="2BT")
+    os.remove(os.path.join(d, "weights", "band14.nbin"))
+    with pytest.raises(capi.LcrcError, match="ERROR: Loading neural network"):
+        capi.Lcrc(d, 15, system="1BT")
+    with pytest.raises(capi.LcrcError, match="merger input size"):     # 3BT over 16 banks: 14 nets x 12 != 180
+        capi.Lcrc(d, 16, system="3BT")

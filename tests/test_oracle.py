@@ -218,3 +218,27 @@ def test_sentence_mean_norm(oracle_mod):
             s = np.float32(s + v)
         want[:, b] += -np.float32(s * (np.float32(1.0) / np.float32(mel.shape[0])))
     assert np.array_equal(got, want)
+
+
+def test_other_posterior_systems_vs_reference_goldens(oracle_mod, tmp_path):
+    """traps_oracle.c (1BT_DCT / 1BT / 3BT, with and without Hamming window and C0) against what the
+    reference's own Traps class produced on the same seeded synthetic models (tests/golden/systems.npz,
+    tools/make_golden_systems.py): bit-exact, and again in-process when oracle/_ref is present"""
+    from tools.make_golden_systems import CASES
+    gold = np.load(os.path.join(GOLD, "systems.npz"))
+    for name, system, nb, hid, nout, seed, kw, lens in CASES:
+        d = str(tmp_path / name)
+        modelgen.write_traps_dir(d, system, nb, hid, nout, seed=seed, **kw)
+        o = oracle_mod.TrapsOracle(d, system, nb, kw.get("add_c0", True), kw.get("hamming", False))
+        assert o.n_out == nout
+        assert o.n_band_nets == (0 if system == "1BT_DCT" else nb - 2 if system == "3BT" else nb)
+        mel, off = gold[name + "/mel"], gold[name + "/off"]
+        assert np.array_equal(mel, np.concatenate([modelgen.synth_mel(n, nb, seed=1000 * seed + i)
+                                                   for i, n in enumerate(lens)]))
+        got = o.posteriors_batch(mel, off)
+        assert np.array_equal(got, gold[name + "/post"]), name
+        if oracle_mod.ref_lib_path(False):
+            t = oracle_mod.RefTraps(d, nb, bunch=3, system=system, add_c0=kw.get("add_c0", True),
+                                    hamming=kw.get("hamming", False))
+            a, b = int(off[0]), int(off[1])
+            assert np.array_equal(t.process_offline(mel[a:b]), got[a:b])
