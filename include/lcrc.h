@@ -179,6 +179,27 @@ typedef struct lcrc_softening {
 } lcrc_softening;
 int lcrc_output_configure(lcrc_ctx *ctx, const lcrc_softening *stages, int n_stages, int big_endian);
 
+/* ---- decoder on the device ("next" row f3; optional -- the shipped arrangement decodes on the host) ------
+ * PhnDec (decoder/type=phndec of every shipped config; phndec.cpp:44-303): the phoneme-loop Viterbi
+ * with S-state left-to-right models, ln 0.5 transitions, insertion penalty, and labels released at the
+ * time_pruning horizon, run by one wave per utterance right behind the posterior kernel, on the
+ * (softened: configure decoder/softening_func with lcrc_output_configure) posteriors in HBM.
+ * After lcrc_decoder_configure every host-synchronous posterior call (lcrc_posteriors, _batch,
+ * lcrc_stage_run, lcrc_wave_to_posteriors) also decodes; lcrc_last_labels returns the result of the most
+ * recent one.  lcrc_set_posterior_readback(ctx, 0) then skips the device-to-host copy of the
+ * posteriors (`post` arguments may be NULL; the staged posterior buffer is not refreshed).
+ * n_phonemes <= 64, states_per_phn <= 4, time_pruning <= 255, n_phonemes*states <= outputs;
+ * n_phonemes = 0 switches the decoder off. */
+typedef struct lcrc_label {
+    int start, end;          /* frames; the reference prints them as "%d00000" (100 ns units)   phndec.cpp:230 */
+    int phn;                 /* line number in dicts/phoneme_list                                              */
+    float score;
+} lcrc_label;
+int lcrc_decoder_configure(lcrc_ctx *ctx, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty);
+int lcrc_set_posterior_readback(lcrc_ctx *ctx, int enabled);
+/* labels of utterance u: labels[first[u]] .. labels[first[u] + count[u] - 1]; valid until the next call */
+int lcrc_last_labels(lcrc_ctx *ctx, const lcrc_label **labels, const int **first, const int **count, int *n_utts);
+
 /* ---- streaming form (Traps semantics) -----------------------------------------
  * lcrc_reset == Traps::Reset (traps.cpp:174-177).
  * lcrc_push  == Traps::CalcFeaturesBunched(mel, post, n, needed)

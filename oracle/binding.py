@@ -222,6 +222,21 @@ class Oracle:
         return post
 
 
+def phndec(logpost, n_phonemes, states=3, time_pruning=40, wpenalty=0.0):
+    """phndec_oracle.c: labels [(start, end, phn, score)] of one utterance of log-posteriors"""
+    L = lib()
+    L.orc_phndec.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                             _i32p, _i32p, _i32p, _f32p]
+    lp = np.ascontiguousarray(logpost, dtype=np.float32)
+    T = lp.shape[0]
+    cols = lp.shape[1] if lp.ndim == 2 else 0
+    st, en, ph = (np.zeros(max(T, 1), np.int32) for _ in range(3))
+    sc = np.zeros(max(T, 1), np.float32)
+    n = L.orc_phndec(lp.reshape(-1) if T else np.zeros(1, np.float32), T, cols, n_phonemes, states,
+                     time_pruning, wpenalty, st, en, ph, sc)
+    return [(int(st[i]), int(en[i]), int(ph[i]), float(sc[i])) for i in range(n)]
+
+
 class TrapsOracle:
     """traps_oracle.c: the 1BT_DCT / 1BT / 3BT variants of Traps (stateless whole-utterance form)."""
 

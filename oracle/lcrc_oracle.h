@@ -107,6 +107,11 @@ void orc_lcrc_process_offline(orc_lcrc *c, const float *mel, int n, float *post,
 /* Sentence mean normalisation in place (srec.cpp:1500-1511, matrix.h:2101-2116) */
 void orc_sentence_mean_norm(float *mel, int n, int nbanks);
 
+/* PhnDec, the phoneme-loop Viterbi decoder (phndec_oracle.c; phndec.cpp:44-303): one utterance of T rows of
+ * softened (log) posteriors; returns the number of labels written (capacity T each). */
+int orc_phndec(const float *logpost, int T, int cols, int P, int S, int prune, float wpen,
+               int *start, int *end, int *phn, float *score);
+
 /* Multi-threaded whole-utterance posteriors (frames split over threads; each
  * frame is independent).  Used only for bench.py's all-cores cpu_baseline. */
 void orc_lcrc_posteriors_mt(const orc_lcrc *c, const float *mel, int n, float *post, int threads);

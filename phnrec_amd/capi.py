@@ -19,7 +19,7 @@ SYMBOLS = [
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
-    "lcrc_output_configure",
+    "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_kernel_name",
 ]
@@ -37,6 +37,11 @@ class Softening(C.Structure):
 
 
 SOFT_FUNCS = {"none": 0, "log": 1, "igor": 2, "gmm_bypass": 3}
+
+
+class Label(C.Structure):
+    """struct lcrc_label (include/lcrc.h)"""
+    _fields_ = [("start", C.c_int), ("end", C.c_int), ("phn", C.c_int), ("score", C.c_float)]
 
 
 class Frontend(C.Structure):
@@ -119,6 +124,10 @@ def load():
     L.lcrc_stage_run.argtypes = [vp, _i32p, C.c_int]
     L.lcrc_frontend_configure.argtypes = [vp, C.POINTER(Frontend)]
     L.lcrc_output_configure.argtypes = [vp, C.POINTER(Softening), C.c_int, C.c_int]
+    L.lcrc_decoder_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.lcrc_set_posterior_readback.argtypes = [vp, C.c_int]
+    L.lcrc_last_labels.argtypes = [vp, C.POINTER(C.POINTER(Label)), C.POINTER(C.POINTER(C.c_int)),
+                                   C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.c_int)]
     L.lcrc_frontend_frames.argtypes = [vp, C.c_longlong]
     _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -224,6 +233,24 @@ class Lcrc:
             args = list(args) + [0.0] * (3 - len(args))
             arr[i] = Softening(SOFT_FUNCS[name], *args)
         self._check(self.L.lcrc_output_configure(self.h, arr, len(stages), int(big_endian)))
+
+    # -- decoder on the device (PhnDec) --
+    def configure_decoder(self, n_phonemes, states=3, time_pruning=40, wpenalty=0.0):
+        self._check(self.L.lcrc_decoder_configure(self.h, n_phonemes, states, time_pruning, wpenalty))
+
+    def set_posterior_readback(self, on):
+        self._check(self.L.lcrc_set_posterior_readback(self.h, int(on)))
+
+    def last_labels(self):
+        """labels of the most recent host-synchronous call: one list of (start, end, phn, score) per utterance"""
+        lab, first, cnt = C.POINTER(Label)(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
+        n = C.c_int()
+        self._check(self.L.lcrc_last_labels(self.h, C.byref(lab), C.byref(first), C.byref(cnt), C.byref(n)))
+        out = []
+        for u in range(n.value):
+            out.append([(lab[first[u] + k].start, lab[first[u] + k].end, lab[first[u] + k].phn, lab[first[u] + k].score)
+                        for k in range(cnt[u])])
+        return out
 
     # -- waveform entry (GPU mel-bank front-end) --
     def configure_frontend(self, wave_format="lin16", sample_freq=8000, vector_size=200, vector_step=80,

@@ -24,6 +24,7 @@ public:
     void SetTimePruning(int n) { prune_ = n; }
     void SetWPenalty(float p) { wpen_ = p; }
     int NumPhonemes() const { return (int)phn_.size(); }
+    const std::vector<std::string> &Names() const { return phn_; }
     void Init();                                          // phndec.cpp:44-94
     void ProcessFrame(const float *logpost);              // phndec.cpp:160-167
     void Done();                                          // phndec.cpp:236-303

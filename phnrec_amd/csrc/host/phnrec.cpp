@@ -30,7 +30,8 @@ static void Help()
     puts(" -g num [1]         number of GPUs to spread a file list over (MI355X build)");
     puts(" -b num [32768]     frames per GPU launch when batching a file list");
     puts(" -j num [all]       host threads for the front-end and the decoder");
-    puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)\n");
+    puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
+    puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)\n");
 }
 
 struct Opt {
@@ -71,7 +72,7 @@ int main(int argc, char **argv)
 {
     const char *config_dir = nullptr, *file_list = nullptr, *input_file = nullptr, *output_file = nullptr;
     const char *output_mlf = nullptr, *wpenalty = nullptr;
-    bool live = false, verbose = false, gpu_fe = false;
+    bool live = false, verbose = false, gpu_fe = false, gpu_dec = false;
     int gpus = 1, batch = 0, threads = 0;
     DataFormat iformat = dfWaveform, oformat = dfStrings;
     WaveFormat wformat = WF_UNKNOWN;
@@ -80,7 +81,7 @@ int main(int argc, char **argv)
     int ind = 0;
     for (;;) {
         const char *arg = nullptr;
-        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:F", ind, arg);
+        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:FD", ind, arg);
         if (c == -1) break;
         switch (c) {
         case 'c': config_dir = arg; break;
@@ -111,6 +112,7 @@ int main(int argc, char **argv)
         case 'b': batch = atoi(arg); break;
         case 'j': threads = atoi(arg); break;
         case 'F': gpu_fe = true; break;
+        case 'D': gpu_dec = true; break;
         case '?': Die("Error during command line parsing\n");
         default: break;                       // bare words are skipped, as in the reference
         }
@@ -123,6 +125,7 @@ int main(int argc, char **argv)
     if (batch > 0) SR.SetBatchFrames(batch);
     if (threads > 0) SR.SetHostThreads(threads);
     SR.SetGpuFrontend(gpu_fe);
+    SR.SetGpuDecoder(gpu_dec);
     if (!SR.Init(std::string(config_dir) + "/config")) Die(SR.LastError());
 
     if (wpenalty) {

@@ -436,14 +436,20 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
     }
     for (int r = 0; r < job.frames; r++) dec.ProcessFrame(post + (size_t)r * cols);
     dec.Done();
+    EmitLabels(job, mlf, dec.Labels());
+}
+
+// label file (phndec.cpp:230,292) or MLF entry (srec.cpp:137-161,1156,1180)
+void SpeechRec::EmitLabels(Job &job, bool mlf, const std::vector<Label> &labels)
+{
     std::string text;
     if (mlf) {
         text = "\"" + job.tgt + "\"\n";
-        for (const Label &l : dec.Labels()) text += FormatMlfLine(l);
+        for (const Label &l : labels) text += FormatMlfLine(l);
         text += ".\n";
         job.labels.swap(text);
     } else {
-        for (const Label &l : dec.Labels()) text += FormatLabelLine(l);
+        for (const Label &l : labels) text += FormatLabelLine(l);
         FILE *f = fopen(job.tgt.c_str(), "w");
         if (!f) { job.ok = false; job.err = "Can not create file: " + job.tgt + "\n"; return; }
         fputs(text.c_str(), f);
@@ -544,6 +550,31 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
             for (auto &g : gpus_)
                 if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
         }
+        // -D: the decoder runs behind the posterior kernel and only labels cross PCIe
+        const bool dev_dec = gpu_decoder_ && out == dfStrings;
+        std::vector<std::string> phn_names;
+        if (dev_dec) {
+            PhnDec names;
+            if (!names.LoadPhnList(phoneme_list_)) return Fail("Can not open the phoneme list: " + phoneme_list_ + "\n");
+            phn_names = names.Names();
+        }
+        for (auto &g : gpus_)
+            if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
+                return Fail(g->LastError() + "\n");
+        auto device_labels = [&](Traps &tr, int first, int cnt) -> bool {
+            const lcrc_label *lab; const int *lfirst, *lcount; int nu = 0;
+            if (!tr.LastLabels(&lab, &lfirst, &lcount, &nu) || nu != cnt) return false;
+            pool_->ParallelFor(cnt, [&](int k) {
+                Job &j = jobs[first + k];
+                std::vector<Label> v((size_t)lcount[k]);
+                for (int i = 0; i < lcount[k]; i++) {
+                    const lcrc_label &l = lab[lfirst[k] + i];
+                    v[i] = Label{l.start, l.end, phn_names[l.phn], l.score};
+                }
+                EmitLabels(j, mlf != nullptr, v);
+            });
+            return true;
+        };
         auto worker = [&](int g) {
             Traps &tr = *gpus_[g];
             std::vector<int> off;
@@ -562,13 +593,18 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                         boff.push_back((long long)raw.size());
                         std::vector<unsigned char>().swap(j.bytes);
                     }
-                    std::vector<float> post((size_t)off.back() * n_out_);
+                    std::vector<float> post(dev_dec ? 0 : (size_t)off.back() * n_out_);
                     std::vector<int> foff(cnt + 1);
                     raw.push_back(0);
-                    if (!tr.WaveToPosteriors(raw.data(), boff.data(), cnt, post.data(), foff.data())) {
+                    if (!tr.WaveToPosteriors(raw.data(), boff.data(), cnt, dev_dec ? nullptr : post.data(), foff.data())) {
                         errs[g] = tr.LastError(); failed = true; return;
                     }
                     if (off.back() > 0) kms[g] += tr.LastKernelMs();
+                    if (dev_dec) {
+                        if (off.back() > 0 && !device_labels(tr, first, cnt)) { errs[g] = "device decoder returned no labels"; failed = true; return; }
+                        if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(jobs[first + k], mlf != nullptr, {}); });
+                        continue;
+                    }
                     float *hp = post.data();
                     pool_->ParallelFor(cnt, [&](int k) {
                         Job &j = jobs[first + k];
@@ -587,6 +623,11 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                 });
                 if (!tr.StageRun(off.data(), cnt)) { errs[g] = tr.LastError(); failed = true; return; }
                 if (off.back() > 0) kms[g] += tr.LastKernelMs();
+                if (dev_dec) {
+                    if (off.back() > 0 && !device_labels(tr, first, cnt)) { errs[g] = "device decoder returned no labels"; failed = true; return; }
+                    if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(jobs[first + k], mlf != nullptr, {}); });
+                    continue;
+                }
                 pool_->ParallelFor(cnt, [&](int k) {
                     Job &j = jobs[first + k];
                     float *post = h_post + (size_t)off[k] * n_out_;

@@ -67,6 +67,7 @@ public:
     void SetGpus(int n) { n_gpus_ = n; }
     void SetBatchFrames(int n) { batch_frames_ = n; }
     void SetHostThreads(int n) { host_threads_ = n; }
+    void SetGpuDecoder(bool v) { gpu_decoder_ = v; }     // -D: PhnDec on the GPU, posteriors never leave it
     void SetGpuFrontend(bool v) { gpu_frontend_ = v; }   // -F: waveform -> posteriors without the host front-end
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
@@ -92,13 +93,14 @@ private:
     // soft funcs, decode / dump; `post` = job.frames x cols posteriors (writable)
     // device_done: softening (and, for dumps, the big-endian byte order) already applied by the GPU
     void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done = false);
+    void EmitLabels(Job &job, bool mlf, const std::vector<Label> &labels);
     bool EnsureGpus();
     void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
     bool Fail(const std::string &msg) { err_ = msg; return false; }
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
 
     std::string config_dir_, err_;
-    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false;
+    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     float wpenalty_ = -2.0f;

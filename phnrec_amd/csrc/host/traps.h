@@ -97,6 +97,18 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // decoder on the device (lcrc_decoder_configure / lcrc_last_labels)
+    bool ConfigureDecoder(int n_phonemes, int states, int time_pruning, float wpenalty, bool posterior_readback)
+    {
+        if (lcrc_decoder_configure(ctx_, n_phonemes, states, time_pruning, wpenalty) == LCRC_OK &&
+            lcrc_set_posterior_readback(ctx_, posterior_readback ? 1 : 0) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    bool LastLabels(const lcrc_label **labels, const int **first, const int **count, int *n_utts)
+    {
+        return lcrc_last_labels(ctx_, labels, first, count, n_utts) == LCRC_OK;
+    }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

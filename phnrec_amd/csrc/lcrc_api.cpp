@@ -73,6 +73,15 @@ struct lcrc_ctx {
     lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     int out_be = 0;
     int tile_frames = 0;
+    // decoder on the device ("next" row f3): configuration, label buffers (device + pinned host)
+    int dec_P = 0, dec_S = 0, dec_prune = 0;
+    float dec_wpen = 0.f;
+    bool readback = true;
+    lcrc_label *d_labels = nullptr, *h_labels = nullptr;
+    int *d_count = nullptr, *h_count = nullptr;
+    size_t cap_label_rows = 0, cap_label_utts = 0;
+    std::vector<int> label_first;
+    int label_utts = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     int dbg_flags = 0;
     std::string err;
@@ -274,6 +283,45 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     return LCRC_OK;
 }
 
+// Decoder behind the posterior kernel: labels and counts are copied to pinned memory on the same stream.
+// h_first: host copy of the utterance offsets (first label slot of each utterance).
+int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, int n_rows, const float *d_post,
+                 hipStream_t s)
+{
+    c->label_utts = 0;
+    if (c->dec_P <= 0 || n_rows <= 0) return LCRC_OK;
+    if (c->out_be) return fail(c, LCRC_E_ARG, "the decoder needs posteriors in host byte order (lcrc_output_configure big_endian=0)");
+    if ((size_t)n_rows > c->cap_label_rows) {
+        const size_t cap = (size_t)n_rows + n_rows / 4 + 64;
+        if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
+        c->d_labels = c->h_labels = nullptr;
+        c->cap_label_rows = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_labels, cap * sizeof(lcrc_label)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), hipHostMallocDefault));
+        c->cap_label_rows = cap;
+    }
+    if ((size_t)n_utts > c->cap_label_utts) {
+        const size_t cap = (size_t)n_utts + n_utts / 4 + 64;
+        if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
+        c->d_count = c->h_count = nullptr;
+        c->cap_label_utts = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_count, cap * sizeof(int)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), hipHostMallocDefault));
+        c->cap_label_utts = cap;
+    }
+    PhnDecParams p;
+    memset(&p, 0, sizeof p);
+    p.logpost = d_post; p.off = d_off; p.n_utts = n_utts; p.cols = c->nets[2].n_out;
+    p.P = c->dec_P; p.S = c->dec_S; p.prune = c->dec_prune; p.wpen = c->dec_wpen;
+    p.labels = c->d_labels; p.count = c->d_count;
+    HIP_TRY(c, phndec_launch(p, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_labels, c->d_labels, (size_t)n_rows * sizeof(lcrc_label), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_count, c->d_count, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, s));
+    c->label_first.assign(h_first, h_first + n_utts);
+    c->label_utts = n_utts;
+    return LCRC_OK;
+}
+
 int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, float *post,
              float *const *probes)
 {
@@ -306,9 +354,18 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
     }
     rc = launch(c, c->d_mel, d_off, off ? n_utts : 1, n, c->d_post, c->stream, any ? dbg : nullptr);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (c->dec_P > 0) {
+        if (!off) {                              // one utterance: the decoder still wants [0, n]
+            c->h_off[0] = 0; c->h_off[1] = n;
+            HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
+        rc = decode_after(c, c->d_off, c->h_off, off ? n_utts : 1, n, c->d_post, c->stream);
+        if (rc) return rc;
+    }
+    const bool copy_post = c->readback || c->dec_P <= 0;
+    if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
+    if (copy_post && post) memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
     if (any)
         for (int i = 0; i < 5; i++)
             if (probes[i]) HIP_TRY(c, hipMemcpy(probes[i], c->d_dbg[i], (size_t)n * widths[i] * sizeof(float), hipMemcpyDeviceToHost));
@@ -577,6 +634,8 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->h_post) (void)hipHostFree(c->h_post);
     if (c->h_off) (void)hipHostFree(c->h_off);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
+    if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
+    if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
     if (c->d_feat) (void)hipFree(c->d_feat);
     if (c->d_minp) (void)hipFree(c->d_minp);
     if (c->d_hamming) (void)hipFree(c->d_hamming);
@@ -684,7 +743,10 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
     HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
     rc = launch(c, c->d_mel, c->d_off, n_utts, n, c->d_post, c->stream, nullptr);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    rc = decode_after(c, c->d_off, c->h_off, n_utts, n, c->d_post, c->stream);
+    if (rc) return rc;
+    if (c->readback || c->dec_P <= 0)
+        HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LCRC_OK;
 }
@@ -851,15 +913,47 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     if (!c) return LCRC_E_ARG;
     int rows = 0;
     int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
-    if (rc || rows == 0) return rc;
-    if (!post) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
+    if (rc || rows == 0) { if (c) c->label_utts = 0; return rc; }
+    const bool copy_post = c->readback || c->dec_P <= 0;
+    if (!post && copy_post) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
     if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, rows, c->nbanks, c->d_means, c->stream));
     rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
+    rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
+    if (rc) return rc;
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
-    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
+    if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    memcpy(post, c->h_post, nbytes);
+    if (copy_post) memcpy(post, c->h_post, nbytes);
+    return LCRC_OK;
+}
+
+int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n_phonemes == 0) { c->dec_P = 0; c->label_utts = 0; return LCRC_OK; }
+    if (n_phonemes < 0 || n_phonemes > 64 || states_per_phn < 1 || states_per_phn > 4 || time_pruning < 1 ||
+        time_pruning > 255 || n_phonemes * states_per_phn > c->nets[2].n_out)
+        return fail(c, LCRC_E_UNSUPPORTED, "lcrc_decoder_configure: needs <= 64 phonemes, <= 4 states, time_pruning <= 255, "
+                                          "phonemes x states <= posterior outputs");
+    c->dec_P = n_phonemes; c->dec_S = states_per_phn; c->dec_prune = time_pruning; c->dec_wpen = wpenalty;
+    return LCRC_OK;
+}
+
+int lcrc_set_posterior_readback(lcrc_ctx *c, int enabled)
+{
+    if (!c) return LCRC_E_ARG;
+    c->readback = enabled != 0;
+    return LCRC_OK;
+}
+
+int lcrc_last_labels(lcrc_ctx *c, const lcrc_label **labels, const int **first, const int **count, int *n_utts)
+{
+    if (!c || !labels || !first || !count || !n_utts) return LCRC_E_ARG;
+    *labels = c->h_labels;
+    *first = c->label_first.data();
+    *count = c->h_count;
+    *n_utts = c->label_utts;
     return LCRC_OK;
 }
 

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/lcrc.h"
+
 namespace phnrec {
 
 // A workgroup owns 16*FT consecutive frames (FT 16-frame MFMA column tiles): FT = 2 for launches that
@@ -117,6 +119,18 @@ constexpr int kMlpKS = 256, kMlpNOT = 13;   // <= 1024 inputs, <= 208 outputs pe
 hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream);
 hipError_t mlp_launch(const MlpParams &p, hipStream_t stream);
 bool mlp_supports(const NetDev &net);
+
+// ---- phoneme-loop Viterbi decoder (phndec_kernels.hip; "next" row f3, optional) ---------------------
+struct PhnDecParams {
+    const float *logpost;   // [rows][cols] softened (log) posteriors, resident in HBM
+    const int *off;         // [n_utts + 1]
+    int n_utts, cols;
+    int P, S, prune;        // phonemes, states per phoneme, decoder/time_pruning
+    float wpen;             // decoder/wpenalty
+    lcrc_label *labels;     // [rows]: the labels of utterance u start at labels[off[u]]
+    int *count;             // [n_utts]
+};
+hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream);
 
 // launcher (lcrc_kernels.hip)
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);

@@ -110,3 +110,30 @@ def test_default_system_1bt_dct_end_to_end(tmp_path):
     rec2 = tmp_path / "t2.rec"
     run("-c", d, "-i", raw, "-o", rec2, "-F")           # GPU front-end feeds these systems as well
     _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))
+
+
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_decoder_on_the_gpu_flag(system, tmp_path):
+    """-D: PhnDec runs on the device behind the posterior kernel; same label files as the reference's, for
+    the single-file form, for the -F form and for a batched list into an MLF"""
+    raw_path = os.path.join(GOLD, "test.raw")
+    out = tmp_path / "t.rec"
+    run("-c", model_dir(system), "-i", raw_path, "-o", out, "-D")
+    _labels_match(out, os.path.join(GOLD, system, "test.rec"))
+    out2 = tmp_path / "t2.rec"
+    run("-c", model_dir(system), "-i", raw_path, "-o", out2, "-D", "-F")
+    _labels_match(out2, os.path.join(GOLD, system, "test.rec"))
+    if system != CZ:
+        return
+    raw = open(raw_path, "rb").read()
+    pieces = {"utt_a": raw, "utt_b": raw[:20000], "utt_c": raw[:3000]}
+    data = tmp_path / "data"
+    data.mkdir()
+    for n, blob in pieces.items():
+        (data / (n + ".raw")).write_bytes(blob)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s\n" % (data / (n + ".raw")) for n in pieces))
+    host, dev = tmp_path / "host.mlf", tmp_path / "dev.mlf"
+    run("-c", model_dir(CZ), "-l", lst, "-m", host)
+    run("-c", model_dir(CZ), "-l", lst, "-m", dev, "-D", "-b", 800)      # several launches
+    assert dev.read_text() == host.read_text()                            # same posteriors, same f32 additions

@@ -421,3 +421,49 @@ def test_other_posterior_systems(capi, oracle_mod, tmp_path):
         capi.Lcrc(d, 15, system="1BT")
     with pytest.raises(capi.LcrcError, match="merger input size"):     # 3BT over 16 banks: 14 nets x 12 != 180
         capi.Lcrc(d, 16, system="3BT")
+
+
+def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
+    """lcrc_decoder_configure ("next" row f3): the PhnDec kernel behind the posterior kernel against the
+    decoder oracle run on the SAME log-posteriors (bit-identical labels, times and scores: both do the same
+    f32 additions), on ragged batches incl. empty, 1-frame and shorter-than-the-pruning-horizon utterances,
+    for several state counts / horizons / penalties; with and without posterior read-back"""
+    for nb, hid, nout, P, S, prune, wpen in ((15, 64, 138, 45, 3, 40, -4.6875), (11, 40, 48, 12, 4, 7, -1.5),
+                                             (9, 30, 20, 20, 1, 255, 0.0), (13, 30, 64, 21, 3, 1, -0.25),
+                                             (15, 50, 192, 64, 3, 40, -2.0)):
+        d = str(tmp_path / ("m%d_%d" % (P, S)))
+        modelgen.write_model_dir(d, nb, hid, nout, seed=P)
+        ctx = capi.Lcrc(d, nb)
+        ctx.configure_output(("log",))
+        lens = [0, 1, 2, prune, prune + 1, 3 * prune + 5, 400, 0, 37]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), nb, seed=S)
+        logpost = ctx.posteriors_batch(mel, off)
+        assert ctx.last_labels() == []                          # decoder not configured yet
+        ctx.configure_decoder(P, S, prune, wpen)
+        again = ctx.posteriors_batch(mel, off)
+        assert np.array_equal(again, logpost)
+        got = ctx.last_labels()
+        assert len(got) == len(lens)
+        for u in range(len(lens)):
+            want = oracle_mod.phndec(logpost[off[u]:off[u + 1]], P, S, prune, wpen)
+            assert got[u] == want, (P, S, prune, u, got[u][:3], want[:3])
+            assert all(0 <= a[0] < a[1] <= lens[u] for a in want)                    # within the utterance,
+            assert all(a[1] <= b[0] for a, b in zip(want, want[1:]))                  # in time order
+        # staged entry without posterior read-back: labels only
+        ctx.set_posterior_readback(False)
+        ctx.posteriors_staged(mel, off)
+        assert ctx.last_labels() == got
+        # single-utterance form
+        u = mel[off[5]:off[6]]
+        ctx.set_posterior_readback(True)
+        lp = ctx.posteriors(u)
+        assert ctx.last_labels() == [oracle_mod.phndec(lp, P, S, prune, wpen)]
+        ctx.configure_decoder(0)
+        ctx.posteriors(u)
+        assert ctx.last_labels() == []
+        with pytest.raises(capi.LcrcError):
+            ctx.configure_decoder(65, 3, 40, 0.0)
+        with pytest.raises(capi.LcrcError):
+            ctx.configure_decoder(nout, 3, 40, 0.0)
+        ctx.close()

@@ -242,3 +242,17 @@ def test_other_posterior_systems_vs_reference_goldens(oracle_mod, tmp_path):
                                     hamming=kw.get("hamming", False))
             a, b = int(off[0]), int(off[1])
             assert np.array_equal(t.process_offline(mel[a:b]), got[a:b])
+
+
+@pytest.mark.parametrize("system", ["PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"])
+def test_phndec_oracle_reproduces_reference_label_files(oracle_mod, system):
+    """phndec_oracle.c on the logarithm of the reference's posterior dump == the reference's .rec
+    (labels and times exact, scores equal at the printed precision)"""
+    lop = read_htk(os.path.join(GOLD, system, "test.lop"))
+    names = [l.rstrip("\r\n") for l in open(os.path.join(model_dir(system), "dicts", "phonemes"))]
+    labs = oracle_mod.phndec(np.log(lop), len(names), 3, 40, modelgen.SYSTEMS[system]["wpenalty"])
+    gold = [l.split() for l in open(os.path.join(GOLD, system, "test.rec"))]
+    mine = [["%d00000" % s if s else "000000", "%d00000" % e, names[p], "%f" % sc] for s, e, p, sc in labs]
+    assert [m[:3] for m in mine] == [g[:3] for g in gold]
+    assert max(abs(float(m[3]) - float(g[3])) for m, g in zip(mine, gold)) < 1e-5
+    assert oracle_mod.phndec(np.zeros((0, lop.shape[1]), np.float32), len(names)) == []

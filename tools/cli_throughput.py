@@ -50,11 +50,12 @@ def main():
             pass
         env = dict(os.environ, PHNREC_STATS="1")
         for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
+                             (["-F", "-D", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end + decoder (-F -D)"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
             t0 = time.time()
             p = subprocess.run([BIN, "-c", mdir, "-l", lst] + extra, env=env, capture_output=True, text=True)
             dt = time.time() - t0
-            print("%-28s rc=%d wall %.2fs  %s" % (label, p.returncode, dt, p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ""), flush=True)
+            print("%-40s rc=%d wall %.2fs  %s" % (label, p.returncode, dt, p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ""), flush=True)
 
 
 if __name__ == "__main__":
