@@ -11,7 +11,7 @@ import pytest
 from phnrec_amd import modelgen
 from tests.util import GOLD, ROOT, model_dir, read_htk, read_htk_header
 
-BIN = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+BIN = os.environ.get("PHNREC_BIN", os.path.join(ROOT, "phnrec_amd", "bin", "phnrec"))
 CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
 
 
