@@ -56,7 +56,7 @@ struct LcrcParams {
 
 // LDS carve-up (bytes), computed identically on host and device.
 struct LdsPlan {
-    unsigned mel, rowinfo, tabs, norms, xf, gf, slab, total;
+    unsigned mel, rowinfo, tabs, xf, slab23, norms, gf, slab, total;
 };
 
 __host__ __device__ inline unsigned lcrc_round16(unsigned v) { return (v + 15u) & ~15u; }
@@ -66,13 +66,18 @@ __host__ __device__ inline LdsPlan lcrc_lds_plan(int ft, int nbanks, int nkq_ban
     LdsPlan p;
     unsigned o = 0;
     const unsigned uft = (unsigned)ft, bm = 16u * uft;
+    // Everything up to the end of xf is dead once the band nets' hidden loops are over; the band
+    // classifiers' second pair of slabs (they run side by side, see run_net) lies over it.
+    p.slab23 = 0;
     p.mel = o;      o += lcrc_round16((bm + 2u * kShift) * nbanks * 4u);
     p.rowinfo = o;  o += 2u * bm * 4u;
     p.tabs = o;     o += (10u * 16u + 2u * 16u) * 4u;
-    p.norms = o;    o += (4u * 16u * nkq_band + 2u * 16u * nkq_merger) * 4u;   // mean|dev of the 3 nets
     p.xf = o;       o += 2u * uft * nkq_band * 1024u;    // [net][f][kq][64] float4
+    const unsigned two_slabs = 2u * (uft * n_ot * 1024u);
+    if (o < two_slabs) o = two_slabs;
+    p.norms = o;    o += (4u * 16u * nkq_band + 2u * 16u * nkq_merger) * 4u;   // mean|dev of the 3 nets
     p.gf = o;       o += uft * nkq_merger * 1024u;       // [f][kq][64] float4
-    p.slab = o;     o += 2u * (uft * n_ot * 1024u);      // two slabs of [ot][f][64] float4
+    p.slab = o;     o += two_slabs;                      // two slabs of [ot][f][64] float4
     p.total = o;
     return p;
 }

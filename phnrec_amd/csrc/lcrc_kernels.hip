@@ -118,10 +118,11 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             nrm_merger[i] = p.net[2].mean[i];
             nrm_merger[wmn + i] = p.net[2].dev[i];
         }
-        f4 *z = reinterpret_cast<f4 *>(xf);
-        const int n = (int)((lp.slab - lp.xf) / 16);    // xf and gf are adjacent
-        const f4 zero = {0.f, 0.f, 0.f, 0.f};
-        for (int i = tid; i < n; i += NT) z[i] = zero;
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};             // pads of the operand images must be zeros
+        f4 *zx = reinterpret_cast<f4 *>(xf), *zg = reinterpret_cast<f4 *>(gf);
+        const int nx = 2 * FT * nkq1 * 64, ng = FT * nkqm * 64;
+        for (int i = tid; i < nx; i += NT) zx[i] = zero;
+        for (int i = tid; i < ng; i += NT) zg[i] = zero;
     }
     __syncthreads();
 
@@ -200,31 +201,40 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     __syncthreads();
 
     LCRC_STAMP(p, wave, lane, 10);              // projection done
-    // ---- stage 2: the two band nets; ln() of their outputs, normalised for the merger,
-    //      goes straight from the softmax registers into the merger's operand image ----
+    // ---- stage 2: the two band nets SIDE BY SIDE (waves 0,1: left context, waves 2,3: right context);
+    //      ln() of their outputs, normalised for the merger, goes straight from the softmax registers
+    //      into the merger's operand image ----
     const NetDev &nm = p.net[2];
     const float *mmean = nrm_merger, *mdev = nrm_merger + 16 * nkqm;
-#pragma unroll 1
-    for (int n = 0; n < 2; n++) {
-        const NetDev &nd = p.net[n];
-        const int O = nd.n_out;
-        const int kofs = n * p.net[0].n_out;
-        float *dp = n == 0 ? p.dbg_p0 : p.dbg_p1;
-        auto epi = [&](int i, int o, float q, bool valid) {
+    {
+        const int O0 = p.net[0].n_out;
+        auto epi = [&](int n, int i, int o, float q, bool valid) {
+            const int kofs = n * O0;
+            float *dp = n == 0 ? p.dbg_p0 : p.dbg_p1;
             const float gl = q > 0.0f ? logf(q) : 0.0f;             // sLn dspc.h:155-160
             if (valid && (dp || p.dbg_g) && r0 + i < p.n_rows) {
-                if (dp) dp[(size_t)(r0 + i) * O + o] = q;
+                if (dp) dp[(size_t)(r0 + i) * p.net[n].n_out + o] = q;
                 if (p.dbg_g) p.dbg_g[(size_t)(r0 + i) * nm.n_inp + kofs + o] = gl;
             }
             float v = gl - mmean[kofs + o];                          // Normalize nn.cpp:702-716
             v *= mdev[kofs + o];
             if (valid) xf_store(gf, nkqm, i, kofs + o, v);
         };
-        run_net<KS1, NOT, NW, EXACT, FT>(p, 2 + 3 * n, nd,
-                                         reinterpret_cast<const f4 *>(xf) + (size_t)n * (FT * nkq1 * 64), slab,
-                                         n_ot, lane, wave, epi);
-        LCRC_STAMP(p, wave, lane, 3 + 3 * n);   // fold + softmax + ln() done
-        LCRC_STAMP(p, wave, lane, 4 + 3 * n);
+#ifndef LCRC_BAND_PAIR
+#define LCRC_BAND_PAIR 1
+#endif
+#if LCRC_BAND_PAIR
+        run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+#else       // A/B switch (tools/ab_kernel.py): the two band nets one after the other on all four waves
+#pragma unroll 1
+        for (int n = 0; n < 2; n++) {
+            auto epi1 = [&](int, int i, int o, float q, bool valid) { epi(n, i, o, q, valid); };
+            run_net<KS1, NOT, NW, EXACT, FT, 1>(p, 2, p.net + n, reinterpret_cast<const f4 *>(xf) + (size_t)n * (FT * nkq1 * 64),
+                                                0, slab, slab, n_ot, lane, wave, epi1);
+        }
+#endif
+        LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
     }
 
     // ---- stage 3: merger; posteriors are gathered as contiguous rows in LDS (slab 0 is
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         const int O = nm.n_out;
         float *outbuf = reinterpret_cast<float *>(slab);
         const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
-        auto epi = [&](int i, int o, float q, bool valid) {
+        auto epi = [&](int, int i, int o, float q, bool valid) {
             if (transform) {                     // posterior writer path: softening, byte order
                 q = soften(p.out_func[0], p.out_c[0], p.out_l[0], q);
                 q = soften(p.out_func[1], p.out_c[1], p.out_l[1], q);
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
             if (valid) outbuf[i * O + o] = q;
         };
-        run_net<KSM, NOT, NW, EXACT, FT>(p, 8, nm, reinterpret_cast<const f4 *>(gf), slab, n_ot, lane, wave, epi);
+        run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab, slab, n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.n_rows - r0);
         const int total = rows * O;
@@ -298,9 +308,11 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
 {
     const Variant *v = pick(nets);
     if (!v) return nullptr;
-    const LdsPlan lp = lcrc_lds_plan(2, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets));
-    if (lds_bytes) *lds_bytes = lp.total;
-    if (lp.total > 160u * 1024u) return nullptr;
+    // 32-frame workgroups when their LDS image fits, else 16-frame ones only (same results)
+    unsigned total = lcrc_lds_plan(2, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets)).total;
+    if (total > 160u * 1024u) total = lcrc_lds_plan(1, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets)).total;
+    if (lds_bytes) *lds_bytes = total;
+    if (total > 160u * 1024u) return nullptr;
     return v->name;
 }
 
@@ -308,7 +320,8 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
 {
     const Variant *v = pick(p.net);
     if (!v) return hipErrorInvalidValue;
-    if (lcrc_lds_plan(2, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
+    const bool fits32 = lcrc_lds_plan(2, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
+    if (!fits32 && lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
         return hipErrorInvalidValue;
     if (variant_name) *variant_name = v->name;
     if (p.n_rows <= 0) return hipSuccess;
@@ -329,6 +342,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     // often, but there are twice as many of them: they win while the 32-frame grid would leave at
     // least half of the CUs without work.
     int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
+    if (!fits32) ft = 1;
     const int vi = (int)(v - kVariants);
     const void *fn = v->fn[ft - 1];
     if (!cached || !granted[vi][ft - 1][dev]) {

@@ -161,13 +161,14 @@ __device__ __forceinline__ void gemm2_group(f4 (&acc)[FT], const f4 &wot, const 
 // All-reduce over aligned groups of 8 lanes with DPP (no LDS traffic, unlike __shfl_xor which is a
 // ds_bpermute): quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <-> 7-i, i.e. the
 // other quad of the 8-lane half row, which by then holds that quad's result).
-// For 16 lanes one more step: row_mirror (lane i <-> 15-i).
+// 4 lanes: the two quad_perm steps; 8: + row_half_mirror; 16: + row_mirror (lane i <-> 15-i).
 template <int LANES, typename Op>
 __device__ __forceinline__ float allreduce(float v, Op op)
 {
     v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
     v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    if constexpr (LANES >= 8)
+        v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
     if constexpr (LANES == 16)
         v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
     return v;
@@ -339,14 +340,23 @@ struct RingLoop {
     }
 };
 
-// Runs one net.  On return `epi(frame, o, posterior, valid)` has been called with valid == true once
-// for every (frame, output) of the tile by SOME thread (calls with valid == false carry a clamped
-// output index and must not store), and a __syncthreads() has been passed.
-template <int KS, int NOT, int NW, bool EXACT, int FT, typename Params, typename Epi>
-__device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev &nd,
-                                        const f4 *__restrict__ XF, f4 *__restrict__ slab,
-                                        int n_ot_slab, int lane, int wave, Epi epi)
+// Runs GROUPS nets of the same shape class at once, each on NW / GROUPS waves (GROUPS = 1: one net on all
+// waves; GROUPS = 2: the two band classifiers of LCRC side by side on wave pairs -- one hidden loop, one
+// softmax phase and no fold round instead of two of each).  nets[g] / XF + g * xf_stride belong to group g.
+// slab01: two slabs of FT * n_ot_slab KiB; slab23: two more (GROUPS = 2 only; they may alias the nets' B
+// images and anything else that is dead once every wave has left its hidden loop).
+// On return `epi(group, frame, o, posterior, valid)` has been called with valid == true once for every
+// (group, frame, output) by SOME thread (calls with valid == false carry a clamped output index and must
+// not store), and a __syncthreads() has been passed.
+template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, typename Params, typename Epi>
+__device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
+                                        const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
+                                        f4 *__restrict__ slab23, int n_ot_slab, int lane, int wave, Epi epi)
 {
+    constexpr int WPG = NW / GROUPS;             // waves per net
+    const int grp = GROUPS == 1 ? 0 : wave / WPG, wig = GROUPS == 1 ? wave : wave % WPG;
+    const NetDev &nd = nets[grp];
+    const f4 *XF = XFbase + (size_t)grp * xf_stride;
     const int n_ot = EXACT ? NOT : nd.n_ot;
     const int g = lane >> 4;
 
@@ -355,14 +365,14 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
 #pragma unroll
     for (int ot = 0; ot < NOT; ot++) {
         f4 b = {0.f, 0.f, 0.f, 0.f};
-        if (wave == 0 && (EXACT || ot < n_ot))
+        if (wig == 0 && (EXACT || ot < n_ot))
             b = *reinterpret_cast<const f4 *>(nd.b2 + 16 * ot + 4 * g);   // PrepareBiases nn.cpp:857
 #pragma unroll
         for (int f = 0; f < FT; f++) acc[ot][f] = b;
     }
 
-    const int tpw = (nd.nht + NW - 1) / NW;
-    const int ht0 = wave * tpw;
+    const int tpw = (nd.nht + WPG - 1) / WPG;
+    const int ht0 = wig * tpw;
     const int ht1 = min(nd.nht, ht0 + tpw);
     // pointers into locals: kernarg fields would be re-read behind every memory fence
     const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
@@ -378,49 +388,68 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
-    // ---- fold the NW partial tiles down to TWO slabs, then every thread sums the two while
-    //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
     const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
-#pragma unroll
-    for (int top = NW; top > 2; top -= 2) {      // waves [top-2, top) fold into [top-4, top-2)
-        if (wave >= top - 2 && wave < top) {
-            f4 *s = slab + (wave - (top - 2)) * slab_f4 + lane;
-#pragma unroll
-            for (int ot = 0; ot < NOT; ot++)
-                if (EXACT || ot < n_ot) {
-#pragma unroll
-                    for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
-                }
-        }
+    if constexpr (WPG == 2) {
+        // two partial tiles per net: no fold round, each wave publishes its own and the softmax adds them
+        // while it reads.  The second pair of slabs may lie over the B images: wait until every wave has
+        // left its hidden loop.
         __syncthreads();
-        if (wave >= top - 4 && wave < top - 2) {
-            f4 *s = slab + (wave - (top - 4)) * slab_f4 + lane;
-            const bool last = top - 4 == 0;     // the two surviving waves publish their sums in place
+        f4 *s = (grp == 0 ? slab01 : slab23) + wig * slab_f4 + lane;
 #pragma unroll
-            for (int ot = 0; ot < NOT; ot++)
-                if (EXACT || ot < n_ot) {
+        for (int ot = 0; ot < NOT; ot++)
+            if (EXACT || ot < n_ot) {
 #pragma unroll
-                    for (int f = 0; f < FT; f++) {
-                        acc[ot][f] += s[(ot * FT + f) * 64];
-                        if (last) s[(ot * FT + f) * 64] = acc[ot][f];
+                for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
+            }
+        __syncthreads();
+    } else {
+        // ---- fold the WPG partial tiles down to TWO slabs, then every thread sums the two while
+        //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
+#pragma unroll
+        for (int top = WPG; top > 2; top -= 2) {     // waves [top-2, top) fold into [top-4, top-2)
+            if (wig >= top - 2 && wig < top) {
+                f4 *s = slab01 + (wig - (top - 2)) * slab_f4 + lane;
+#pragma unroll
+                for (int ot = 0; ot < NOT; ot++)
+                    if (EXACT || ot < n_ot) {
+#pragma unroll
+                        for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
                     }
-                }
+            }
+            __syncthreads();
+            if (wig >= top - 4 && wig < top - 2) {
+                f4 *s = slab01 + (wig - (top - 4)) * slab_f4 + lane;
+                const bool last = top - 4 == 0;     // the two surviving waves publish their sums in place
+#pragma unroll
+                for (int ot = 0; ot < NOT; ot++)
+                    if (EXACT || ot < n_ot) {
+#pragma unroll
+                        for (int f = 0; f < FT; f++) {
+                            acc[ot][f] += s[(ot * FT + f) * 64];
+                            if (last) s[(ot * FT + f) * 64] = acc[ot][f];
+                        }
+                    }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    LCRC_STAMP(prm, wave, lane, 12 + (stamp0 == 8 ? 0 : 0));   // fold done (last net's value survives)
-    // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a frame, each
+    LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
+    // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a (net, frame) row, each
     // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
     // frame = 16f + c  ->  float index ((FT*ot + f)*64 + 16g + c)*4 + rr.
     {
-        constexpr int LPF = NW * 64 / (16 * FT); // lanes cooperating on one frame
-        constexpr int NV = 16 * NOT / LPF;       // values per lane
+        constexpr int BM = 16 * FT;
+        constexpr int LPF = NW * 64 / (GROUPS * BM);   // lanes cooperating on one row
+        constexpr int NV = 16 * NOT / LPF;             // values per lane
+        static_assert(LPF == 4 || LPF == 8 || LPF == 16, "softmax lane groups are 4, 8 or 16 wide");
         const int tid = wave * 64 + lane;
-        const int frame = tid / LPF, part = tid % LPF;
-        const float *sa = reinterpret_cast<const float *>(slab);
+        const int row = tid / LPF, part = tid % LPF;
+        const int rg = GROUPS == 1 ? 0 : row / BM;     // wave-uniform: a wave's rows belong to one net
+        const int frame = GROUPS == 1 ? row : row % BM;
+        const float *sa = reinterpret_cast<const float *>(rg == 0 ? slab01 : slab23);
         const float *sb = sa + slab_f4 * 4;
         const int fbase = ((frame >> 4) * 64 + (frame & 15)) * 4;
-        const int O = nd.n_out;
+        const int O = nets[rg].n_out;
         float v[NV];
         float m = -FLT_MAX;
 #pragma unroll
@@ -433,33 +462,34 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
             v[j] = o < O ? t : -FLT_MAX;
             m = fmaxf(m, v[j]);
         }
-        static_assert(LPF == 8 || LPF == 16, "softmax lane groups are 8 (4 waves) or 16 (8 waves) wide");
         m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
-        // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly, whatever
-        // the workgroup's frame count: with 8 lanes per frame a lane carries two of the 16 partials
-        // (even / odd j) and the last butterfly step becomes a plain add, so 16- and 32-frame
-        // workgroups produce the same bits.
-        float sum = 0.0f, sum_hi = 0.0f;
+        // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly (pairs, then
+        // quads, then halves of 8, then the two halves), whatever LPF is: with fewer than 16 lanes per row a
+        // lane carries 16 / LPF of the partials and the last butterfly steps become plain adds -- so every
+        // geometry (16- or 32-frame workgroups, one or two nets at a time) produces the same bits.
+        constexpr int PPL = 16 / LPF;                  // partials per lane
+        float ps[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; q++) ps[q] = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
             v[j] = part + LPF * j < O ? e : 0.0f;
-            if (LPF == 8 && (j & 1)) sum_hi += v[j]; else sum += v[j];
+            ps[j % PPL] += v[j];
         }
-        if constexpr (LPF == 8) {
-            sum = allreduce<8>(sum, [](float a, float b) { return a + b; });
-            sum_hi = allreduce<8>(sum_hi, [](float a, float b) { return a + b; });
-            sum += sum_hi;
-        } else {
-            sum = allreduce<16>(sum, [](float a, float b) { return a + b; });
-        }
+#pragma unroll
+        for (int q = 0; q < PPL; q++) ps[q] = allreduce<LPF>(ps[q], [](float a, float b) { return a + b; });
+        float sum;
+        if constexpr (PPL == 1) sum = ps[0];
+        else if constexpr (PPL == 2) sum = ps[0] + ps[1];
+        else sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
         const float scale = 1.0f / sum;
         __syncthreads();                          // slabs are free again (the epilogue may reuse them)
         LCRC_STAMP(prm, wave, lane, 13);
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
-            epi(frame, min(o, O - 1), v[j] * scale, o < O);   // loads inside stay unconditional
+            epi(rg, frame, min(o, O - 1), v[j] * scale, o < O);   // loads inside stay unconditional
         }
     }
     __syncthreads();

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
 
     float *outbuf = reinterpret_cast<float *>(slab);         // slab 0 is free again in the epilogue
     const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
-    auto epi = [&](int i, int o, float q, bool valid) {
+    auto epi = [&](int, int i, int o, float q, bool valid) {
         if (p.neg_log) {
             q = (q > 0.0f ? logf(q) : 0.0f) * -1.0f;
         } else if (transform) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         }
         if (valid) outbuf[i * O + o] = q;
     };
-    run_net<KS, NOT, NW, false, 1>(p, 0, nd, reinterpret_cast<const f4 *>(xf), slab, n_ot, lane, wave, epi);
+    run_net<KS, NOT, NW, false, 1, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab, n_ot, lane, wave, epi);
     const int rows = min(BM, p.n_rows - r0);
     for (int idx = tid; idx < rows * O; idx += NT) {
         const int i = idx / O, o = idx - i * O;

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""A/B timing of two builds of the library on the SAME GPU in the SAME process, interleaved (boxes differ by
+a few percent, so numbers from separate runs cannot be compared at that level).
+
+usage: ab_kernel.py LIB_A LIB_B [frames]      (paths relative to the repo root; needs a GPU)
+Each library is loaded under its own handle; per system the two are timed alternately, 5 rounds of 100 launches.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from phnrec_amd import capi, modelgen  # noqa: E402
+
+
+class Ctx:
+    def __init__(self, lib, mdir, nbanks):
+        self.L = lib
+        self.h = C.c_void_p()
+        vp = C.c_void_p
+        lib.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.lcrc_posteriors_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        lib.lcrc_num_outputs.argtypes = [vp]
+        lib.lcrc_set_timing.argtypes = [vp, C.c_int]
+        assert lib.lcrc_create(C.byref(self.h), mdir.encode(), nbanks, 31, 1, 0) == 0
+        lib.lcrc_set_timing(self.h, 0)
+        self.n_out = lib.lcrc_num_outputs(self.h)
+
+    def run(self, mel, post, n, stream):
+        assert self.L.lcrc_posteriors_device(self.h, mel.data_ptr(), None, 1, n, post.data_ptr(), stream) == 0
+
+
+def main():
+    pa, pb = (os.path.join(ROOT, p) for p in sys.argv[1:3])
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+    capi._load_hip_runtime()
+    libs = [C.CDLL(pa), C.CDLL(pb)]
+    s = torch.cuda.current_stream()
+    print("A = %s\nB = %s\n%d frames; ms per launch, 5 interleaved rounds of 100" % (sys.argv[1], sys.argv[2], n))
+    for system, spec in modelgen.SYSTEMS.items():
+        mdir = os.path.join(ROOT, "tests", "golden", "models", system)
+        if not os.path.isdir(mdir):
+            mdir = "/tmp/ab_model_" + system
+            modelgen.write_system(mdir, system, seed=1)
+        ctxs = [Ctx(L, mdir, spec["nbanks"]) for L in libs]
+        mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
+        posts = [torch.empty((n, c.n_out), device="cuda") for c in ctxs]
+        for c, p in zip(ctxs, posts):
+            for _ in range(20):
+                c.run(mel, p, n, s.cuda_stream)
+        s.synchronize()
+        same = bool(torch.equal(posts[0], posts[1]))
+        t = [[], []]
+        for _ in range(5):
+            for k in (0, 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                for _ in range(100):
+                    ctxs[k].run(mel, posts[k], n, s.cuda_stream)
+                e1.record(s)
+                s.synchronize()
+                t[k].append(e0.elapsed_time(e1) / 100)
+        a, b = np.array(t[0]), np.array(t[1])
+        print("%-26s A %.4f (+-%.4f)  B %.4f (+-%.4f)  B/A %.4f  identical output: %s"
+              % (system, a.mean(), a.std(), b.mean(), b.std(), b.mean() / a.mean(), same))
+
+
+if __name__ == "__main__":
+    main()

@@ -19,10 +19,9 @@ import torch  # noqa: E402
 from phnrec_amd import capi, modelgen  # noqa: E402
 
 NAMES = ["stage0 stage (mel tile, tables, zero images)", "stage1 projection",
-         "band0 hidden loop", "band0 fold+softmax", "band0 ln epilogue",
-         "band1 hidden loop", "band1 fold+softmax", "band1 ln epilogue",
+         "band nets (side by side) hidden loop", "band nets softmax + ln epilogue",
          "merger hidden loop", "merger fold+softmax", "store"]
-ORDER = [0, 1, 10, 2, 3, 4, 5, 6, 7, 8, 9, 11]     # stamp indices in program order
+ORDER = [0, 1, 10, 2, 3, 8, 9, 11]     # stamp indices in program order
 
 
 def main():
