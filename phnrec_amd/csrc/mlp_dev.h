@@ -225,6 +225,9 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
 // are in flight, so the in-order vmcnt waits never drain more than the one fragment needed.
 constexpr int lcrc_ring_size(int f)
 {
+#ifdef LCRC_RING_FIXED      // A/B switch (tools/ab_kernel.py)
+    return LCRC_RING_FIXED;
+#endif
     int best = 8, pad = 1 << 30;
     for (int r = 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
         const int p = (f + r - 1) / r * r - f;

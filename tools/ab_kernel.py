@@ -3,7 +3,8 @@
 a few percent, so numbers from separate runs cannot be compared at that level).
 
 usage: ab_kernel.py LIB_A LIB_B [frames]      (paths relative to the repo root; needs a GPU)
-Each library is loaded under its own handle; per system the two are timed alternately, 5 rounds of 100 launches.
+Each library is loaded under its own handle; per system the two are timed alternately (order swapped every
+round), 9 rounds of 100 launches, first round dropped, medians reported.
 """
 import ctypes as C
 import os
@@ -42,7 +43,7 @@ def main():
     capi._load_hip_runtime()
     libs = [C.CDLL(pa), C.CDLL(pb)]
     s = torch.cuda.current_stream()
-    print("A = %s\nB = %s\n%d frames; ms per launch, 5 interleaved rounds of 100" % (sys.argv[1], sys.argv[2], n))
+    print("A = %s\nB = %s\n%d frames; ms per launch, medians of 8 interleaved rounds of 100" % (sys.argv[1], sys.argv[2], n))
     for system, spec in modelgen.SYSTEMS.items():
         mdir = os.path.join(ROOT, "tests", "golden", "models", system)
         if not os.path.isdir(mdir):
@@ -57,8 +58,8 @@ def main():
         s.synchronize()
         same = bool(torch.equal(posts[0], posts[1]))
         t = [[], []]
-        for _ in range(5):
-            for k in (0, 1):
+        for rnd in range(9):                     # order alternates; the first round (clock ramp) is dropped
+            for k in ((0, 1) if rnd % 2 == 0 else (1, 0)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(s)
                 for _ in range(100):
@@ -66,9 +67,9 @@ def main():
                 e1.record(s)
                 s.synchronize()
                 t[k].append(e0.elapsed_time(e1) / 100)
-        a, b = np.array(t[0]), np.array(t[1])
+        a, b = np.array(t[0][1:]), np.array(t[1][1:])
         print("%-26s A %.4f (+-%.4f)  B %.4f (+-%.4f)  B/A %.4f  identical output: %s"
-              % (system, a.mean(), a.std(), b.mean(), b.std(), b.mean() / a.mean(), same))
+              % (system, np.median(a), a.std(), np.median(b), b.std(), np.median(b) / np.median(a), same))
 
 
 if __name__ == "__main__":
