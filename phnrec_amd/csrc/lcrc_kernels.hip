@@ -136,6 +136,9 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     //      from the reference's separate mul and add). ----
     {
         const int K = p.net[0].n_inp;            // nbanks * 11
+        const float normc = p.normc;
+        const int n_rows = p.n_rows;
+        float *const dbg_in0 = p.dbg_in0, *const dbg_in1 = p.dbg_in1;
         const int g = lane >> 4, c = lane & 15;
         float basis[4];
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
         for (int f = 0; f < FT; f++) {
             const int i = 16 * f + c;            // this lane's frame as an A-operand row
-            rr[f] = min(r0 + i, p.n_rows - 1) - kShift;
+            rr[f] = min(r0 + i, n_rows - 1) - kShift;
             lo[f] = rowlo[i];
             hi[f] = rowhi[i];
         }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             const int n = it / nb, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (FT * nkq1 * 256);
-            float *dbg = n == 0 ? p.dbg_in0 : p.dbg_in1;
+            float *dbg = n == 0 ? dbg_in0 : dbg_in1;
             // all eight operand values first (independent LDS reads), then the eight MFMAs
             float xw[FT][4];
 #pragma unroll
@@ -188,8 +191,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
                         const int fr = 16 * f + 4 * g + reg;
-                        const float val = acc[f][reg] * p.normc;         // CalcC0 / sDCT scaling
-                        if (dbg && r0 + fr < p.n_rows) dbg[(size_t)(r0 + fr) * K + k] = val;
+                        const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
+                        if (dbg && r0 + fr < n_rows) dbg[(size_t)(r0 + fr) * K + k] = val;
                         float v = val - mk;                              // Normalize nn.cpp:702-716
                         v *= dk;
                         img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
@@ -207,14 +210,18 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const NetDev &nm = p.net[2];
     const float *mmean = nrm_merger, *mdev = nrm_merger + 16 * nkqm;
     {
-        const int O0 = p.net[0].n_out;
+        // kernel arguments used per value live in locals: fields of `p` are re-read from the kernarg
+        // segment (a scalar load + wait) behind every memory fence and barrier
+        const int O0 = p.net[0].n_out, O1 = p.net[1].n_out, n_rows = p.n_rows, merger_inp = nm.n_inp;
+        float *const dbg_p0 = p.dbg_p0, *const dbg_p1 = p.dbg_p1, *const dbg_g = p.dbg_g;
+        const bool probes = dbg_p0 || dbg_p1 || dbg_g;              // NULL in production
         auto epi = [&](int n, int i, int o, float q, bool valid) {
             const int kofs = n * O0;
-            float *dp = n == 0 ? p.dbg_p0 : p.dbg_p1;
             const float gl = q > 0.0f ? logf(q) : 0.0f;             // sLn dspc.h:155-160
-            if (valid && (dp || p.dbg_g) && r0 + i < p.n_rows) {
-                if (dp) dp[(size_t)(r0 + i) * p.net[n].n_out + o] = q;
-                if (p.dbg_g) p.dbg_g[(size_t)(r0 + i) * nm.n_inp + kofs + o] = gl;
+            if (probes && valid && r0 + i < n_rows) {
+                float *dp = n == 0 ? dbg_p0 : dbg_p1;
+                if (dp) dp[(size_t)(r0 + i) * (n == 0 ? O0 : O1) + o] = q;
+                if (dbg_g) dbg_g[(size_t)(r0 + i) * merger_inp + kofs + o] = gl;
             }
             float v = gl - mmean[kofs + o];                          // Normalize nn.cpp:702-716
             v *= mdev[kofs + o];
@@ -242,12 +249,17 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     {
         const int O = nm.n_out;
         float *outbuf = reinterpret_cast<float *>(slab);
-        const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
+        // the writer path's settings in locals (kernarg fields are re-read behind every fence)
+        const int f0 = p.out_func[0], f1 = p.out_func[1], be = p.out_be;
+        float c0[3], c1[3], l0[2], l1[2];
+        for (int i = 0; i < 3; i++) { c0[i] = p.out_c[0][i]; c1[i] = p.out_c[1][i]; }
+        for (int i = 0; i < 2; i++) { l0[i] = p.out_l[0][i]; l1[i] = p.out_l[1][i]; }
+        const bool transform = (f0 | f1 | be) != 0;
         auto epi = [&](int, int i, int o, float q, bool valid) {
             if (transform) {                     // posterior writer path: softening, byte order
-                q = soften(p.out_func[0], p.out_c[0], p.out_l[0], q);
-                q = soften(p.out_func[1], p.out_c[1], p.out_l[1], q);
-                if (p.out_be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
+                q = soften(f0, c0, l0, q);
+                q = soften(f1, c1, l1, q);
+                if (be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
             }
             if (valid) outbuf[i * O + o] = q;
         };
