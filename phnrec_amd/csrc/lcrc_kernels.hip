@@ -12,9 +12,11 @@
 //
 // Geometry.  A workgroup owns 16*FT consecutive frames (FT = 2 16-frame MFMA column
 // tiles when the launch fills the GPU that way, FT = 1 for smaller launches) and
-// runs the three nets one after the other; its NW = 4 waves (one per SIMD) split
-// the HIDDEN dimension of each net.  Both products are computed transposed so
-// that no data has to change lanes between them:
+// has NW = 4 waves, one per SIMD, which split the HIDDEN dimension of a net: first
+// the two band classifiers side by side (waves 0,1: left context, waves 2,3: right
+// context -- they have the same shape and do not depend on each other), then the
+// merger on all four.  Both products are computed transposed so that no data has
+// to change lanes between them:
 //   layer 1:  S^T[16 hidden x 16 frames] = W1[16 x K] . X^T          A = W1 fragment (HBM/L2, pre-packed)
 //                                                                    B = X fragment  (LDS)
 //   layer 2:  O^T[16 out x 16 frames]   += W2[16 x 16] . sig(S^T)     A = W2 fragment (HBM/L2, pre-packed)
@@ -24,10 +26,11 @@
 // `reg`; so sig(S^T) feeds layer 2 from registers.  Hidden activations (M x 1500
 // floats per net) therefore never exist in LDS or HBM.  Weights are streamed
 // from L2/Infinity Cache as whole 1-KiB wave loads (host pre-packs them in
-// fragment order), prefetched one hidden tile ahead.  At the end of a net the
-// NW partial O^T tiles are folded through LDS, softmax runs on all threads,
-// and the result becomes the next net's B image (band nets) or is stored to HBM
-// as whole contiguous rows (merger).
+// fragment order) through a ring of registers (mlp_dev.h: RingLoop).  At the end
+// of a net its waves' partial O^T tiles meet in LDS (two per net are added while the
+// softmax reads them; four are first folded to two), softmax runs on all threads,
+// and the result becomes the merger's B image (band nets) or is stored to HBM as
+// whole contiguous rows (merger).
 //
 // Arithmetic contract (tests/: <= 1e-4 max-abs per frame vs the reference):
 //   * exp is the reference's FEXP bit trick, bit-emulated (fexp.h:14-21), incl.
