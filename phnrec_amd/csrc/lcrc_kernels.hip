@@ -103,29 +103,62 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             rowhi[tid] = p.off[lo + 1] - 1;
         }
     }
-    for (int i = tid; i < kTileRows * nb; i += NT) {
-        const int row = tbase + i / nb;
-        melT[i] = (row >= 0 && row < p.n_rows) ? p.mel[(long)tbase * nb + i] : 0.0f;
-    }
-    for (int i = tid; i < 10 * 16 + 2 * 16; i += NT)
-        costab[i] = i < 160 ? p.costab[i] : p.win[i - 160];
     {
-        const int w1n = 16 * nkq1, wmn = 16 * nkqm;
-        for (int i = tid; i < w1n; i += NT) {
-            nrm_band[i] = p.net[0].mean[i];
-            nrm_band[w1n + i] = p.net[0].dev[i];
-            nrm_band[2 * w1n + i] = p.net[1].mean[i];
-            nrm_band[3 * w1n + i] = p.net[1].dev[i];
+        // Every global value a thread stages is REQUESTED first (unconditional loads, clamped indices, static
+        // trip counts), the operand images are zeroed while the requests travel, then the values are stored:
+        // one L2 round trip for the stage instead of one per loop.
+        constexpr int kMaxBanks = 23, kMaxW1 = 16 * 16, kMaxWm = 16 * 26;      // the variants' upper bounds
+        constexpr int MPT = (kTileRows * kMaxBanks + NT - 1) / NT;             // mel values per thread
+        constexpr int WPT = (kMaxW1 + NT - 1) / NT, GPT = (kMaxWm + NT - 1) / NT;
+        const int w1n = 16 * nkq1, wmn = 16 * nkqm, ntile = kTileRows * nb;
+        const long nmel = (long)p.n_rows * nb;
+        float mv[MPT], tv, wv[WPT][4], gv[GPT][2];
+#pragma unroll
+        for (int q = 0; q < MPT; q++) {
+            const long g = (long)tbase * nb + tid + q * NT;
+            mv[q] = p.mel[max(0L, min(nmel - 1, g))];
         }
-        for (int i = tid; i < wmn; i += NT) {
-            nrm_merger[i] = p.net[2].mean[i];
-            nrm_merger[wmn + i] = p.net[2].dev[i];
+        static_assert((KS1 + 3) / 4 <= 16 && (KSM + 3) / 4 <= 26, "staging bounds");
+        const float *tsrc = tid < 160 ? p.costab + tid : p.win + (min(tid, 191) - 160);
+        tv = *tsrc;
+#pragma unroll
+        for (int q = 0; q < WPT; q++) {
+            const int i = min(tid + q * NT, w1n - 1);
+            wv[q][0] = p.net[0].mean[i]; wv[q][1] = p.net[0].dev[i];
+            wv[q][2] = p.net[1].mean[i]; wv[q][3] = p.net[1].dev[i];
         }
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+            const int i = min(tid + q * NT, wmn - 1);
+            gv[q][0] = p.net[2].mean[i]; gv[q][1] = p.net[2].dev[i];
+        }
+        LCRC_FENCE();
         const f4 zero = {0.f, 0.f, 0.f, 0.f};             // pads of the operand images must be zeros
         f4 *zx = reinterpret_cast<f4 *>(xf), *zg = reinterpret_cast<f4 *>(gf);
         const int nx = 2 * FT * nkq1 * 64, ng = FT * nkqm * 64;
         for (int i = tid; i < nx; i += NT) zx[i] = zero;
         for (int i = tid; i < ng; i += NT) zg[i] = zero;
+        LCRC_FENCE();
+#pragma unroll
+        for (int q = 0; q < MPT; q++) {
+            const int i = tid + q * NT;
+            const int row = tbase + i / nb;
+            if (i < ntile) melT[i] = (row >= 0 && row < p.n_rows) ? mv[q] : 0.0f;
+        }
+        if (tid < 10 * 16 + 2 * 16) costab[tid] = tv;
+#pragma unroll
+        for (int q = 0; q < WPT; q++) {
+            const int i = tid + q * NT;
+            if (i < w1n) {
+                nrm_band[i] = wv[q][0]; nrm_band[w1n + i] = wv[q][1];
+                nrm_band[2 * w1n + i] = wv[q][2]; nrm_band[3 * w1n + i] = wv[q][3];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GPT; q++) {
+            const int i = tid + q * NT;
+            if (i < wmn) { nrm_merger[i] = gv[q][0]; nrm_merger[wmn + i] = gv[q][1]; }
+        }
     }
     __syncthreads();
 
