@@ -263,20 +263,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             v *= mdev[kofs + o];
             if (valid) xf_store(gf, nkqm, i, kofs + o, v);
         };
-#ifndef LCRC_BAND_PAIR
-#define LCRC_BAND_PAIR 1
-#endif
-#if LCRC_BAND_PAIR
+        // (the sequential alternative -- one band net after the other on four waves -- was 1.6-3 % slower in
+        //  same-GPU A/B runs, profiles/r01_ab_runs.txt)
         run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
                                             reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
-#else       // A/B switch (tools/ab_kernel.py): the two band nets one after the other on all four waves
-#pragma unroll 1
-        for (int n = 0; n < 2; n++) {
-            auto epi1 = [&](int, int i, int o, float q, bool valid) { epi(n, i, o, q, valid); };
-            run_net<KS1, NOT, NW, EXACT, FT, 1>(p, 2, p.net + n, reinterpret_cast<const f4 *>(xf) + (size_t)n * (FT * nkq1 * 64),
-                                                0, slab, slab, n_ot, lane, wave, epi1);
-        }
-#endif
         LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
     }
 
@@ -299,7 +289,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
             if (valid) outbuf[i * O + o] = q;
         };
-        run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab, slab, n_ot, lane, wave, epi);
+        run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.n_rows - r0);
         const int total = rows * O;

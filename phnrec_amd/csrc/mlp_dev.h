@@ -346,8 +346,9 @@ struct RingLoop {
 // Runs GROUPS nets of the same shape class at once, each on NW / GROUPS waves (GROUPS = 1: one net on all
 // waves; GROUPS = 2: the two band classifiers of LCRC side by side on wave pairs -- one hidden loop, one
 // softmax phase and no fold round instead of two of each).  nets[g] / XF + g * xf_stride belong to group g.
-// slab01: two slabs of FT * n_ot_slab KiB; slab23: two more (GROUPS = 2 only; they may alias the nets' B
-// images and anything else that is dead once every wave has left its hidden loop).
+// slab01: two slabs of FT * n_ot_slab KiB; slab23: two more (with GROUPS = 2 they may alias the nets' B
+// images and anything else that is dead once every wave has left its hidden loop; with GROUPS = 1 they must
+// be free when the first wave leaves its loop).
 // On return `epi(group, frame, o, posterior, valid)` has been called with valid == true once for every
 // (group, frame, output) by SOME thread (calls with valid == false carry a clamped output index and must
 // not store), and a __syncthreads() has been passed.
@@ -392,12 +393,13 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
     const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
-    if constexpr (WPG == 2) {
-        // two partial tiles per net: no fold round, each wave publishes its own and the softmax adds them
-        // while it reads.  The second pair of slabs may lie over the B images: wait until every wave has
-        // left its hidden loop.
-        __syncthreads();
-        f4 *s = (grp == 0 ? slab01 : slab23) + wig * slab_f4 + lane;
+    {
+        // No fold round: every wave publishes its partial tile in a slab of its own and the softmax adds
+        // them while it reads (two per net when two nets share the waves, four otherwise).  slab23 may lie over
+        // the B images: wait until every wave has left its hidden loop before writing there.
+        if (GROUPS == 2) __syncthreads();
+        f4 *s = (GROUPS == 2 ? (grp == 0 ? slab01 : slab23) + wig * slab_f4
+                             : (wig < 2 ? slab01 : slab23) + (wig & 1) * slab_f4) + lane;
 #pragma unroll
         for (int ot = 0; ot < NOT; ot++)
             if (EXACT || ot < n_ot) {
@@ -405,36 +407,6 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
                 for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
             }
         __syncthreads();
-    } else {
-        // ---- fold the WPG partial tiles down to TWO slabs, then every thread sums the two while
-        //      it reads its softmax inputs (no single-wave phase, no dense copy) ----
-#pragma unroll
-        for (int top = WPG; top > 2; top -= 2) {     // waves [top-2, top) fold into [top-4, top-2)
-            if (wig >= top - 2 && wig < top) {
-                f4 *s = slab01 + (wig - (top - 2)) * slab_f4 + lane;
-#pragma unroll
-                for (int ot = 0; ot < NOT; ot++)
-                    if (EXACT || ot < n_ot) {
-#pragma unroll
-                        for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
-                    }
-            }
-            __syncthreads();
-            if (wig >= top - 4 && wig < top - 2) {
-                f4 *s = slab01 + (wig - (top - 4)) * slab_f4 + lane;
-                const bool last = top - 4 == 0;     // the two surviving waves publish their sums in place
-#pragma unroll
-                for (int ot = 0; ot < NOT; ot++)
-                    if (EXACT || ot < n_ot) {
-#pragma unroll
-                        for (int f = 0; f < FT; f++) {
-                            acc[ot][f] += s[(ot * FT + f) * 64];
-                            if (last) s[(ot * FT + f) * 64] = acc[ot][f];
-                        }
-                    }
-            }
-            __syncthreads();
-        }
     }
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
     // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a (net, frame) row, each
@@ -451,6 +423,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         const int frame = GROUPS == 1 ? row : row % BM;
         const float *sa = reinterpret_cast<const float *>(rg == 0 ? slab01 : slab23);
         const float *sb = sa + slab_f4 * 4;
+        const float *sc = reinterpret_cast<const float *>(slab23), *sd = sc + slab_f4 * 4;   // GROUPS == 1
         const int fbase = ((frame >> 4) * 64 + (frame & 15)) * 4;
         const int O = nets[rg].n_out;
         float v[NV];
@@ -461,7 +434,8 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
             // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
             // unconditionally so the 2*NV LDS reads are issued back to back, select afterwards
             const int idx = fbase + (o >> 4) * (256 * FT) + ((o >> 2) & 3) * 64 + (o & 3);
-            const float t = sa[idx] + sb[idx];
+            float t = sa[idx] + sb[idx];
+            if (GROUPS == 1) t += sc[idx] + sd[idx];       // waves (0 + 1) + (2 + 3): a fixed order
             v[j] = o < O ? t : -FLT_MAX;
             m = fmaxf(m, v[j]);
         }

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void traps_features_kernel(const TrapsFeatPara
     }
 }
 
-// LDS: [mean | dev] (2 * 16 * nkq floats), B image [nkq][64] float4, two slabs [n_ot][64] float4
+// LDS: [mean | dev] (2 * 16 * nkq floats), B image [nkq][64] float4, four slabs [n_ot][64] float4
 __host__ __device__ inline unsigned mlp_lds_bytes(int nkq, int n_ot)
 {
-    return 2u * 16u * nkq * 4u + (unsigned)nkq * 1024u + 2u * (unsigned)n_ot * 1024u;
+    return 2u * 16u * nkq * 4u + (unsigned)nkq * 1024u + 4u * (unsigned)n_ot * 1024u;
 }
 
 template <int KS, int NOT, int NW>
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         }
         if (valid) outbuf[i * O + o] = q;
     };
-    run_net<KS, NOT, NW, false, 1, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab, n_ot, lane, wave, epi);
+    run_net<KS, NOT, NW, false, 1, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab + 2 * n_ot * 64, n_ot,
+                                      lane, wave, epi);
     const int rows = min(BM, p.n_rows - r0);
     for (int idx = tid; idx < rows * O; idx += NT) {
         const int i = idx / O, o = idx - i * O;
