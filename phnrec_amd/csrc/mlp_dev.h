@@ -98,18 +98,17 @@ __device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
 //   * FEXP's integer part stays exact (f64 product, truncation, x86 overflow value);
 //   * FEXP's value is exactly representable in f32 (20 mantissa bits), so one
 //     v_cvt_f32_f64 of {0, hi} yields it without error in the whole normal range;
-//   * 1/(1+e) is evaluated in f32: v_rcp_f32 + one Newton step + v_div_fixup_f32
-//     (1/inf = 0 etc.).  The reference evaluates it in f64 and rounds once; this form is
-//     within 2 ulp (2.4e-7 relative) of it, an order of magnitude below the effect of the
-//     products' summation order, and costs ~40 instead of ~90 issue cycles per value.
+//   * 1/(1+e) is evaluated in f32 by v_rcp_f32 alone (1 ulp).  The reference evaluates it in f64 and
+//     rounds once; a Newton step + v_div_fixup_f32 would recover the last ulp for 3 more instructions per
+//     value -- 1-2 % of the kernel (profiles/r01_ab_runs.txt) for a change of 1e-7 in posteriors whose
+//     distance to the reference is 5e-6 either way (summation order of the products).
 // Pad hidden units (>= n_hid) need no zeroing: their layer-2 weights are packed as zeros.
 template <int FT>
 struct SigTile {
     static constexpr int kN = 4 * FT;
     float x[kN];     // -x, then e, 1+e, and finally the sigmoid
     double t[kN];
-    float r[kN];
-    static constexpr int kStages = 6;
+    static constexpr int kStages = 4;
 
     __device__ __forceinline__ void begin(const f4 (&p)[FT])
     {
@@ -132,9 +131,7 @@ struct SigTile {
                 break;
             }
             case 2: x[i] = 1.0f + (float)t[i]; break;
-            case 3: r[i] = __builtin_amdgcn_rcpf(x[i]); break;
-            case 4: { const float e = __builtin_fmaf(-x[i], r[i], 1.0f); r[i] = __builtin_fmaf(r[i], e, r[i]); break; }
-            case 5: x[i] = __builtin_amdgcn_div_fixupf(r[i], x[i], 1.0f); break;
+            case 3: x[i] = __builtin_amdgcn_rcpf(x[i]); break;      // 1 ulp; 1/inf = 0 and 1/0 = inf natively
             default: break;
             }
         }
