@@ -193,23 +193,34 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             hi[f] = rowhi[i];
         }
         const int cc = min(c, kNCoef - 1);       // loads below stay unconditional (clamped index)
+        // The clamped source rows of a lane's taps depend on the half context (n) only, not on the band:
+        // their tile offsets and the window values are formed once, an item adds its band.
+        int roff[2][FT][4];
+        float wv[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int tap = 4 * s4 + g;
+                wv[n][s4] = win[n * kHalf + tap];
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    const int srow = max(lo[f], min(hi[f], rr[f] + n * kShift + tap));
+                    roff[n][f][s4] = (srow - tbase) * nb;
+                }
+            }
         for (int it = wave; it < items; it += NW) {
-            const int n = it / nb, b = it - n * nb;
+            const int n = it >= nb ? 1 : 0, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (FT * nkq1 * 256);
             float *dbg = n == 0 ? dbg_in0 : dbg_in1;
             // all eight operand values first (independent LDS reads), then the eight MFMAs
             float xw[FT][4];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-                const int tap = 4 * s4 + g;
-                const float w = win[n * kHalf + tap];
+            for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                for (int f = 0; f < FT; f++) {
-                    const int srow = max(lo[f], min(hi[f], rr[f] + n * kShift + tap));
-                    xw[f][s4] = melT[(srow - tbase) * nb + b] * w;
-                }
-            }
+                for (int f = 0; f < FT; f++)
+                    xw[f][s4] = melT[(n ? roff[1][f][s4] : roff[0][f][s4]) + b] * (n ? wv[1][s4] : wv[0][s4]);
             const int k = b * kNCoef + cc;
             const float mk = mean[k], dk = dev[k];
             f4 acc[FT];
@@ -226,13 +237,20 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 for (int f = 0; f < FT; f++) {
 #pragma unroll
                     for (int reg = 0; reg < 4; reg++) {
-                        const int fr = 16 * f + 4 * g + reg;
                         const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
-                        if (dbg && r0 + fr < n_rows) dbg[(size_t)(r0 + fr) * K + k] = val;
                         float v = val - mk;                              // Normalize nn.cpp:702-716
                         v *= dk;
                         img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                     }
+                }
+                if (dbg) {                       // stage probe (NULL in production): one uniform branch per item
+#pragma unroll
+                    for (int f = 0; f < FT; f++)
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int fr = 16 * f + 4 * g + reg;
+                            if (r0 + fr < n_rows) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
+                        }
                 }
             }
         }
