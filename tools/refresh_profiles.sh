@@ -6,6 +6,7 @@
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/refresh_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
