@@ -129,3 +129,25 @@ def test_no_cpu_fallback():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert not pat.search(txt), "%s reaches into oracle/: the product may not depend on it" % f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lcrc.h is the boundary a C / cgo / JNI binding would include: it must compile as C99 on its
+    own, and a C program that only takes the addresses of all entry points must link against the library"""
+    import re
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "lcrc.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                   check=True)
+    names = sorted(set(re.findall(r"\b(lcrc_[a-z_0-9]+)\s*\(", open(hdr).read())) - {"lcrc_ctx"})
+    src = tmp_path / "link.c"
+    src.write_text('#include "lcrc.h"\n#include <stdio.h>\nint main(void) {\n  const void *p[] = {%s};\n'
+                   '  printf("%%d %%d\\n", (int)(sizeof p / sizeof p[0]), lcrc_abi_version());\n  return 0;\n}\n'
+                   % ", ".join("(const void *)%s" % n for n in names))
+    exe = tmp_path / "link"
+    lib = os.path.join(ROOT, "phnrec_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", lib,
+                    "-lphnrec_lcrc", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == len(names) >= 30 and int(out[1]) >= 1
