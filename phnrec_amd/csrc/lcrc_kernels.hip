@@ -42,6 +42,8 @@
 //     order (file is compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "lcrc_dev.h"
 #include "mlp_dev.h"
 
@@ -383,13 +385,14 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     if (variant_name) *variant_name = v->name;
     if (p.n_rows <= 0) return hipSuccess;
     // > 64 KiB of dynamic LDS has to be granted per function and per device: once, not per launch
-    static bool granted[sizeof kVariants / sizeof kVariants[0]][2][64] = {};
-    static int cus[64] = {};
+    // (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
+    static std::atomic<bool> granted[sizeof kVariants / sizeof kVariants[0]][2][64] = {};
+    static std::atomic<int> cus[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const bool cached = dev >= 0 && dev < 64;
-    int n_cu = cached ? cus[dev] : 0;
+    int n_cu = cached ? cus[dev].load() : 0;
     if (n_cu == 0) {
         e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;

@@ -12,6 +12,8 @@
 //                           posterior writer path's softening / byte order.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "lcrc_dev.h"
 #include "mlp_dev.h"
 
@@ -146,7 +148,7 @@ hipError_t mlp_launch(const MlpParams &p, hipStream_t stream)
     if (p.n_rows <= 0) return hipSuccess;
     constexpr int NW = 4;
     const void *fn = reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW>);
-    static bool granted[64] = {};
+    static std::atomic<bool> granted[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
