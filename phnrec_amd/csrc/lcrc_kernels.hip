@@ -211,18 +211,25 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                     roff[n][f][s4] = (srow - tbase) * nb;
                 }
             }
+        // The operand values of item i + NW are read (independent LDS gathers) before the MFMAs of item i:
+        // the compiler cannot move LDS reads above the previous item's operand-image stores by itself.
+        auto gather = [&](int it, float (&x)[FT][4]) {
+            const int itc = min(it, items - 1);
+            const int n = itc >= nb ? 1 : 0, b = itc - n * nb;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                for (int f = 0; f < FT; f++)
+                    x[f][s4] = melT[(n ? roff[1][f][s4] : roff[0][f][s4]) + b] * (n ? wv[1][s4] : wv[0][s4]);
+        };
+        float xw[FT][4], xn[FT][4];
+        gather(wave, xw);
         for (int it = wave; it < items; it += NW) {
             const int n = it >= nb ? 1 : 0, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (FT * nkq1 * 256);
             float *dbg = n == 0 ? dbg_in0 : dbg_in1;
-            // all eight operand values first (independent LDS reads), then the eight MFMAs
-            float xw[FT][4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                for (int f = 0; f < FT; f++)
-                    xw[f][s4] = melT[(n ? roff[1][f][s4] : roff[0][f][s4]) + b] * (n ? wv[1][s4] : wv[0][s4]);
+            gather(it + NW, xn);
             const int k = b * kNCoef + cc;
             const float mk = mean[k], dk = dev[k];
             f4 acc[FT];
@@ -255,6 +262,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                         }
                 }
             }
+#pragma unroll
+            for (int f = 0; f < FT; f++)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) xw[f][s4] = xn[f][s4];
         }
     }
     __syncthreads();
