@@ -231,7 +231,11 @@ def main():
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                              "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                             "flop_per_frame": flops_frame},
+                             "flop_per_frame": flops_frame,
+                             # secondary figure: HBM-side bytes (PMC, per launch) over the live kernel time,
+                             # against the ~8 TB/s HBM3E peak -- the kernel is nowhere near memory-bound
+                             "hbm_gbps": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
+                             "hbm_frac_of_8TBps": (round(traffic / (kernel_ms * 1e-3) / 8e12, 4) if traffic else None)},
             }
             if ranks.world == 1:
                 # the host-pointer entry point (pageable buffers in, pageable out): PCIe-inclusive,
