@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r01}
 OUT=gpurun_out/refresh_$TAG
-rm -rf $OUT
+rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
