@@ -347,8 +347,9 @@ struct RingLoop {
 // images and anything else that is dead once every wave has left its hidden loop; with GROUPS = 1 they must
 // be free when the first wave leaves its loop).
 // On return `epi(group, frame, o, posterior, valid)` has been called with valid == true once for every
-// (group, frame, output) by SOME thread (calls with valid == false carry a clamped output index and must
-// not store), and a __syncthreads() has been passed.
+// (group, frame, output) by SOME thread (calls with valid == false carry a pad output index o in
+// [n_out, 16 * n_ot): they may load from arrays padded to the output tiles but must not store), and a
+// __syncthreads() has been passed.
 template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, typename Params, typename Epi>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
@@ -421,7 +422,10 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         const float *sa = reinterpret_cast<const float *>(rg == 0 ? slab01 : slab23);
         const float *sb = sa + slab_f4 * 4;
         const float *sc = reinterpret_cast<const float *>(slab23), *sd = sc + slab_f4 * 4;   // GROUPS == 1
-        const int fbase = ((frame >> 4) * 64 + (frame & 15)) * 4;
+        // o = part + LPF*j: because LPF is a multiple of 4 and part < LPF <= 16, the slab index of o splits
+        // into a per-thread part and a COMPILE-TIME part of j (no carries between the bit fields), so the
+        // reads below are base + immediate offset
+        const int pbase = ((frame >> 4) * 64 + (frame & 15)) * 4 + ((part >> 2) & 3) * 64 + (part & 3);
         const int O = nets[rg].n_out;
         float v[NV];
         float m = -FLT_MAX;
@@ -429,8 +433,8 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
             // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
-            // unconditionally so the 2*NV LDS reads are issued back to back, select afterwards
-            const int idx = fbase + (o >> 4) * (256 * FT) + ((o >> 2) & 3) * 64 + (o & 3);
+            // unconditionally so the LDS reads are issued back to back, select afterwards
+            const int idx = pbase + ((LPF * j) >> 4) * (256 * FT) + (((LPF * j) >> 2) & 3) * 64;
             float t = sa[idx] + sb[idx];
             if (GROUPS == 1) t += sc[idx] + sd[idx];       // waves (0 + 1) + (2 + 3): a fixed order
             v[j] = o < O ? t : -FLT_MAX;
@@ -463,7 +467,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
 #pragma unroll
         for (int j = 0; j < NV; j++) {
             const int o = part + LPF * j;
-            epi(rg, frame, min(o, O - 1), v[j] * scale, o < O);   // loads inside stay unconditional
+            epi(rg, frame, o, v[j] * scale, o < O);   // o may be a pad output (>= O): loads only, no store
         }
     }
     __syncthreads();
