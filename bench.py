@@ -65,6 +65,16 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def reference_scaling(mdir, nbanks, seconds):
     """The reference code in its sgemm regime (bunch_size=512), on one core and on every usable core
     (one process per core, each on its own utterance: the reference is not thread-safe)."""
@@ -138,9 +148,12 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
             "parity_max_abs_vs_gpu": float(np.abs(p1 - gpu_post[:n1]).max()),
             "all_cores": {"value": round(nall / dta, 1), "cores": cores, "cores_visible": os.cpu_count(),
                           "sample": "%d frames, %.1f s" % (nall, dta)}}
+    host = {"cpu_model": cpu_model(), "cores_visible": os.cpu_count(), "cores_usable": cores}
     if out is None:
+        port["host"] = host
         return port
     out["port"] = port
+    out["host"] = host
     return out
 
 
