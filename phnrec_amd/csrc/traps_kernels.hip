@@ -147,15 +147,20 @@ hipError_t mlp_launch(const MlpParams &p, hipStream_t stream)
     if (!mlp_supports(p.net)) return hipErrorInvalidValue;
     if (p.n_rows <= 0) return hipSuccess;
     constexpr int NW = 4;
-    const void *fn = reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW>);
-    static std::atomic<bool> granted[64] = {};
+    // three size classes of the same kernel (k-steps, output tiles): the loops are unrolled over the class's
+    // maxima, so a small net in a large class would step over mostly empty entries
+    const int cls = (p.net.ksteps <= 8 && p.net.n_ot <= 4) ? 0 : (p.net.ksteps <= 64 ? 1 : 2);
+    const void *fn = cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW>)
+                   : cls == 1 ? reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW>)
+                              : reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW>);
+    static std::atomic<bool> granted[3][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !granted[dev]) {
+    if (dev < 0 || dev >= 64 || !granted[cls][dev]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) granted[dev] = true;
+        if (dev >= 0 && dev < 64) granted[cls][dev] = true;
     }
     MlpParams args = p;
     void *kargs[] = {&args};

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Timing of the non-LCRC `posteriors/system` variants (feature kernel + MLP kernels) on seeded synthetic
+models, 8192 frames resident in HBM.  Run under `rocprofv3 --kernel-trace --stats` for per-kernel times."""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from phnrec_amd import capi, modelgen  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    capi.load()
+    for system, kw in (("1BT_DCT", dict(coefs=11)), ("1BT", dict(band_out=24, band_hidden=100))):
+        with tempfile.TemporaryDirectory() as d:
+            modelgen.write_traps_dir(d, system, 15, 1500, 138, seed=5, **kw)
+            ctx = capi.Lcrc(d, 15, system=system)
+            mel = torch.from_numpy(modelgen.synth_mel(n, 15, seed=1)).cuda()
+            post = torch.empty((n, ctx.n_out), device="cuda")
+            s = torch.cuda.current_stream()
+            ctx.set_timing(False)
+            for _ in range(5):
+                ctx.posteriors_device(mel.data_ptr(), n, post.data_ptr(), stream=s.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(20):
+                ctx.posteriors_device(mel.data_ptr(), n, post.data_ptr(), stream=s.cuda_stream)
+            e1.record(s)
+            s.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            dims = [ctx.net_dims(i) for i in range((0 if system == "1BT_DCT" else 15) + 1)]
+            flop = sum(2 * (a * b + b * c) for a, b, c in dims)
+            print("%-8s %d frames: %.3f ms per batch = %.2f M frames/s; nets %s ...; %.1f TFLOP/s algorithmic = %.0f %% of f32 MFMA peak"
+                  % (system, n, ms, n / ms / 1e3, dims[-1], n * flop / (ms * 1e-3) / 1e12, 100 * n * flop / (ms * 1e-3) / 157.3e12))
+            ctx.close()
+
+
+if __name__ == "__main__":
+    main()
