@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,9 @@ struct lcrc_ctx {
     int system = SYS_LCRC, trap_bands = 0, shift = 0;
     bool use_hamming = false, add_c0 = true;
     std::vector<NetDev> band_nets;       // 1BT / 3BT: trap_bands nets of 31 inputs
+    const NetDev *d_band_nets = nullptr; // the same on the device (one launch runs them all)
+    const int *d_band_col = nullptr;     // first merger-input column of each band net
+    NetDev band_max = {};                // maxima of ksteps / nkq / n_ot over the band nets
     float *d_hamm31 = nullptr, *d_costab31 = nullptr;
     float normc31 = 0.f;
     float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
@@ -238,15 +242,13 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     m.n_rows = n_rows;
     const float *merger_in = c->d_feat;
     if (c->system != SYS_1BT_DCT) {
-        size_t col = 0;
-        for (int b = 0; b < c->trap_bands; b++) {
-            m.net = c->band_nets[b];
-            m.in = c->d_feat + (size_t)b * n_rows * kTrapLen; m.in_ld = kTrapLen;
-            m.out = c->d_minp + col; m.out_ld = (long)Km;
-            m.neg_log = 1;
-            HIP_TRY(c, mlp_launch(m, s));
-            col += c->band_nets[b].n_out;
-        }
+        m.net = c->band_max;                 // one launch, grid.y = band
+        m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = c->trap_bands;
+        m.in = c->d_feat; m.in_ld = kTrapLen; m.in_net_stride = (long)n_rows * kTrapLen;
+        m.out = c->d_minp; m.out_ld = (long)Km;
+        m.neg_log = 1;
+        HIP_TRY(c, mlp_launch(m, s));
+        m.nets_dev = nullptr; m.out_col = nullptr; m.n_nets = 0;
         merger_in = c->d_minp;
     }
     m.net = c->nets[2];
@@ -594,6 +596,22 @@ int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system
         int rc = pack_net(c, band[i], c->band_nets[i]);
         if (rc) return bail(rc);
         if (!mlp_supports(c->band_nets[i])) { c->err = "band classifier too large (<= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
+    }
+    if (!c->band_nets.empty()) {
+        std::vector<int> col(c->band_nets.size());
+        int acc_col = 0;
+        c->band_max = c->band_nets[0];
+        for (size_t i = 0; i < c->band_nets.size(); i++) {
+            col[i] = acc_col;
+            acc_col += c->band_nets[i].n_out;
+            c->band_max.ksteps = std::max(c->band_max.ksteps, c->band_nets[i].ksteps);
+            c->band_max.nkq = std::max(c->band_max.nkq, c->band_nets[i].nkq);
+            c->band_max.n_ot = std::max(c->band_max.n_ot, c->band_nets[i].n_ot);
+        }
+        if (dev_upload(c, c->band_nets, &c->d_band_nets) != hipSuccess || dev_upload(c, col, &c->d_band_col) != hipSuccess) {
+            c->err = "upload failed";
+            return bail(LCRC_E_DEVICE);
+        }
     }
     c->host[2] = merger;
     {

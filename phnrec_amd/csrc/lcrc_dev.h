@@ -112,6 +112,12 @@ struct MlpParams {
     float *out;          // row r at out + r*out_ld (n_out values)
     long in_ld, out_ld;
     int n_rows;
+    // Many nets of one size class in ONE launch (grid.y = net; the band classifiers of 1BT / 3BT): net y is
+    // nets_dev[y], reads in + y*in_net_stride and writes out + out_col[y]; lds_nkq / lds_n_ot = maxima over y
+    const NetDev *nets_dev;     // NULL: the single net above
+    const int *out_col;
+    long in_net_stride;
+    int n_nets, lds_nkq, lds_n_ot;
     int neg_log;         // 1: store -(x > 0 ? ln x : 0)   (sLn + sMultiplication(-1), traps.cpp:424-425)
     int out_func[2];     // else: softening stages / byte order of lcrc_output_configure
     float out_c[2][4];

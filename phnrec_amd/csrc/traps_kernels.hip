@@ -74,14 +74,38 @@ __host__ __device__ inline unsigned mlp_lds_bytes(int nkq, int n_ot)
     return 2u * 16u * nkq * 4u + (unsigned)nkq * 1024u + 4u * (unsigned)n_ot * 1024u;
 }
 
-template <int KS, int NOT, int NW>
+// A NetDev read from device memory at a wave-uniform address, moved into SGPRs field by field: the weight
+// pointers must be scalar for the hidden loop's scalar-base addressing.
+template <typename T>
+__device__ __forceinline__ T uniform_ptr(T v)
+{
+    const unsigned long long u = reinterpret_cast<unsigned long long>(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<T>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ NetDev uniform_net(const NetDev *g)
+{
+    NetDev n = *g;
+    n.w1p = uniform_ptr(n.w1p); n.w2p = uniform_ptr(n.w2p);
+    n.b1 = uniform_ptr(n.b1); n.b2 = uniform_ptr(n.b2); n.mean = uniform_ptr(n.mean); n.dev = uniform_ptr(n.dev);
+    n.n_inp = __builtin_amdgcn_readfirstlane(n.n_inp); n.n_hid = __builtin_amdgcn_readfirstlane(n.n_hid);
+    n.n_out = __builtin_amdgcn_readfirstlane(n.n_out); n.ksteps = __builtin_amdgcn_readfirstlane(n.ksteps);
+    n.nkq = __builtin_amdgcn_readfirstlane(n.nkq); n.nht = __builtin_amdgcn_readfirstlane(n.nht);
+    n.n_ot = __builtin_amdgcn_readfirstlane(n.n_ot);
+    return n;
+}
+
+template <int KS, int NOT, int NW, bool BATCHED>
 __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = NW * 64, BM = 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const NetDev &nd = p.net;
+    const NetDev nd = BATCHED ? uniform_net(p.nets_dev + blockIdx.y) : p.net;
+    const float *const in = BATCHED ? p.in + (size_t)blockIdx.y * p.in_net_stride : p.in;
+    float *const out = BATCHED ? p.out + __builtin_amdgcn_readfirstlane(p.out_col[blockIdx.y]) : p.out;
     const int nkq = nd.nkq, n_ot = nd.n_ot, K = nd.n_inp, O = nd.n_out;
     float *nrm = reinterpret_cast<float *>(smem);
     float *xf = nrm + 2 * 16 * nkq;
@@ -101,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     for (int idx = tid; idx < BM * K; idx += NT) {
         const int i = idx / K, k = idx - i * K;
         const int r = r0 + i;
-        float v = r < p.n_rows ? p.in[(size_t)r * p.in_ld + k] : 0.0f;
+        float v = r < p.n_rows ? in[(size_t)r * p.in_ld + k] : 0.0f;
         v = v - nrm[k];                                      // Normalize nn.cpp:702-716
         v *= nrm[16 * nkq + k];
         xf_store(xf, nkq, i, k, v);
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     const int rows = min(BM, p.n_rows - r0);
     for (int idx = tid; idx < rows * O; idx += NT) {
         const int i = idx / O, o = idx - i * O;
-        p.out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[idx];
+        out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[idx];
     }
 }
 
@@ -144,27 +168,33 @@ hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream)
 
 hipError_t mlp_launch(const MlpParams &p, hipStream_t stream)
 {
+    // batched form: the caller vouches for every net (mlp_supports) and passes the maxima in net.{ksteps,nkq,n_ot}
     if (!mlp_supports(p.net)) return hipErrorInvalidValue;
-    if (p.n_rows <= 0) return hipSuccess;
+    if (p.n_rows <= 0 || (p.nets_dev && p.n_nets <= 0)) return hipSuccess;
     constexpr int NW = 4;
-    // three size classes of the same kernel (k-steps, output tiles): the loops are unrolled over the class's
+    // four size classes of the same kernel (k-steps, output tiles): the loops are unrolled over the class's
     // maxima, so a small net in a large class would step over mostly empty entries
-    const int cls = (p.net.ksteps <= 8 && p.net.n_ot <= 4) ? 0 : (p.net.ksteps <= 64 ? 1 : 2);
-    const void *fn = cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW>)
-                   : cls == 1 ? reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW>)
-                              : reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW>);
-    static std::atomic<bool> granted[3][64] = {};
+    const int cls = (p.net.ksteps <= 8 && p.net.n_ot <= 4) ? 0 : p.net.ksteps <= 64 ? 1 : p.net.ksteps <= 128 ? 2 : 3;
+    const bool batched = p.nets_dev != nullptr;
+    const void *fn = batched ? (cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW, true>)
+                                         : reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW, true>))
+                   : cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW, false>)
+                   : cls == 1 ? reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW, false>)
+                   : cls == 2 ? reinterpret_cast<const void *>(&mlp_kernel<128, kMlpNOT, NW, false>)
+                              : reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW, false>);
+    if (batched && cls >= 2) return hipErrorInvalidValue;    // band classifiers take 31 inputs
+    static std::atomic<bool> granted[2][4][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !granted[cls][dev]) {
+    if (dev < 0 || dev >= 64 || !granted[batched][cls][dev]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) granted[cls][dev] = true;
+        if (dev >= 0 && dev < 64) granted[batched][cls][dev] = true;
     }
     MlpParams args = p;
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((p.n_rows + 15) / 16), dim3(NW * 64), kargs,
+    return hipLaunchKernel(fn, dim3((p.n_rows + 15) / 16, p.nets_dev ? p.n_nets : 1), dim3(NW * 64), kargs,
                            mlp_lds_bytes(p.net.nkq, p.net.n_ot), stream);
 }
 
