@@ -1024,7 +1024,11 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
     if (needed) {
         HIP_TRY(c, hipSetDevice(c->device));
         std::vector<float> out((H + n) * O);
+        // (the streaming form never decodes: a chunk is not an utterance)
+        const int dec_P = c->dec_P;
+        c->dec_P = 0;
         int rc = run_host(c, strip.data(), nullptr, 1, (int)(H + n), out.data(), nullptr);
+        c->dec_P = dec_P;
         if (rc) return rc;
         memcpy(post, out.data() + (size_t)kShift * O, (size_t)n * O * sizeof(float));
     }
