@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Randomised parity run (dev tool, GPU): 60 random LCRC model shapes (1-23 banks, hidden 1-399, 2-208 outputs,
+independent merger hidden size) on ragged batches, 16- and 32-frame workgroups, each against the oracle at the
+1e-4 bar.  usage: fuzz_parity.py [seed]"""
+import os, sys, tempfile, numpy as np
+sys.path.insert(0, os.getcwd())
+from phnrec_amd import capi, modelgen
+from oracle import binding as ob
+capi.load()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+worst = 0.0
+for it in range(60):
+    nb = int(rng.integers(1, 24))
+    hid = int(rng.integers(1, 400))
+    nout = int(rng.integers(2, 209))
+    hm = int(rng.integers(1, 400))
+    with tempfile.TemporaryDirectory() as d:
+        modelgen.write_model_dir(d, nb, hid, nout, seed=int(rng.integers(1 << 30)), hidden_merger=hm)
+        try:
+            ctx = capi.Lcrc(d, nb)
+        except capi.LcrcError as e:
+            print("skip", nb, hid, nout, hm, str(e)[:60]); continue
+        o = ob.Oracle(d, nb)
+        lens = [int(v) for v in rng.integers(0, 120, size=int(rng.integers(1, 7)))]
+        if sum(lens) == 0: lens.append(5)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), nb, seed=it, mean_norm=bool(it & 1))
+        want = o.posteriors_batch(mel, off)
+        for fr in (16, 32):
+            ctx.set_tile_frames(fr)
+            got = ctx.posteriors_batch(mel, off)
+            err = float(np.abs(got - want).max())
+            worst = max(worst, err)
+            assert err < 1e-4, (nb, hid, nout, hm, fr, err)
+        ctx.close()
+print("fuzz ok, worst max-abs", worst)
