@@ -288,8 +288,12 @@ bool SpeechRec::EnsureGpus()
     if (!gpus_.empty()) return true;
     int n = n_gpus_;
     if (n <= 0) n = 1;
-    for (int k = 0; k < 2 * n; k++) {              // two contexts per GPU: one stages / decodes while
-        const int d = k / 2;                       // the other's launch is in flight
+    // several contexts per GPU: while one's launch is in flight the others stage / decode / write
+    // (PHNREC_CTX_PER_GPU overrides the default for experiments)
+    int per_gpu = 2;
+    if (const char *e = getenv("PHNREC_CTX_PER_GPU")) per_gpu = std::max(1, std::min(8, atoi(e)));
+    for (int k = 0; k < per_gpu * n; k++) {
+        const int d = k / per_gpu;
         std::unique_ptr<Traps> t(new Traps);
         t->SetSystem(C.GetString("posteriors", "system").c_str());
         t->SetTrapLen(C.GetInt("posteriors", "length"));

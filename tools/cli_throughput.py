@@ -49,6 +49,8 @@ def main():
         except OSError:
             pass
         env = dict(os.environ, PHNREC_STATS="1")
+        if len(sys.argv) > 3:
+            env["PHNREC_CTX_PER_GPU"] = sys.argv[3]
         for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
                              (["-F", "-D", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end + decoder (-F -D)"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
