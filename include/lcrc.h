@@ -161,6 +161,13 @@ int lcrc_wave_to_mel(lcrc_ctx *ctx, const unsigned char *bytes, const long long 
                      float *mel, int *frame_off);
 int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const long long *byte_off,
                             int n_utts, float *post, int *frame_off);
+/* Zero-copy variant: lcrc_wave_stage_buffer returns the context's pinned byte buffer (valid until a later
+ * call asks for more capacity); the caller reads its files straight into it -- utterance u at start[u]
+ * (ascending, not overlapping, even for lin16), n_bytes[u] long -- and lcrc_wave_stage_run does what
+ * lcrc_wave_to_posteriors does without copying the bytes again. */
+int lcrc_wave_stage_buffer(lcrc_ctx *ctx, long long capacity, unsigned char **bytes);
+int lcrc_wave_stage_run(lcrc_ctx *ctx, const long long *start, const long long *n_bytes, int n_utts,
+                        float *post, int *frame_off);
 
 /* ---- posterior writer path ("next" row f2) ---------------------------------------------
  * The softening functions SpeechRec applies to every posterior after the nets

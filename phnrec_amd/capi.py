@@ -19,6 +19,7 @@ SYMBOLS = [
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
+    "lcrc_wave_stage_buffer", "lcrc_wave_stage_run",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_kernel_name",
@@ -133,6 +134,8 @@ def load():
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
     L.lcrc_wave_to_mel.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
     L.lcrc_wave_to_posteriors.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
+    L.lcrc_wave_stage_buffer.argtypes = [vp, C.c_longlong, C.POINTER(C.POINTER(C.c_ubyte))]
+    L.lcrc_wave_stage_run.argtypes = [vp, _i64p, _i64p, C.c_int, _f32p, _i32p]
     L.lcrc_model_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t,
                                   C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -282,6 +285,24 @@ class Lcrc:
 
     def wave_to_posteriors(self, blobs):
         return self._wave(self.L.lcrc_wave_to_posteriors, blobs, self.n_out)
+
+    def wave_to_posteriors_staged(self, blobs):
+        """lcrc_wave_stage_buffer / lcrc_wave_stage_run: the files are written straight into the pinned buffer"""
+        blobs = [bytes(b) for b in blobs]
+        start, pos = [], 0
+        for b in blobs:
+            start.append(pos)
+            pos += len(b) + (len(b) & 1)
+        buf = C.POINTER(C.c_ubyte)()
+        self._check(self.L.lcrc_wave_stage_buffer(self.h, pos, C.byref(buf)))
+        for s, b in zip(start, blobs):
+            C.memmove(C.addressof(buf.contents) + s, b, len(b))
+        rows = sum(self.frontend_frames(len(b)) for b in blobs)
+        out = np.zeros((rows, self.n_out), np.float32)
+        foff = np.zeros(len(blobs) + 1, np.int32)
+        self._check(self.L.lcrc_wave_stage_run(self.h, np.array(start, np.int64), np.array([len(b) for b in blobs], np.int64),
+                                               len(blobs), out, foff))
+        return out, foff
 
     def posteriors_probe(self, mel):
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)

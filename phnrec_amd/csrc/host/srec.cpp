@@ -589,18 +589,24 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                 if (gpu_frontend_ && in == dfWaveform) {
                     // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the
                     // three nets all run on the device
-                    std::vector<unsigned char> raw;
-                    std::vector<long long> boff(1, 0);
+                    // the files go straight into the context's pinned byte buffer (copied in parallel)
+                    std::vector<long long> bstart(cnt), blen(cnt);
+                    long long pos = 0;
                     for (int k = 0; k < cnt; k++) {
-                        Job &j = jobs[first + k];
-                        raw.insert(raw.end(), j.bytes.begin(), j.bytes.end());
-                        boff.push_back((long long)raw.size());
-                        std::vector<unsigned char>().swap(j.bytes);
+                        bstart[k] = pos;
+                        blen[k] = (long long)jobs[first + k].bytes.size();
+                        pos += blen[k] + (blen[k] & 1);
                     }
+                    unsigned char *pinned = nullptr;
+                    if (!tr.WaveStageBuffer(pos, &pinned)) { errs[g] = tr.LastError(); failed = true; return; }
+                    pool_->ParallelFor(cnt, [&](int k) {
+                        Job &j = jobs[first + k];
+                        if (blen[k]) memcpy(pinned + bstart[k], j.bytes.data(), (size_t)blen[k]);
+                        std::vector<unsigned char>().swap(j.bytes);
+                    });
                     std::vector<float> post(dev_dec ? 0 : (size_t)off.back() * n_out_);
                     std::vector<int> foff(cnt + 1);
-                    raw.push_back(0);
-                    if (!tr.WaveToPosteriors(raw.data(), boff.data(), cnt, dev_dec ? nullptr : post.data(), foff.data())) {
+                    if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, dev_dec ? nullptr : post.data(), foff.data())) {
                         errs[g] = tr.LastError(); failed = true; return;
                     }
                     if (off.back() > 0) kms[g] += tr.LastKernelMs();

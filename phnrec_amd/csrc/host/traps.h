@@ -109,6 +109,19 @@ public:
     {
         return lcrc_last_labels(ctx_, labels, first, count, n_utts) == LCRC_OK;
     }
+    // zero-copy waveform staging (lcrc_wave_stage_buffer / lcrc_wave_stage_run)
+    bool WaveStageBuffer(long long capacity, unsigned char **bytes)
+    {
+        if (lcrc_wave_stage_buffer(ctx_, capacity, bytes) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    bool WaveStageRun(const long long *start, const long long *n_bytes, int n_utts, float *post, int *frame_off)
+    {
+        if (lcrc_wave_stage_run(ctx_, start, n_bytes, n_utts, post, frame_off) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

@@ -843,21 +843,9 @@ int lcrc_frontend_frames(const lcrc_ctx *c, long long n_bytes)
 
 // Shared by the two waveform entry points: stage the bytes (each utterance at an even offset),
 // run the front-end into d_mel; on return *rows = total frames.
-static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
-                        int *frame_off, int *rows)
+// Capacity of the pinned / device byte buffers of the waveform entry
+static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
 {
-    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
-    if (n_utts < 0 || (n_utts > 0 && (!bytes || !byte_off || !frame_off)) || (n_utts > 0 && byte_off[0] != 0))
-        return fail(c, LCRC_E_ARG, "waveform entry: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    long long total_bytes = 0, total_frames = 0;
-    for (int u = 0; u < n_utts; u++) {
-        const long long nb = byte_off[u + 1] - byte_off[u];
-        if (nb < 0) return fail(c, LCRC_E_ARG, "waveform entry: offsets must be non-decreasing");
-        total_bytes += nb + (nb & 1);
-        total_frames += lcrc_frontend_frames(c, nb);
-    }
-    if (total_frames > 0x7fffffffLL / 256) return fail(c, LCRC_E_ARG, "waveform entry: too many frames for one call");
     if ((size_t)total_bytes + 16 > c->cap_bytes) {
         if (c->d_bytes) { (void)hipFree(c->d_bytes); (void)hipHostFree(c->h_bytes); }
         c->d_bytes = c->h_bytes = nullptr; c->cap_bytes = 0;
@@ -866,6 +854,17 @@ static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long
         HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, hipHostMallocDefault));
         c->cap_bytes = cap;
     }
+    return LCRC_OK;
+}
+
+// The front-end over utterances that already lie in the pinned byte buffer: utterance u = bytes
+// [start[u], start[u] + len[u]) of c->h_bytes.  Leaves the features in c->d_mel.
+static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long long *len, int n_utts,
+                               long long extent, int *frame_off, int *rows)
+{
+    long long total_frames = 0;
+    for (int u = 0; u < n_utts; u++) total_frames += lcrc_frontend_frames(c, len[u]);
+    if (total_frames > 0x7fffffffLL / 256) return fail(c, LCRC_E_ARG, "waveform entry: too many frames for one call");
     if (2 * (size_t)n_utts + 2 > c->cap_fe_utts) {
         if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
         c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
@@ -878,15 +877,11 @@ static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long
         c->cap_fe_utts = cap;
     }
     const int unit = c->fe.wave_format == 1 ? 2 : 1;
-    long long pos = 0;
     c->h_foff[0] = 0;
     for (int u = 0; u < n_utts; u++) {               // h_soff: [start of u ...][sample count of u ...]
-        const long long nb = byte_off[u + 1] - byte_off[u];
-        memcpy(c->h_bytes + pos, bytes + byte_off[u], (size_t)nb);
-        c->h_soff[u] = pos / unit;
-        c->h_soff[n_utts + u] = fe_samples(c, nb);
-        c->h_foff[u + 1] = c->h_foff[u] + lcrc_frontend_frames(c, nb);
-        pos += nb + (nb & 1);                        // keep lin16 utterances 2-byte aligned
+        c->h_soff[u] = start[u] / unit;
+        c->h_soff[n_utts + u] = fe_samples(c, len[u]);
+        c->h_foff[u + 1] = c->h_foff[u] + lcrc_frontend_frames(c, len[u]);
     }
     for (int u = 0; u < n_utts; u++) frame_off[u] = c->h_foff[u];
     if (n_utts >= 0) frame_off[n_utts] = c->h_foff[n_utts];
@@ -894,7 +889,7 @@ static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long
     if (total_frames == 0) return LCRC_OK;
     int rc = ensure_staging(c, (size_t)total_frames, (size_t)n_utts);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)pos, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)extent, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_soff, c->h_soff, (size_t)(2 * n_utts) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     FrontendParams p;
@@ -908,6 +903,32 @@ static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long
     p.z_mean_source = c->fe.z_mean_source;
     HIP_TRY(c, frontend_launch(p, c->stream));
     return LCRC_OK;
+}
+
+static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                        int *frame_off, int *rows)
+{
+    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
+    if (n_utts < 0 || (n_utts > 0 && (!bytes || !byte_off || !frame_off)) || (n_utts > 0 && byte_off[0] != 0))
+        return fail(c, LCRC_E_ARG, "waveform entry: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long total_bytes = 0;
+    for (int u = 0; u < n_utts; u++) {
+        const long long nb = byte_off[u + 1] - byte_off[u];
+        if (nb < 0) return fail(c, LCRC_E_ARG, "waveform entry: offsets must be non-decreasing");
+        total_bytes += nb + (nb & 1);
+    }
+    int rc = ensure_wave_bytes(c, total_bytes);
+    if (rc) return rc;
+    std::vector<long long> start((size_t)std::max(n_utts, 0)), len((size_t)std::max(n_utts, 0));
+    long long pos = 0;
+    for (int u = 0; u < n_utts; u++) {
+        const long long nb = byte_off[u + 1] - byte_off[u];
+        memcpy(c->h_bytes + pos, bytes + byte_off[u], (size_t)nb);
+        start[u] = pos; len[u] = nb;
+        pos += nb + (nb & 1);                        // keep lin16 utterances 2-byte aligned
+    }
+    return run_frontend_staged(c, start.data(), len.data(), n_utts, pos, frame_off, rows);
 }
 
 int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
@@ -925,17 +946,13 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
     return LCRC_OK;
 }
 
-int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
-                            float *post, int *frame_off)
+// the part of the waveform -> posteriors entries behind the front-end
+static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
 {
-    if (!c) return LCRC_E_ARG;
-    int rows = 0;
-    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
-    if (rc || rows == 0) { if (c) c->label_utts = 0; return rc; }
     const bool copy_post = c->readback || c->dec_P <= 0;
-    if (!post && copy_post) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
+    if (!post && copy_post) return fail(c, LCRC_E_ARG, "waveform entry: NULL output");
     if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, rows, c->nbanks, c->d_means, c->stream));
-    rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
+    int rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
     rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
     if (rc) return rc;
@@ -944,6 +961,46 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (copy_post) memcpy(post, c->h_post, nbytes);
     return LCRC_OK;
+}
+
+int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
+                            float *post, int *frame_off)
+{
+    if (!c) return LCRC_E_ARG;
+    int rows = 0;
+    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
+    if (rc || rows == 0) { c->label_utts = 0; return rc; }
+    return wave_finish(c, n_utts, rows, post);
+}
+
+int lcrc_wave_stage_buffer(lcrc_ctx *c, long long capacity, unsigned char **bytes)
+{
+    if (!c || capacity < 0 || !bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_buffer: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_wave_bytes(c, capacity);
+    if (rc) return rc;
+    *bytes = c->h_bytes;
+    return LCRC_OK;
+}
+
+int lcrc_wave_stage_run(lcrc_ctx *c, const long long *start, const long long *n_bytes, int n_utts, float *post,
+                        int *frame_off)
+{
+    if (!c) return LCRC_E_ARG;
+    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
+    if (n_utts < 0 || (n_utts > 0 && (!start || !n_bytes || !frame_off))) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long extent = 0;
+    for (int u = 0; u < n_utts; u++) {
+        if (start[u] < extent || n_bytes[u] < 0 || (c->fe.wave_format == 1 && (start[u] & 1)))
+            return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: utterances must be in order, not overlap, and start on even bytes (lin16)");
+        extent = start[u] + n_bytes[u];
+    }
+    if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: beyond the capacity lcrc_wave_stage_buffer reserved");
+    int rows = 0;
+    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows);
+    if (rc || rows == 0) { c->label_utts = 0; return rc; }
+    return wave_finish(c, n_utts, rows, post);
 }
 
 int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty)

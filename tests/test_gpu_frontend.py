@@ -109,3 +109,29 @@ def test_frontend_errors(capi):
         ctx.configure_frontend(vector_size=1000)
     ctx.configure_frontend()
     assert ctx.frontend_frames(119846) == 747 and ctx.frontend_frames(10) == 1
+
+
+def test_zero_copy_waveform_staging(capi):
+    capi_mod = capi
+    """lcrc_wave_stage_buffer / lcrc_wave_stage_run == lcrc_wave_to_posteriors (bit for bit), incl. odd byte
+    counts, an empty file and buffer regrowth; misuse is rejected"""
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    ctx = capi_mod.Lcrc(model_dir(system), 15)
+    ctx.configure_frontend(wave_format="lin16", sample_freq=8000, vector_size=200, vector_step=80,
+                           lower_freq=64.0, higher_freq=4000.0, sent_mean_norm=True)
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    for blobs in ([raw[:4001], raw[:20000], b"", raw[:777]], [raw, raw[:30001]]):
+        a, fa = ctx.wave_to_posteriors(blobs)
+        b, fb = ctx.wave_to_posteriors_staged(blobs)
+        assert np.array_equal(fa, fb) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    import ctypes as C
+    buf = C.POINTER(C.c_ubyte)()
+    assert ctx.L.lcrc_wave_stage_buffer(ctx.h, 1000, C.byref(buf)) == 0
+    post = np.zeros((10, ctx.n_out), np.float32)
+    foff = np.zeros(3, np.int32)
+    bad = ctx.L.lcrc_wave_stage_run(ctx.h, np.array([0, 401], np.int64), np.array([400, 400], np.int64), 2, post, foff)
+    assert bad == capi_mod.LCRC_E_ARG                          # odd start of a lin16 utterance
+    bad = ctx.L.lcrc_wave_stage_run(ctx.h, np.array([0, 200], np.int64), np.array([400, 400], np.int64), 2, post, foff)
+    assert bad == capi_mod.LCRC_E_ARG                          # overlap
+    bad = ctx.L.lcrc_wave_stage_run(ctx.h, np.array([0], np.int64), np.array([1 << 30], np.int64), 1, post, foff)
+    assert bad == capi_mod.LCRC_E_ARG                          # beyond the reserved capacity
