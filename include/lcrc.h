@@ -168,6 +168,9 @@ int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const lon
 int lcrc_wave_stage_buffer(lcrc_ctx *ctx, long long capacity, unsigned char **bytes);
 int lcrc_wave_stage_run(lcrc_ctx *ctx, const long long *start, const long long *n_bytes, int n_utts,
                         float *post, int *frame_off);
+/* post == NULL in lcrc_wave_stage_run leaves the posteriors in the context's pinned output buffer: this
+ * returns it (rows as in frame_off; valid until the next call on the context) */
+int lcrc_staged_posteriors(lcrc_ctx *ctx, const float **post);
 
 /* ---- posterior writer path ("next" row f2) ---------------------------------------------
  * The softening functions SpeechRec applies to every posterior after the nets
@@ -195,7 +198,7 @@ int lcrc_output_configure(lcrc_ctx *ctx, const lcrc_softening *stages, int n_sta
  * lcrc_stage_run, lcrc_wave_to_posteriors) also decodes; lcrc_last_labels returns the result of the most
  * recent one.  lcrc_set_posterior_readback(ctx, 0) then skips the device-to-host copy of the
  * posteriors (`post` arguments may be NULL; the staged posterior buffer is not refreshed).
- * n_phonemes <= 64, states_per_phn <= 4, time_pruning <= 255, n_phonemes*states <= outputs;
+ * n_phonemes <= 64, states_per_phn <= 4, time_pruning <= 63 (shipped configs: 40), n_phonemes*states <= outputs;
  * n_phonemes = 0 switches the decoder off. */
 typedef struct lcrc_label {
     int start, end;          /* frames; the reference prints them as "%d00000" (100 ns units)   phndec.cpp:230 */

@@ -604,9 +604,8 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                         if (blen[k]) memcpy(pinned + bstart[k], j.bytes.data(), (size_t)blen[k]);
                         std::vector<unsigned char>().swap(j.bytes);
                     });
-                    std::vector<float> post(dev_dec ? 0 : (size_t)off.back() * n_out_);
-                    std::vector<int> foff(cnt + 1);
-                    if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, dev_dec ? nullptr : post.data(), foff.data())) {
+                    std::vector<int> foff(cnt + 1);      // posteriors stay in the context's pinned output buffer
+                    if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) {
                         errs[g] = tr.LastError(); failed = true; return;
                     }
                     if (off.back() > 0) kms[g] += tr.LastKernelMs();
@@ -615,7 +614,7 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                         if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(jobs[first + k], mlf != nullptr, {}); });
                         continue;
                     }
-                    float *hp = post.data();
+                    float *hp = const_cast<float *>(tr.StagedPosteriors());
                     pool_->ParallelFor(cnt, [&](int k) {
                         Job &j = jobs[first + k];
                         float *pp = hp + (size_t)foff[k] * n_out_;

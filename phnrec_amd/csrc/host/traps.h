@@ -122,6 +122,7 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    const float *StagedPosteriors() { const float *p = nullptr; lcrc_staged_posteriors(ctx_, &p); return p; }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }
     bool Ready() const { return ctx_ != nullptr; }

@@ -950,7 +950,6 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
 static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
 {
     const bool copy_post = c->readback || c->dec_P <= 0;
-    if (!post && copy_post) return fail(c, LCRC_E_ARG, "waveform entry: NULL output");
     if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, rows, c->nbanks, c->d_means, c->stream));
     int rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
@@ -959,7 +958,14 @@ static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
     if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (copy_post) memcpy(post, c->h_post, nbytes);
+    if (copy_post && post) memcpy(post, c->h_post, nbytes);   // post == NULL: read them in place (lcrc_staged_posteriors)
+    return LCRC_OK;
+}
+
+int lcrc_staged_posteriors(lcrc_ctx *c, const float **post)
+{
+    if (!c || !post) return LCRC_E_ARG;
+    *post = c->h_post;
     return LCRC_OK;
 }
 
@@ -970,6 +976,7 @@ int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long 
     int rows = 0;
     int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
     if (rc || rows == 0) { c->label_utts = 0; return rc; }
+    if (!post && (c->readback || c->dec_P <= 0)) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
     return wave_finish(c, n_utts, rows, post);
 }
 
@@ -1008,8 +1015,8 @@ int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int 
     if (!c) return LCRC_E_ARG;
     if (n_phonemes == 0) { c->dec_P = 0; c->label_utts = 0; return LCRC_OK; }
     if (n_phonemes < 0 || n_phonemes > 64 || states_per_phn < 1 || states_per_phn > 4 || time_pruning < 1 ||
-        time_pruning > 255 || n_phonemes * states_per_phn > c->nets[2].n_out)
-        return fail(c, LCRC_E_UNSUPPORTED, "lcrc_decoder_configure: needs <= 64 phonemes, <= 4 states, time_pruning <= 255, "
+        time_pruning > 63 || n_phonemes * states_per_phn > c->nets[2].n_out)
+        return fail(c, LCRC_E_UNSUPPORTED, "lcrc_decoder_configure: needs <= 64 phonemes, <= 4 states, time_pruning <= 63, "
                                           "phonemes x states <= posterior outputs");
     c->dec_P = n_phonemes; c->dec_S = states_per_phn; c->dec_prune = time_pruning; c->dec_wpen = wpenalty;
     return LCRC_OK;

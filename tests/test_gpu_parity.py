@@ -429,7 +429,7 @@ def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
     f32 additions), on ragged batches incl. empty, 1-frame and shorter-than-the-pruning-horizon utterances,
     for several state counts / horizons / penalties; with and without posterior read-back"""
     for nb, hid, nout, P, S, prune, wpen in ((15, 64, 138, 45, 3, 40, -4.6875), (11, 40, 48, 12, 4, 7, -1.5),
-                                             (9, 30, 20, 20, 1, 255, 0.0), (13, 30, 64, 21, 3, 1, -0.25),
+                                             (9, 30, 20, 20, 1, 63, 0.0), (13, 30, 64, 21, 3, 1, -0.25),
                                              (15, 50, 192, 64, 3, 40, -2.0)):
         d = str(tmp_path / ("m%d_%d" % (P, S)))
         modelgen.write_model_dir(d, nb, hid, nout, seed=P)
@@ -464,6 +464,8 @@ def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
         assert ctx.last_labels() == []
         with pytest.raises(capi.LcrcError):
             ctx.configure_decoder(65, 3, 40, 0.0)
+        with pytest.raises(capi.LcrcError):
+            ctx.configure_decoder(P, S, 64, 0.0)                # the winner history lives one slot per lane
         with pytest.raises(capi.LcrcError):
             ctx.configure_decoder(nout, 3, 40, 0.0)
         ctx.close()

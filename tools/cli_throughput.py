@@ -51,8 +51,19 @@ def main():
         env = dict(os.environ, PHNREC_STATS="1")
         if len(sys.argv) > 3:
             env["PHNREC_CTX_PER_GPU"] = sys.argv[3]
+        if os.environ.get("CLI_ROCPROF"):      # per-kernel times of one configuration (dev aid)
+            out = os.path.join(ROOT, "gpurun_out", "cli_prof")
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--",
+                   BIN, "-c", mdir, "-l", lst] + os.environ["CLI_ROCPROF"].split() + ["-m", os.path.join(td, "out.mlf")]
+            subprocess.run(cmd, env=dict(env, TMPDIR="/tmp"), capture_output=True, text=True)
+            import glob
+            for f in glob.glob(os.path.join(out, "*", "*_kernel_stats.csv")):
+                print(open(f).read())
+            return
         for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
                              (["-F", "-D", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end + decoder (-F -D)"),
+                             (["-F", "-D", "-b", "131072", "-m", os.path.join(td, "out.mlf")], "wf->str, -F -D, 131072 frames per launch"),
+                             (["-F", "-b", "131072", "-m", os.path.join(td, "out.mlf")], "wf->str, -F, 131072 frames per launch"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
             t0 = time.time()
             p = subprocess.run([BIN, "-c", mdir, "-l", lst] + extra, env=env, capture_output=True, text=True)
