@@ -87,7 +87,6 @@ struct lcrc_ctx {
     std::vector<int> label_first;
     int label_utts = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
-    int dbg_flags = 0;
     std::string err;
     const char *variant = "none";
     unsigned lds_bytes = 0;
@@ -277,7 +276,6 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     fill_output_transform(c, p.out_func, p.out_c, p.out_l, &p.out_be);
     p.tile_frames = c->tile_frames;
     p.stamps = c->d_stamps;
-    p.dbg_flags = c->dbg_flags;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
     HIP_TRY(c, lcrc_launch(p, s, nullptr));
@@ -1109,12 +1107,6 @@ int lcrc_debug_set_stamps(lcrc_ctx *c, void *d_buf)
 {
     if (!c) return LCRC_E_ARG;
     c->d_stamps = static_cast<unsigned long long *>(d_buf);
-    return LCRC_OK;
-}
-int lcrc_debug_set_flags(lcrc_ctx *c, int flags)
-{
-    if (!c) return LCRC_E_ARG;
-    c->dbg_flags = flags;
     return LCRC_OK;
 }
 #endif

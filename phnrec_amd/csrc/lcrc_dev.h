@@ -51,7 +51,6 @@ struct LcrcParams {
     float *dbg_in0, *dbg_in1, *dbg_p0, *dbg_p1, *dbg_g;
     // [grid][8 waves][16] s_memtime stamps; only written by the diagnostic build (-DLCRC_STAMPS)
     unsigned long long *stamps;
-    int dbg_flags;       // diagnostic build only
 };
 
 // LDS carve-up (bytes), computed identically on host and device.
