@@ -75,6 +75,8 @@ void MelBanks::Init()
     fftlo_ = f.fftlo;
     ffthi_ = f.ffthi;
     fft_buf_.assign(2 * (size_t)fft_ + 1, 0.0f);
+    BuildTwiddles(fft_, twiddle_);        // the reference's per-frame recurrence, evaluated once
+    en_.assign((size_t)nbanks_full_, 0.0f);
     init_ = true;
 }
 
@@ -82,7 +84,7 @@ void MelBanks::Init()
 // 1 (the classic "four1" arrangement the reference uses, dspc.cpp:24-78).  Parity needs
 // its exact arithmetic: twiddles by the double-precision recurrence w += w*(wpr,wpi),
 // butterfly products formed in double and rounded to float before the add/subtract.
-static void Fft(float *d, unsigned nn)
+static void Fft(float *d, unsigned nn, const double *tw)
 {
     const unsigned n = nn << 1;
     for (unsigned i = 1, j = 1; i < n; i += 2) {          // bit reversal
@@ -94,13 +96,13 @@ static void Fft(float *d, unsigned nn)
         while (m >= 2 && j > m) { j -= m; m >>= 1; }
         j += m;
     }
+    // twiddle (stage of half-size h = span/2, butterfly k) = entry h - 1 + k of the table (meltables.cpp:
+    // the recurrence w += w * (wpr, wpi) in double, exactly the values the reference forms per frame)
     for (unsigned span = 2; n > span; span <<= 1) {
         const unsigned stride = span << 1;
-        const double theta = -(6.28318530717959 / span);     // forward transform
-        const double s = sin(0.5 * theta);
-        const double wpr = -2.0 * s * s, wpi = sin(theta);
-        double wr = 1.0, wi = 0.0;
+        const double *stage = tw + 2 * (size_t)(span / 2 - 1);
         for (unsigned m = 1; m < span; m += 2) {
+            const double wr = stage[m - 1], wi = stage[m];
             for (unsigned i = m; i <= n; i += stride) {
                 const unsigned j = i + span;
                 const float tr = (float)(wr * d[j] - wi * d[j + 1]);
@@ -110,9 +112,6 @@ static void Fft(float *d, unsigned nn)
                 d[i] += tr;
                 d[i + 1] += ti;
             }
-            const double t = wr;
-            wr = t * wpr - wi * wpi + t;
-            wi = wi * wpr + t * wpi + wi;
         }
     }
 }
@@ -136,8 +135,9 @@ void MelBanks::Frame(float *x, float *out)
         d[1 + 2 * i] = i < vs_ ? x[i] * hamming_[i] : 0.0f;
         d[2 + 2 * i] = 0.0f;
     }
-    Fft(d, (unsigned)fft_);
-    std::vector<float> en(nbanks_full_, 0.0f);
+    Fft(d, (unsigned)fft_, twiddle_.data());
+    std::vector<float> &en = en_;
+    std::fill(en.begin(), en.end(), 0.0f);
     for (int i = fftlo_; i <= ffthi_; i++) {            // _mbApply dspc.cpp:236-269
         const float re = d[1 + 2 * i], im = d[2 + 2 * i];
         const float p = re * re + im * im;              // cPower dspc.h:141-146

@@ -48,7 +48,8 @@ private:
     int nbanks_ = 15, nbanks_full_ = -1, fs_ = 8000, vs_ = 200, step_ = 80, fft_ = 256;
     float preem_ = 0.0f, lo_ = 64.0f, hi_ = 4000.0f;
     bool zmean_ = false, init_ = false;
-    std::vector<float> hamming_, coeffs_, fft_buf_;
+    std::vector<float> hamming_, coeffs_, fft_buf_, en_;
+    std::vector<double> twiddle_;
     std::vector<short> bank_of_;
     int fftlo_ = 0, ffthi_ = 0;
 };
