@@ -194,25 +194,27 @@ def main():
         stream = torch.cuda.current_stream(dev)
         ctx.set_timing(False)       # per-step kernel times come from the events below
 
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
+        # Kernel time: ONE pair of HIP events on the launch stream around the K timed launches (the average
+        # launch duration over the timed region, dispatch gaps included); an event pair per launch would put
+        # two more packets between consecutive kernels and inflate both this figure and the step time.
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         state = {"i": -args.warmup}
 
         def step():
             i = state["i"]
-            if i >= 0:
-                ev[i][0].record(stream)
+            if i == 0:
+                ev0.record(stream)
             ctx.posteriors_device(d_mel.data_ptr(), args.batch, d_post.data_ptr(),
                                   stream=stream.cuda_stream)
-            if i >= 0:
-                ev[i][1].record(stream)
+            if i == args.steps - 1:
+                ev1.record(stream)
             state["i"] = i + 1
 
         def sync():
             torch.cuda.synchronize(dev)
 
         elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=dev)
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps
         kernel_ms = ranks.max_float(kernel_ms, device=dev)
         total_frames = args.batch * args.steps * max(1, ranks.world)
         fps = total_frames / elapsed
