@@ -161,7 +161,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # default warm-up: the device needs ~100 launches (~25 ms of load) to reach its steady clock after idling
+    # (0.236 ms per launch at launch 11-20, 0.210 ms from launch ~100 on; profiles/README.md)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
