@@ -346,12 +346,16 @@ void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
 {
     char msg[1200];
     if (in == dfWaveform && gpu_frontend_ && out != dfParams) {
-        if (!ReadFile(job.src, job.bytes)) {
+        // -F: only the size is needed to plan the launches; the GPU worker reads the file straight into
+        // its context's pinned byte buffer
+        struct stat st;
+        if (stat(job.src.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) {
             snprintf(msg, sizeof msg, "Can not open waveform file: %s\n", job.src.c_str());
             job.ok = false; job.err = msg;
             return;
         }
-        job.frames = gpus_[0]->FrontendFrames((long long)job.bytes.size());
+        job.file_bytes = (long long)st.st_size;
+        job.frames = gpus_[0]->FrontendFrames(job.file_bytes);
         job.cols = nbanks_;
         return;
     }
@@ -594,16 +598,22 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
                     long long pos = 0;
                     for (int k = 0; k < cnt; k++) {
                         bstart[k] = pos;
-                        blen[k] = (long long)jobs[first + k].bytes.size();
+                        blen[k] = jobs[first + k].file_bytes;
                         pos += blen[k] + (blen[k] & 1);
                     }
                     unsigned char *pinned = nullptr;
                     if (!tr.WaveStageBuffer(pos, &pinned)) { errs[g] = tr.LastError(); failed = true; return; }
-                    pool_->ParallelFor(cnt, [&](int k) {
+                    std::atomic<int> bad(-1);
+                    pool_->ParallelFor(cnt, [&](int k) {          // files -> pinned memory, in parallel
                         Job &j = jobs[first + k];
-                        if (blen[k]) memcpy(pinned + bstart[k], j.bytes.data(), (size_t)blen[k]);
-                        std::vector<unsigned char>().swap(j.bytes);
+                        FILE *f = fopen(j.src.c_str(), "rb");
+                        const bool ok = f && (blen[k] == 0 || fread(pinned + bstart[k], 1, (size_t)blen[k], f) == (size_t)blen[k]);
+                        if (f) fclose(f);
+                        if (!ok) { int e = -1; bad.compare_exchange_strong(e, k); }
                     });
+                    if (bad >= 0) {
+                        errs[g] = "Can not open waveform file: " + jobs[first + bad].src; failed = true; return;
+                    }
                     std::vector<int> foff(cnt + 1);      // posteriors stay in the context's pinned output buffer
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) {
                         errs[g] = tr.LastError(); failed = true; return;

@@ -83,6 +83,7 @@ private:
         std::vector<float> post;
         std::vector<unsigned char> bytes;  // raw file (GPU front-end mode)
         int frames = 0, cols = 0;
+        long long file_bytes = 0;          // -F: size of the waveform file (read later, into pinned memory)
         std::string labels;                // formatted label / MLF text
         bool ok = true;
         std::string err;
