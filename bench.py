@@ -157,6 +157,27 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     return out
 
 
+def stub_main(args, ranks):
+    """Launcher self-test: everything of the N-rank harness except the GPU (see --stub)."""
+    from phnrec_amd import distrun
+    ranks.init("gloo")
+    state = {"n": 0}
+
+    def step():
+        time.sleep(0.002 * (1 + ranks.rank))         # the last rank is the slowest: MAX over ranks must see it
+        state["n"] += BATCH
+
+    elapsed = distrun.timed_steps(ranks, step, lambda: None, args.steps, args.warmup)
+    total = ranks.sum_int(state["n"])
+    if ranks.rank == 0:
+        print(json.dumps({"stub": True, "metric": "launcher self-test (no GPU work)", "n_gpus": 0,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "frames_all_ranks": total,
+                          "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
+                                    "device_map": distrun.device_map(ranks.world)}}), flush=True)
+    ranks.finish()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,25 +188,55 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    # launcher self-test (tests/test_distrun.py): the same launch / rendezvous / barrier / MAX-over-ranks
+    # code with a sleeping step and gloo instead of the GPU step and RCCL; its line says "stub": true
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    import torch
-    from phnrec_amd import capi, distrun, modelgen
+    from phnrec_amd import distrun
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # No launcher around us: start the N ranks ourselves, as fresh child processes, BEFORE anything in
+        # this process touches the GPU (counting devices does not initialise HIP on this image).
+        if not args.stub:
+            import torch
+            have, need = torch.cuda.device_count(), max(distrun.device_map(args.gpus)) + 1
+            if have < need:
+                raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); refusing to report a %d-GPU "
+                                 "figure from fewer devices (PHNREC_DEVICE_MAP=0,0,... maps several ranks onto "
+                                 "one GPU for a functional test and labels the output accordingly)"
+                                 % (args.gpus, have, args.gpus))
+        sys.exit(distrun.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     ranks = distrun.Ranks(args.gpus)
-    if ranks.world != args.gpus and ranks.world > 1:
+    if ranks.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ranks.world))
+    dmap = distrun.device_map(ranks.world)
+    oversubscribed = len(set(dmap)) < len(dmap)
+    if args.stub:
+        return stub_main(args, ranks)
+
+    import torch
+    from phnrec_amd import capi, modelgen
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the LCRC path has no CPU fallback")
-    torch.cuda.set_device(ranks.local_rank)
-    dev = torch.device("cuda", ranks.local_rank)
-    ranks.init("nccl")
+    gpu = dmap[ranks.local_rank]
+    if gpu >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants GPU %d, this node shows %d" % (ranks.rank, gpu, torch.cuda.device_count()))
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    # RCCL refuses two ranks on one device: an oversubscribed functional run makes its rendezvous over gloo
+    ranks.init("gloo" if oversubscribed else "nccl")
+    red_dev = None if oversubscribed else dev      # where the MAX / SUM reductions' tensors live
 
     spec = modelgen.SYSTEMS[SYSTEM]
     nb = spec["nbanks"]
     with tempfile.TemporaryDirectory() as tmp:
         mdir, weights_desc = model_directory(tmp)
-        ctx = capi.Lcrc(mdir, nb, device=ranks.local_rank)
+        ctx = capi.Lcrc(mdir, nb, device=gpu)
         dims = [ctx.net_dims(i) for i in range(3)]
         flops_frame = algorithmic_flops_per_frame(dims)
 
@@ -215,9 +266,9 @@ def main():
         def sync():
             torch.cuda.synchronize(dev)
 
-        elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=dev)
+        elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=red_dev)
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
-        kernel_ms = ranks.max_float(kernel_ms, device=dev)
+        kernel_ms = ranks.max_float(kernel_ms, device=red_dev)
         total_frames = args.batch * args.steps * max(1, ranks.world)
         fps = total_frames / elapsed
 
@@ -234,7 +285,7 @@ def main():
                     traffic = None
             line = {
                 "metric": "frames/sec (LCRC posterior path)", "value": round(fps, 1), "unit": "frames/s",
-                "n_gpus": max(1, ranks.world), "steps": args.steps, "warmup": args.warmup,
+                "n_gpus": len(set(dmap)), "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
@@ -243,6 +294,9 @@ def main():
                                        % (SYSTEM, args.batch),
                            "weights": weights_desc, "kernel": ctx.kernel_name,
                            "sharding": "one replica per GPU, utterances never exchanged (no collective)"},
+                # what actually ran: ranks as the process group counted them, how they were started, where
+                "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
+                          "device_map": dmap, "oversubscribed": oversubscribed},
                 "frames_per_s_per_gpu": round(fps / max(1, ranks.world), 1),
                 "xrt": round(100.0 / (fps / max(1, ranks.world)), 8),
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,

@@ -292,8 +292,22 @@ bool SpeechRec::EnsureGpus()
     // (PHNREC_CTX_PER_GPU overrides the default for experiments)
     int per_gpu = 2;
     if (const char *e = getenv("PHNREC_CTX_PER_GPU")) per_gpu = std::max(1, std::min(8, atoi(e)));
+    // PHNREC_DEVICE_MAP="0,0": the physical device of each of the -g N logical GPUs (default: 0..N-1).  Lets a
+    // 1-GPU box run the -g 2 arrangement (4 contexts, one launch queue); on an 8-GPU node it picks the GPUs.
+    std::vector<int> dmap;
+    if (const char *e = getenv("PHNREC_DEVICE_MAP")) {
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q || v < 0) return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
+            dmap.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
+        }
+        if ((int)dmap.size() < n) return Fail("PHNREC_DEVICE_MAP names fewer devices than -g asks for\n");
+    }
     for (int k = 0; k < per_gpu * n; k++) {
-        const int d = k / per_gpu;
+        const int d = dmap.empty() ? k / per_gpu : dmap[k / per_gpu];
         std::unique_ptr<Traps> t(new Traps);
         t->SetSystem(C.GetString("posteriors", "system").c_str());
         t->SetTrapLen(C.GetInt("posteriors", "length"));
@@ -670,18 +684,22 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
     stage1(0, std::min(n, kChunkFiles));
     for (int lo = 0; lo < n && ok; lo += kChunkFiles) {
         const int hi = std::min(n, lo + kChunkFiles), nhi = std::min(n, hi + kChunkFiles);
-        if (const Job *bad = first_error(lo, hi)) { ok = Fail(bad->err); break; }
+        // A file that cannot be read stops the run where the reference's sequential loop stops
+        // (srec.cpp:1280-1284): everything BEFORE it is still computed and written, then the error is reported.
+        const Job *bad = first_error(lo, hi);
+        const int stop = bad ? (int)(bad - jobs.data()) : hi;
         std::thread ahead;
-        if (hi < n) ahead = std::thread([&, hi, nhi] { stage1(hi, nhi); });
-        ok = stage23(lo, hi);
+        if (!bad && hi < n) ahead = std::thread([&, hi, nhi] { stage1(hi, nhi); });
+        if (stop > lo) ok = stage23(lo, stop);
         if (ahead.joinable()) ahead.join();
         if (!ok) break;
-        for (int i = lo; i < hi; i++) {
+        for (int i = lo; i < stop; i++) {
             Job &j = jobs[i];
             if (!j.ok) { ok = Fail(j.err); break; }
             if (mlf) fputs(j.labels.c_str(), mlf);
             j = Job();                               // results are out: release the buffers
         }
+        if (ok && bad) ok = Fail(bad->err);
     }
     stats_.stage1_seconds += stage1_us.load() * 1e-6;
     if (!ok) return false;
@@ -710,16 +728,20 @@ bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string
     const size_t kChunk = 1024;                       // utterances in flight (bounds host memory)
     char buf[1024];
     bool ok = true, eof = false;
-    while (ok && !eof) {
+    std::string parse_err;
+    while (ok && !eof && parse_err.empty()) {
         std::vector<Job> jobs;
         while (jobs.size() < kChunk) {
             if (!fgets(buf, 1023, fl)) { eof = true; break; }
             Job j;
-            if (!ParseLine(buf, out, mlf != nullptr, j)) { ok = false; break; }
+            // an invalid line stops the list there; the lines before it are processed first (srec.cpp:1246-1290
+            // works line by line)
+            if (!ParseLine(buf, out, mlf != nullptr, j)) { parse_err = LastError(); break; }
             jobs.push_back(std::move(j));
         }
-        if (ok && !jobs.empty()) ok = RunJobs(in, out, jobs, mlf);
+        if (!jobs.empty()) ok = RunJobs(in, out, jobs, mlf);
     }
+    if (ok && !parse_err.empty()) ok = Fail(parse_err);
     if (mlf) fclose(mlf);
     fclose(fl);
     return ok;

@@ -46,7 +46,10 @@ void BuildMelFilters(int count, int fft, int fs, float fmin, float fmax, MelFilt
     int ch = 0;
     for (int i = f.fftlo; i <= f.ffthi; i++) {
         const float mf = MelOf((float)i * bf);
-        while (mf > centre[ch] && ch <= count) ++ch;
+        // (index test first: `centre` has count + 1 entries; a bin beyond the last centre -- only reachable
+        //  through rounding at the very top of the band -- stays with the last filter's falling edge)
+        while (ch <= count && mf > centre[ch]) ++ch;
+        if (ch > count) ch = count;
         f.bank_of[i] = (short)ch;
     }
     for (int i = f.fftlo; i <= f.ffthi; i++) {

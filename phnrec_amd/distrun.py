@@ -8,6 +8,65 @@ agree on the start/stop of the timed region and reduce the elapsed time (MAX).
 No data-path collective exists and none is invented.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
+
+
+def device_map(world):
+    """Physical GPU of every local rank.  Default: rank r -> GPU r.  PHNREC_DEVICE_MAP="0,0" maps several
+    ranks onto one GPU (a 1-GPU box can then exercise the N-rank path; RCCL refuses two ranks on one device,
+    so such a run makes its rendezvous over gloo and says so in its output)."""
+    spec = os.environ.get("PHNREC_DEVICE_MAP", "").strip()
+    if not spec:
+        return list(range(world))
+    try:
+        m = [int(x) for x in spec.split(",")]
+    except ValueError:
+        raise SystemExit("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices, got %r" % spec)
+    if len(m) < world or min(m) < 0:
+        raise SystemExit("PHNREC_DEVICE_MAP=%s names %d devices, %d ranks were asked for" % (spec, len(m), world))
+    return m[:world]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(script, argv, world, poll_s=0.05):
+    """`python bench.py --gpus N` without a launcher: start N fresh single-GPU ranks of `script` (the
+    environment torch.distributed.run would give them, rendezvous on 127.0.0.1) and return the worst exit
+    code.  The calling process must not have touched the GPU and never does: the ranks are CHILD
+    processes, nothing is re-executed.  Rank 0 inherits stdout (its one JSON line is the run's output);
+    the other ranks' stdout goes to stderr.  If a rank fails, the others are terminated (by PID) instead
+    of being left waiting at a barrier."""
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PHNREC_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if rank == 0 else sys.stderr))
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:          # a rank died: the rest would hang at the next barrier
+                    q.terminate()
+        time.sleep(poll_s)
+    return worst
 
 
 class Ranks:
@@ -19,7 +78,10 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.gpus = gpus
         self.launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+        self.launcher = ("self" if os.environ.get("PHNREC_SELF_LAUNCHED") == "1" else
+                         "torch.distributed.run" if self.launched else "none")
         self.pg = False
+        self.backend = None
 
     def init(self, backend):
         # also under a launcher with a single rank, so that the rendezvous / RCCL path is the one
@@ -30,6 +92,9 @@ class Ranks:
             os.environ.setdefault("MASTER_PORT", "29500")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.pg = True
+            self.backend = backend
+            # what the process group itself says, not what the environment promised
+            self.world = dist.get_world_size()
         return self
 
     def barrier(self):

@@ -41,6 +41,8 @@ def test_library_has_gfx950_code_object_and_no_torch_types():
 
 
 @pytest.mark.parametrize("system,kernel", [("PHN_CZ_SPDAT_LCRC_N1500", "cz_42_69_9"),
+                                           ("PHN_HU_SPDAT_LCRC_N1500", "hu_42_93_12"),
+                                           ("PHN_RU_SPDAT_LCRC_N1500", "ru_42_80_10"),
                                            ("PHN_EN_TIMIT_LCRC_N500", "en_64_60_8")])
 def test_model_info_on_shipped_models(system, kernel):
     spec = modelgen.SYSTEMS[system]

@@ -26,7 +26,7 @@ def test_binary_exists():
     assert os.path.exists(BIN), "build with make -C phnrec_amd/csrc"
 
 
-@pytest.mark.parametrize("system", [CZ, EN])
+@pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
 def test_front_end_dump_is_bit_identical(system, tmp_path):
     out = tmp_path / "t.mel"
     run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-t", "par", "-o", out)
@@ -152,3 +152,33 @@ def test_verbose_banner(tmp_path):
         assert needle in p.stdout
     q = run("-c", model_dir(CZ), "-s", "post", "-i", os.path.join(GOLD, CZ, "test.lop"), "-o", tmp_path / "q.rec")
     assert q.stdout == ""
+
+
+def test_a_missing_file_in_the_middle_of_a_list(tmp_path):
+    """The reference works through a list line by line and exit(1)s at the first file it cannot open
+    (srec.cpp:1280-1284, MError srec.cpp:118-122): everything BEFORE that line has been written (label files,
+    MLF entries), nothing after it.  The chunked pipeline here must leave the same outputs behind."""
+    data = tmp_path / "data"
+    data.mkdir()
+    names = ["utt_a", "utt_b", "gone", "utt_c"]
+    for n in names:
+        if n != "gone":
+            shutil.copyfile(os.path.join(GOLD, "cli", n + ".lop"), data / (n + ".lop"))
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s\n" % (data / (n + ".lop")) for n in names))
+    mlf = tmp_path / "out.mlf"
+    p = run("-c", model_dir(CZ), "-s", "post", "-l", lst, "-m", mlf, ok=False)
+    assert p.returncode == 1 and "ERROR: Can not open file: %s" % (data / "gone.lop") in p.stderr
+    gold = open(os.path.join(GOLD, "cli", "list.mlf")).read()
+    want = gold[:gold.index('"*/utt_c.rec"')]                  # header + utt_a + utt_b
+    assert mlf.read_text() == want
+    p = run("-c", model_dir(CZ), "-s", "post", "-l", lst, ok=False)
+    assert p.returncode == 1
+    assert (data / "utt_a.rec").exists() and (data / "utt_b.rec").exists() and not (data / "utt_c.rec").exists()
+    # an unparsable line stops the list the same way: the lines before it are processed
+    lst.write_text("%s\n%s\n \n%s\n" % (data / "utt_a.lop", data / "utt_b.lop", data / "utt_c.lop"))
+    for n in ("utt_a", "utt_b"):
+        os.remove(data / (n + ".rec"))
+    p = run("-c", model_dir(CZ), "-s", "post", "-l", lst, ok=False)
+    assert p.returncode == 1 and "Invalid line in file list" in p.stderr
+    assert (data / "utt_a.rec").exists() and (data / "utt_b.rec").exists() and not (data / "utt_c.rec").exists()

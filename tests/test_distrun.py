@@ -83,3 +83,65 @@ def test_single_process_is_a_noop_world():
         r.barrier()
         t = distrun.timed_steps(r, lambda: None, lambda: None, steps=3, warmup=1)
         assert t >= 0
+
+
+# ---- bench.py's own launcher (python bench.py --gpus N without torch.distributed.run) ----------------------
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _last_json(text):
+    import json
+    return json.loads([l for l in text.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_self_launch_starts_n_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment starts two fresh ranks itself; the line
+    rank 0 prints carries the world size the process group counted (stub step, gloo: no GPU here)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["ranks"] == {"world": 2, "launcher": "self", "backend": "gloo", "device_map": [0, 1]}
+    assert line["frames_all_ranks"] == 2 * (4 + 1) * 8192          # both ranks stepped, warm-up included
+    assert line["ms_per_step"] >= 4.0 * 0.9, "rank 1 (4 ms per step) sets the time: MAX over ranks"
+
+
+def test_bench_under_torch_distributed_run():
+    """the driver's form: torch.distributed.run starts the ranks, bench.py does not start more"""
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["ranks"]["world"] == 2 and line["ranks"]["launcher"] == "torch.distributed.run"
+    assert line["frames_all_ranks"] == 2 * (3 + 1) * 8192
+
+
+def test_bench_refuses_to_misreport_the_gpu_count():
+    """More GPUs asked for than the node has (none here): a loud failure, never an n_gpus: 1 line; and a
+    launcher's WORLD_SIZE that disagrees with --gpus is refused as well."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PHNREC_DEVICE_MAP")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert p.returncode != 0 and "refusing" in p.stderr and "{" not in p.stdout
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--stub"], capture_output=True, text=True, env=env2, timeout=240)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_device_map_override(monkeypatch):
+    monkeypatch.delenv("PHNREC_DEVICE_MAP", raising=False)
+    assert distrun.device_map(4) == [0, 1, 2, 3]
+    monkeypatch.setenv("PHNREC_DEVICE_MAP", "0,0")
+    assert distrun.device_map(2) == [0, 0]
+    import pytest
+    with pytest.raises(SystemExit):
+        distrun.device_map(3)

@@ -11,6 +11,7 @@ from tests.util import GOLD, ROOT, model_dir, read_htk
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
 CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
+HU, RU = "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"
 
 
 def run(*args, env=None):
@@ -28,7 +29,7 @@ def _labels_match(mine_path, gold_path):
     assert max(abs(float(m[3]) - float(g[3])) for m, g in zip(mine, gold)) < 1e-2
 
 
-@pytest.mark.parametrize("system", [CZ, EN])
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_bundled_utterance_end_to_end(system, tmp_path):
     """the reference's own smoke test (test.sh): phnrec -c DIR -i test.raw -o test.rec"""
     out = tmp_path / "t.rec"
@@ -112,7 +113,7 @@ def test_default_system_1bt_dct_end_to_end(tmp_path):
     _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))
 
 
-@pytest.mark.parametrize("system", [CZ, EN])
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_decoder_on_the_gpu_flag(system, tmp_path):
     """-D: PhnDec runs on the device behind the posterior kernel; same label files as the reference's, for
     the single-file form, for the -F form and for a batched list into an MLF"""
@@ -137,3 +138,77 @@ def test_decoder_on_the_gpu_flag(system, tmp_path):
     run("-c", model_dir(CZ), "-l", lst, "-m", host)
     run("-c", model_dir(CZ), "-l", lst, "-m", dev, "-D", "-b", 800)      # several launches
     assert dev.read_text() == host.read_text()                            # same posteriors, same f32 additions
+
+
+# ---- the multi-GPU split (BASELINE configs[3] / configs[4]) on a 1-GPU box -----------------------
+def _make_list(tmp_path, name, n_files, seed, fmt="lin16", rate=8000):
+    """`n_files` synthetic waveform files of 0.2-2.5 s (5 sines + noise, as SURVEY 8d prescribes) + the list"""
+    rng = np.random.default_rng(seed)
+    d = tmp_path / name
+    d.mkdir()
+    lines = []
+    for i in range(n_files):
+        n = int(rng.integers(rate // 5, int(rate * 2.5)))
+        t = np.arange(n) / rate
+        x = sum(np.sin(2 * np.pi * f * t + p) for f, p in zip(rng.uniform(200, 3400, 5), rng.uniform(0, 6.28, 5)))
+        x = 0.3 * 32767 / 5 * x + rng.normal(0, 1000, n)
+        p = d / ("f%03d.raw" % i)
+        np.clip(x, -32768, 32767).astype("<i2").tofile(p)
+        lines.append(str(p))
+    lst = tmp_path / (name + ".scp")
+    lst.write_text("\n".join(lines) + "\n")
+    return lst
+
+
+@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D")])
+def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
+    """`-g 2` (four contexts pulling launches from one queue; both logical GPUs mapped onto this box's GPU
+    with PHNREC_DEVICE_MAP) writes byte for byte the MLF of `-g 1`: utterances never interact, outputs are
+    gathered in list order (srec.cpp:1246-1290, MLF format srec.cpp:1273,1156,1180)."""
+    lst = _make_list(tmp_path, "hu", 60, seed=4)
+    one, two = tmp_path / "one.mlf", tmp_path / "two.mlf"
+    run("-c", model_dir(HU), "-l", lst, "-m", one, "-g", 1, "-b", 600, *flags)
+    p = run("-c", model_dir(HU), "-l", lst, "-m", two, "-g", 2, "-b", 600, *flags,
+            env={"PHNREC_DEVICE_MAP": "0,0", "PHNREC_STATS": "1"})
+    assert "files=60" in p.stderr
+    a, b = one.read_text(), two.read_text()
+    assert a == b and a.startswith("#!MLF!#\n") and a.count("\n.\n") == 60
+    # posterior dumps as well
+    run("-c", model_dir(HU), "-l", lst, "-t", "post", "-g", 2, "-b", 600, *flags[:1], env={"PHNREC_DEVICE_MAP": "0,0"})
+    two_lop = {f: open(f, "rb").read() for f in sorted(str(x) for x in (tmp_path / "hu").glob("*.lop"))}
+    run("-c", model_dir(HU), "-l", lst, "-t", "post", "-g", 1, "-b", 600, *flags[:1])
+    assert len(two_lop) == 60
+    for f, blob in two_lop.items():
+        assert open(f, "rb").read() == blob, f
+
+
+def test_more_gpus_than_the_box_has_fails_loudly(tmp_path):
+    lst = _make_list(tmp_path, "cz", 3, seed=1)
+    e = dict(os.environ)
+    e.pop("PHNREC_DEVICE_MAP", None)
+    p = subprocess.run([BIN, "-c", model_dir(CZ), "-l", str(lst), "-m", str(tmp_path / "x.mlf"), "-g", "64"],
+                       capture_output=True, text=True, env=e)
+    assert p.returncode != 0 and "device_id out of range" in p.stderr
+
+
+def test_four_systems_at_once(tmp_path):
+    """BASELINE configs[4]: tools/run_four_systems.sh -- four `phnrec -g 2` processes, one per system (CZ, HU,
+    RU at 8 kHz, EN at 16 kHz), here with every GPU pair mapped onto this box's one GPU; each system's MLF equals
+    the one a plain single-GPU run of that system writes."""
+    script = os.path.join(ROOT, "tools", "run_four_systems.sh")
+    args, lists = [], {}
+    for k, system in enumerate((CZ, HU, RU, EN)):
+        lst = _make_list(tmp_path, system[4:6].lower(), 12, seed=10 + k, rate=16000 if system == EN else 8000)
+        lists[system] = lst
+        args += [model_dir(system), str(lst)]
+    e = dict(os.environ, PHNREC_GPU_PAIRS="0,0 0,0 0,0 0,0")
+    p = subprocess.run(["bash", script] + args + ["-b", "500"], capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr
+    assert p.stderr.count("phnrec: files=12") == 4
+    for system, lst in lists.items():
+        mlf = str(lst)[:-4] + ".mlf"
+        four = open(mlf).read()
+        ref = tmp_path / (system + ".ref.mlf")
+        run("-c", model_dir(system), "-l", lst, "-m", ref)
+        assert four == ref.read_text(), system
+        assert four.count("\n.\n") == 12

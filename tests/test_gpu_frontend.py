@@ -10,6 +10,7 @@ from tests.util import GOLD, model_dir, read_htk
 
 pytestmark = pytest.mark.gpu
 CZ, EN = "PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"
+HU, RU = "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"
 # the FFT, window, power and mel sums follow the reference operation by operation; ln() is computed in
 # double and rounded once, glibc's logf is correctly rounded except in rare cases: <= 1 ulp (1.9e-6 at ~20)
 TOL_MEL = 2e-6
@@ -33,7 +34,7 @@ def _ctx(capi, system, **over):
     return ctx
 
 
-@pytest.mark.parametrize("system", [CZ, EN])
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_mel_matches_reference_dump(capi, system):
     raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
     ctx = _ctx(capi, system)
@@ -62,7 +63,7 @@ def test_alaw_and_short_files(capi):
     assert np.isfinite(mel).all()
 
 
-@pytest.mark.parametrize("system", [CZ, EN])
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_wave_to_posteriors(capi, system):
     """waveform -> posteriors without leaving the GPU vs the reference's -t post dump"""
     raw = open(os.path.join(GOLD, "test.raw"), "rb").read()

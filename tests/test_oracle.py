@@ -94,7 +94,7 @@ def test_oracle_matches_reference_posteriors(oracle_mod, system):
     assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
 
 
-@pytest.mark.parametrize("system", ["PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"])
+@pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
 def test_oracle_intermediates(oracle_mod, system):
     ob = oracle_mod
     spec = modelgen.SYSTEMS[system]
@@ -244,7 +244,7 @@ def test_other_posterior_systems_vs_reference_goldens(oracle_mod, tmp_path):
             assert np.array_equal(t.process_offline(mel[a:b]), got[a:b])
 
 
-@pytest.mark.parametrize("system", ["PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"])
+@pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
 def test_phndec_oracle_reproduces_reference_label_files(oracle_mod, system):
     """phndec_oracle.c on the logarithm of the reference's posterior dump == the reference's .rec
     (labels and times exact, scores equal at the printed precision)"""

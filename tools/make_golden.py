@@ -7,7 +7,7 @@ the GPU box; the fixtures it writes are data (inputs + expected outputs):
   test.raw                          the reference's bundled test input (test.sh:1)
   rec/*.rec                         the reference's golden label files for it
                                     (test.rec.org, test_en.rec, test_hu.rec, test_ru.rec)
-  models/PHN_{CZ,EN}_*              the two model directories the tests need on the
+  models/PHN_{CZ,EN,HU,RU}_*        the four model directories the tests need on the
                                     GPU box (weights .nbin, norms, windows, config,
                                     phoneme list, licence) -- research-licensed DATA
   <SYS>/test.mel  <SYS>/test.lop    `phnrec_ref -t par` / `-t post` HTK dumps for all
@@ -38,7 +38,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 REC = {"PHN_CZ_SPDAT_LCRC_N1500": "test.rec.org", "PHN_EN_TIMIT_LCRC_N500": "test_en.rec",
        "PHN_HU_SPDAT_LCRC_N1500": "test_hu.rec", "PHN_RU_SPDAT_LCRC_N1500": "test_ru.rec"}
-SHIP_MODELS = ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500")
+SHIP_MODELS = tuple(REC)      # all four shipped systems (BASELINE configs[3] names HU, configs[4] all of them)
 
 # (name, nbanks, hidden, n_out, seed, utterance lengths)
 SYNTH_CASES = [
