@@ -113,6 +113,13 @@ int lcrc_posteriors_batch(lcrc_ctx *ctx, const float *mel, const int *off, int n
 int lcrc_posteriors_device(lcrc_ctx *ctx, const float *d_mel, const int *d_off, int n_utts,
                            int n_rows, float *d_post, void *hip_stream);
 
+/* A row range of one utterance (or of a chunk of one, cut with its 15-frame halos): mel holds n_rows
+ * frames, only the posteriors of rows [row_first, row_first + row_count) are computed and returned
+ * (post has row_count rows); the other rows are context.  This is how lcrc_push evaluates a bunch on
+ * [history | pushed frames] and how a file longer than one launch is cut.  posteriors/system=LCRC only. */
+int lcrc_posteriors_rows(lcrc_ctx *ctx, const float *mel, int n_rows, int row_first, int row_count,
+                         float *post);
+
 /* Zero-copy variant of lcrc_posteriors_batch for callers that assemble batches themselves
  * (this repository's SpeechRec does): lcrc_stage_buffers returns pinned host buffers owned
  * by the context with room for `rows` frames (valid until the next lcrc_stage_buffers call
@@ -216,7 +223,9 @@ int lcrc_last_labels(lcrc_ctx *ctx, const lcrc_label **labels, const int **first
  * (traps.cpp:518-535): the first frame after a reset floods the 31-frame
  * history; when `needed`, post row i is the estimate for the window ENDING at
  * pushed frame i (i.e. centred 15 frames earlier); when !needed only the
- * history advances and `post` is not touched (may be NULL).
+ * history advances and `post` is not touched (may be NULL).  The frames are kept in a pinned strip
+ * the kernel reads in place and only the n pushed rows are computed (no re-upload of the history,
+ * no allocation per call).
  * lcrc_delay == Traps::GetDelay (frames pushed since reset minus one, capped
  * at 9999, traps.cpp:199,215-217). */
 int lcrc_reset(lcrc_ctx *ctx);
@@ -233,6 +242,14 @@ int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
 /* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
  * (tuning and test hook; results are bit-identical either way) */
 int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
+/* Small launches (streaming bunches, short utterances: fewer 16-frame tiles than half of the CUs) run
+ * on the split-hidden kernels: every frame tile's hidden dimension is spread over several workgroups,
+ * whose partial output tiles the last arriver adds in a fixed order.  The result of a frame then depends
+ * on the number of workgroups per tile (last bits; each setting is deterministic and within the parity
+ * tolerance), i.e. on the size of the launch it is part of.  0 = automatic (default), 1 = never split:
+ * every launch uses the fused kernel and a frame's posteriors are bit-identical however it is batched
+ * (the CLI sets this); k > 1 = at most k workgroups per tile. */
+int lcrc_set_hidden_split(lcrc_ctx *ctx, int workgroups_per_tile);
 /* Name of the kernel variant selected for this model ("cz_11_18_9", "generic", ...) */
 const char *lcrc_kernel_name(const lcrc_ctx *ctx);
 

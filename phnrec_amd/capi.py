@@ -16,13 +16,13 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 SYMBOLS = [
     "lcrc_create", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
-    "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe",
+    "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
@@ -141,6 +141,8 @@ def load():
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.lcrc_set_timing.argtypes = [vp, C.c_int]
     L.lcrc_set_tile_frames.argtypes = [vp, C.c_int]
+    L.lcrc_set_hidden_split.argtypes = [vp, C.c_int]
+    L.lcrc_posteriors_rows.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
     _lib = L
     return L
 
@@ -206,6 +208,13 @@ class Lcrc:
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
         post = np.empty((mel.shape[0], self.n_out), np.float32)
         self._check(self.L.lcrc_posteriors(self.h, mel, mel.shape[0], post))
+        return post
+
+    def posteriors_rows(self, mel, row_first, row_count):
+        """rows [row_first, row_first + row_count) of the strip `mel`; the other rows are context only"""
+        mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
+        post = np.empty((row_count, self.n_out), np.float32)
+        self._check(self.L.lcrc_posteriors_rows(self.h, mel, mel.shape[0], row_first, row_count, post))
         return post
 
     def posteriors_batch(self, mel, off):
@@ -343,6 +352,10 @@ class Lcrc:
     def set_tile_frames(self, frames):
         """0 = per launch (default), 16 or 32 = forced frames per workgroup"""
         self._check(self.L.lcrc_set_tile_frames(self.h, frames))
+
+    def set_hidden_split(self, workgroups_per_tile):
+        """0 = automatic (default), 1 = never split (bit-identical however frames are batched), k = at most k"""
+        self._check(self.L.lcrc_set_hidden_split(self.h, workgroups_per_tile))
 
     def set_timing(self, on):
         self._check(self.L.lcrc_set_timing(self.h, int(on)))

@@ -316,6 +316,8 @@ bool SpeechRec::EnsureGpus()
         t->SetAddC0(C.GetBool("posteriors", "add_c0"));
         t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
         t->SetDevice(d);
+        // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
+        t->SetHiddenSplit(1);
         if (!t->Init(config_dir_.c_str())) return Fail(t->LastError() + "\n");
         if (gpu_frontend_) {
             if (wave_.noise_level != 0.0f) return Fail("source/noise_level needs the host front-end (libc rand()); drop -F\n");

@@ -34,6 +34,7 @@ public:
         const int rc = lcrc_create_system(&ctx_, dir, system_.c_str(), nbanks_, trap_len_, add_c0_ ? 1 : 0,
                                           hamming_ ? 1 : 0, device_);
         if (rc != LCRC_OK) { err_ = lcrc_last_error(nullptr); ctx_ = nullptr; return false; }
+        lcrc_set_hidden_split(ctx_, hidden_split_);
         return true;
     }
     void Reset() { lcrc_reset(ctx_); }
@@ -51,6 +52,9 @@ public:
 
     // -- additions --
     void SetDevice(int d) { device_ = d; }
+    // lcrc_set_hidden_split: 0 = small launches spread a tile's hidden units over several workgroups (default),
+    // 1 = fused kernel only (a frame's output never depends on what else shares its launch)
+    void SetHiddenSplit(int v) { hidden_split_ = v; if (ctx_) lcrc_set_hidden_split(ctx_, v); }
     bool CalcUtterance(const float *mel, int n, float *post)
     {
         if (lcrc_posteriors(ctx_, mel, n, post) == LCRC_OK) return true;
@@ -130,7 +134,7 @@ public:
 private:
     lcrc_ctx *ctx_ = nullptr;
     std::string system_ = "LCRC", err_;
-    int trap_len_ = 31, nbanks_ = 15, bunch_ = 1, device_ = 0;
+    int trap_len_ = 31, nbanks_ = 15, bunch_ = 1, device_ = 0, hidden_split_ = 0;
     bool hamming_ = false, add_c0_ = true;
 };
 

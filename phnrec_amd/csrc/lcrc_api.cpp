@@ -66,10 +66,18 @@ struct lcrc_ctx {
     int *d_foff = nullptr, *h_foff = nullptr;
     float *d_means = nullptr;
     size_t cap_bytes = 0, cap_fe_utts = 0;
-    // streaming state: the 30 most recent frames (Traps::be_mat minus its newest slot)
-    std::vector<float> hist;
+    // streaming state (lcrc_push): the pushed frames live in a pinned, device-mapped strip whose last 30 rows
+    // are the history (Traps::be_mat minus its newest slot); the kernel reads the strip and writes the
+    // posteriors of a push in place (zero-copy), so a push costs no allocation and no copy command
+    float *h_ring = nullptr, *d_ring = nullptr;       // [ring_cap][nbanks], host and device view
+    float *h_pushout = nullptr, *d_pushout = nullptr; // [pushout_cap][n_out]
+    size_t ring_cap = 0, ring_rows = 0, pushout_cap = 0;
     bool hist_init = false;
     int delay = 0;
+    // split-hidden path (small launches): scratch for partial output tiles, operand images, tickets
+    float4 *d_part = nullptr, *d_gimg = nullptr;
+    unsigned *d_cnt = nullptr;
+    int split_hint = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = true, timed = false;
@@ -260,13 +268,19 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     return LCRC_OK;
 }
 
+// Rows [row_first, row_first + row_count) of the n_rows rows are computed (row_count < 0: all of them);
+// d_post receives row_first's posteriors first.
 int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
-           hipStream_t s, float *const *dbg)
+           hipStream_t s, float *const *dbg, int row_first = 0, int row_count = -1, bool timed = true)
 {
+    if (row_count < 0) { row_first = 0; row_count = n_rows; }
     if (c->system != SYS_LCRC) {
         if (dbg) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
+        if (row_first != 0 || row_count != n_rows)
+            return fail(c, LCRC_E_UNSUPPORTED, "row ranges exist for posteriors/system=LCRC only");
         return launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
     }
+    if (row_count == 0) return LCRC_OK;
     LcrcParams p;
     memset(&p, 0, sizeof p);
     for (int i = 0; i < 3; i++) p.net[i] = c->nets[i];
@@ -276,10 +290,15 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     fill_output_transform(c, p.out_func, p.out_c, p.out_l, &p.out_be);
     p.tile_frames = c->tile_frames;
     p.stamps = c->d_stamps;
+    p.row_first = row_first; p.row_end = row_first + row_count;
+    p.part = c->d_part; p.gimg = c->d_gimg; p.cnt = c->d_cnt;
+    p.split_cap_wgs = c->d_part ? kSplitCapWgs : 0;
+    p.split_hint = c->split_hint;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
+    timed = timed && c->timing;
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev0, s));
     HIP_TRY(c, lcrc_launch(p, s, nullptr));
-    if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
+    if (timed) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
     return LCRC_OK;
 }
 
@@ -323,7 +342,7 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
 }
 
 int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, float *post,
-             float *const *probes)
+             float *const *probes, bool decode = true)
 {
     const size_t nb = c->nbanks, O = c->nets[2].n_out;
     int rc = ensure_staging(c, n, n_utts);
@@ -354,7 +373,8 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
     }
     rc = launch(c, c->d_mel, d_off, off ? n_utts : 1, n, c->d_post, c->stream, any ? dbg : nullptr);
     if (rc) return rc;
-    if (c->dec_P > 0) {
+    const bool decoding = decode && c->dec_P > 0;
+    if (decoding) {
         if (!off) {                              // one utterance: the decoder still wants [0, n]
             c->h_off[0] = 0; c->h_off[1] = n;
             HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -362,7 +382,7 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
         rc = decode_after(c, c->d_off, c->h_off, off ? n_utts : 1, n, c->d_post, c->stream);
         if (rc) return rc;
     }
-    const bool copy_post = c->readback || c->dec_P <= 0;
+    const bool copy_post = c->readback || !decoding;
     if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (copy_post && post) memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
@@ -470,7 +490,6 @@ static int open_context(lcrc_ctx **out, int nbanks, int device_id)
         lcrc_destroy(c);
         return LCRC_E_DEVICE;
     }
-    c->hist.assign((size_t)(kTrapLen - 1) * nbanks, 0.f);
     *out = c;
     return LCRC_OK;
 }
@@ -523,6 +542,23 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
     }
     c->variant = v;
     c->trap_bands = 2;
+    {
+        // scratch of the split-hidden path (small launches): zeroed once, the kernels leave the tickets at zero
+        size_t pb = 0, gb = 0, cb = 0;
+        lcrc_split_scratch(c->nets, kSplitCapWgs, &pb, &gb, &cb);
+        void *part = nullptr, *gimg = nullptr, *cnt = nullptr;
+        if (hipMalloc(&part, pb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
+        c->allocs.push_back(part);
+        if (hipMalloc(&gimg, gb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
+        c->allocs.push_back(gimg);
+        if (hipMalloc(&cnt, cb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
+        c->allocs.push_back(cnt);
+        if (hipMemset(gimg, 0, gb) != hipSuccess || hipMemset(cnt, 0, cb) != hipSuccess) {
+            c->err = "cannot clear split scratch";
+            return bail(LCRC_E_DEVICE);
+        }
+        c->d_part = static_cast<float4 *>(part); c->d_gimg = static_cast<float4 *>(gimg); c->d_cnt = static_cast<unsigned *>(cnt);
+    }
     *out = c;
     return LCRC_OK;
 }
@@ -665,6 +701,8 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->d_foff) (void)hipFree(c->d_foff);
     if (c->h_foff) (void)hipHostFree(c->h_foff);
     if (c->d_means) (void)hipFree(c->d_means);
+    if (c->h_ring) (void)hipHostFree(c->h_ring);
+    if (c->h_pushout) (void)hipHostFree(c->h_pushout);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1066,38 +1104,113 @@ int lcrc_reset(lcrc_ctx *c)
 
 int lcrc_delay(const lcrc_ctx *c) { return c ? c->delay : LCRC_E_ARG; }
 
+// Room for `n` more rows behind the history in the pinned strip, and for n rows of output.
+static int ensure_ring(lcrc_ctx *c, size_t n)
+{
+    const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
+    if (c->ring_rows + n > c->ring_cap) {
+        if (H + n + n / 2 + 256 > c->ring_cap) {            // grow (keeps the history)
+            const size_t cap = std::max<size_t>(4096, 2 * (H + n) + 256);
+            float *h = nullptr, *d = nullptr;
+            HIP_TRY(c, hipHostMalloc((void **)&h, cap * nb * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+            if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed"); }
+            if (c->h_ring) {
+                const size_t keep = std::min(c->ring_rows, H);
+                memcpy(h, c->h_ring + (c->ring_rows - keep) * nb, keep * nb * sizeof(float));
+                (void)hipHostFree(c->h_ring);
+                c->ring_rows = keep;
+            }
+            c->h_ring = h; c->d_ring = d; c->ring_cap = cap;
+        } else {                                             // wrap: the history moves to the front
+            // (no kernel reads the strip now: every push that launches also waits for its kernel)
+            memmove(c->h_ring, c->h_ring + (c->ring_rows - H) * nb, H * nb * sizeof(float));
+            c->ring_rows = H;
+        }
+    }
+    if (n > c->pushout_cap) {
+        const size_t cap = n + n / 4 + 64;
+        if (c->h_pushout) (void)hipHostFree(c->h_pushout);
+        c->h_pushout = c->d_pushout = nullptr; c->pushout_cap = 0;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_pushout, cap * O * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        if (hipHostGetDevicePointer((void **)&c->d_pushout, c->h_pushout, 0) != hipSuccess) return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed");
+        c->pushout_cap = cap;
+    }
+    return LCRC_OK;
+}
+
 // Traps::CalcFeaturesBunched.  The reference slides a 31-slot window one frame at a
 // time (traps.cpp:180-219) and evaluates the nets on what the window holds after
-// each push.  Here the 30 frames of history are put in front of the pushed
-// frames and the whole-utterance kernel is run on that strip: row 15+i of the
-// strip has the window [i, i+30], i.e. exactly the ring contents after push i.
+// each push.  Here the pushed frames are appended to a strip whose preceding 30 rows are
+// the history: row 15+i of the strip [history | pushed] has the window [i, i+30], i.e. exactly
+// the ring contents after push i, so ONE launch on the row range [15, 15+n) of that strip
+// (30 rows of context, n rows computed) gives the n estimates.  The strip and the output are pinned
+// host memory the kernel reads / writes in place: a push is a host memcpy of the frames, the launch
+// (split over many workgroups when n is small), one stream wait and a memcpy of the posteriors.
 int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
 {
     if (!c) return LCRC_E_ARG;
     if (n < 0 || (n > 0 && !mel) || (n > 0 && needed && !post)) return fail(c, LCRC_E_ARG, "lcrc_push: bad argument");
     if (n == 0) return LCRC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
     const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
+    if (!c->hist_init) c->ring_rows = 0;
+    int rc = ensure_ring(c, (c->hist_init ? 0 : H) + (size_t)n);
+    if (rc) return rc;
     if (!c->hist_init) {                     // first frame floods the history (traps.cpp:184-200)
-        for (size_t i = 0; i < H; i++) memcpy(&c->hist[i * nb], mel, nb * sizeof(float));
+        for (size_t i = 0; i < H; i++) memcpy(c->h_ring + i * nb, mel, nb * sizeof(float));
+        c->ring_rows = H;
     }
-    std::vector<float> strip((H + n) * nb);
-    memcpy(strip.data(), c->hist.data(), H * nb * sizeof(float));
-    memcpy(strip.data() + H * nb, mel, (size_t)n * nb * sizeof(float));
+    const size_t first = c->ring_rows - H;   // strip = rows [first, first + H + n)
+    memcpy(c->h_ring + c->ring_rows * nb, mel, (size_t)n * nb * sizeof(float));
+    c->ring_rows += n;
     if (needed) {
-        HIP_TRY(c, hipSetDevice(c->device));
-        std::vector<float> out((H + n) * O);
         // (the streaming form never decodes: a chunk is not an utterance)
-        const int dec_P = c->dec_P;
-        c->dec_P = 0;
-        int rc = run_host(c, strip.data(), nullptr, 1, (int)(H + n), out.data(), nullptr);
-        c->dec_P = dec_P;
-        if (rc) return rc;
-        memcpy(post, out.data() + (size_t)kShift * O, (size_t)n * O * sizeof(float));
+        if (c->system == SYS_LCRC) {
+            rc = launch(c, c->d_ring + first * nb, nullptr, 1, (int)(H + n), c->d_pushout, c->stream, nullptr, kShift, n, false);
+            if (rc) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            memcpy(post, c->h_pushout, (size_t)n * O * sizeof(float));
+        } else {                             // the unfused systems compute the whole strip
+            rc = run_host(c, c->h_ring + first * nb, nullptr, 1, (int)(H + n), nullptr, nullptr, false);
+            if (rc) return rc;
+            memcpy(post, c->h_post + (size_t)kShift * O, (size_t)n * O * sizeof(float));
+        }
     }
-    memcpy(c->hist.data(), strip.data() + (size_t)n * nb, H * nb * sizeof(float));
     if (!c->hist_init) { c->hist_init = true; c->delay = n - 1; }
     else c->delay += n;
     if (c->delay > 9999) c->delay = 9999;
+    return LCRC_OK;
+}
+
+// Rows [row_first, row_first + row_count) of a strip of n_rows frames (one utterance, or a chunk of one with
+// its halos): the other rows are context only.
+int lcrc_posteriors_rows(lcrc_ctx *c, const float *mel, int n_rows, int row_first, int row_count, float *post)
+{
+    if (!c) return LCRC_E_ARG;
+    if (n_rows < 0 || row_first < 0 || row_count < 0 || row_first + (long long)row_count > n_rows ||
+        (row_count > 0 && (!mel || !post)))
+        return fail(c, LCRC_E_ARG, "lcrc_posteriors_rows: bad argument");
+    if (row_count == 0) return LCRC_OK;
+    if (c->system != SYS_LCRC) return fail(c, LCRC_E_UNSUPPORTED, "row ranges exist for posteriors/system=LCRC only");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nb = c->nbanks, O = c->nets[2].n_out;
+    int rc = ensure_staging(c, n_rows, 1);
+    if (rc) return rc;
+    memcpy(c->h_mel, mel, (size_t)n_rows * nb * sizeof(float));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n_rows * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = launch(c, c->d_mel, nullptr, 1, n_rows, c->d_post, c->stream, nullptr, row_first, row_count);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)row_count * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(post, c->h_post, (size_t)row_count * O * sizeof(float));
+    return LCRC_OK;
+}
+
+int lcrc_set_hidden_split(lcrc_ctx *c, int workgroups_per_tile)
+{
+    if (!c) return LCRC_E_ARG;
+    if (workgroups_per_tile < 0 || workgroups_per_tile > 64) return fail(c, LCRC_E_ARG, "lcrc_set_hidden_split: 0 (automatic), 1 (never) .. 64");
+    c->split_hint = workgroups_per_tile;
     return LCRC_OK;
 }
 

@@ -41,6 +41,19 @@ struct LcrcParams {
     float normc;         // sqrtf(2/16)
     int n_utts, n_rows, nbanks;
     int n_ot_slab;       // max n_ot over the three nets (set by lcrc_launch)
+    // Row range: only the rows [row_first, row_end) of the n_rows rows are computed (the others are context:
+    // streaming strips, chunks of a long file with halos); `post` points at the output of row_first.
+    // lcrc_launch fills in row_end = n_rows when it is 0.
+    int row_first, row_end;
+    // Split-hidden path (small launches; lcrc_launch decides): a frame tile's hidden dimension is spread
+    // over `split_*` workgroups of `tps_*` hidden tiles each, partial output tiles meet in `part` and the
+    // last arriver of a tile (ticket in `cnt`) finishes it.  Scratch owned by the context.
+    int split_b, tps_b, split_m, tps_m;
+    int split_hint;      // 0 = automatic, 1 = never split, k = at most k workgroups per tile (lcrc_set_hidden_split)
+    float4 *part;        // [workgroup][net (band phase: 2)][n_ot_slab][64] partial output tiles
+    float4 *gimg;        // [tile][nkq_merger][64] merger operand images handed from the band to the merger phase
+    unsigned *cnt;       // [tile][2] arrival tickets (band phase, merger phase); zero between launches
+    int split_cap_wgs;   // capacity of `part` in workgroups (`gimg`, `cnt`: as many tiles)
     int tile_frames;     // 0 = choose by launch size, 16 or 32 = forced (lcrc_set_tile_frames)
     // posterior writer path (lcrc_output_configure): softening stages and byte order of `post`
     int out_func[2];     // LCRC_SOFT_* per stage (0 = none)
@@ -79,6 +92,12 @@ __host__ __device__ inline LdsPlan lcrc_lds_plan(int ft, int nbanks, int nkq_ban
     p.slab = o;     o += two_slabs;                      // two slabs of [ot][f][64] float4
     p.total = o;
     return p;
+}
+
+// LDS of the split path's merger phase: operand image, four wave slabs, ticket word
+__host__ __device__ inline unsigned lcrc_split_merger_lds(int nkq_merger, int n_ot)
+{
+    return (unsigned)nkq_merger * 1024u + 4u * (unsigned)n_ot * 1024u + 16u;
 }
 
 inline int lcrc_n_ot_slab(const NetDev *nets)
@@ -144,6 +163,10 @@ hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream);
 
 // launcher (lcrc_kernels.hip)
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);
+// scratch the split-hidden path needs for `wgs` workgroups (bytes of part / gimg / cnt); 0,0,0 when the
+// model has no split kernels
+void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes);
+constexpr int kSplitCapWgs = 512;    // workgroups of a split launch (tiles x split) never exceed this
 // variant that WOULD be selected for these nets (no launch); NULL if unsupported
 const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes);
 

@@ -49,7 +49,50 @@
 
 namespace phnrec {
 
-template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT>
+// The last-arriver seam of the split-hidden path (guide recipe: plain slab stores, every wave drains its
+// stores, barrier, ONE lane releases at agent scope and draws a ticket; the workgroup that draws the last
+// ticket acquires at agent scope and reads every slab).  Returns true in the workgroup that finishes the tile.
+// Correct for any placement of a tile's workgroups over CUs / XCDs; nobody waits for anybody.
+__device__ __forceinline__ bool split_arrive(unsigned *counter, int n_arrivals, int *lds_ticket, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *lds_ticket = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*lds_ticket != n_arrivals - 1) return false;
+    if (tid == 0) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return true;
+}
+
+// dst[i] = src[i] + src[stride + i] + ... (n_parts slabs, added in slab order: a fixed association)
+__device__ __forceinline__ f4 split_sum(const f4 *src, size_t stride, int n_parts)
+{
+    f4 a = src[0];
+    int s = 1;
+    for (; s + 3 < n_parts; s += 4) {           // four independent loads in flight, added in order
+        const f4 b0 = src[(size_t)s * stride], b1 = src[(size_t)(s + 1) * stride];
+        const f4 b2 = src[(size_t)(s + 2) * stride], b3 = src[(size_t)(s + 3) * stride];
+        a += b0; a += b1; a += b2; a += b3;
+    }
+    for (; s < n_parts; s++) a += src[(size_t)s * stride];
+    return a;
+}
+
+// SPLIT = false: the fused kernel, one workgroup per frame tile, everything up to the posteriors.
+// SPLIT = true:  band phase of the split-hidden path (small launches): p.split_b workgroups per frame tile,
+//                each runs stages 0/1 and its slice of the band nets' hidden tiles; the last arriver of a tile
+//                adds the partial output tiles, runs the band softmax and hands the merger's operand image to
+//                lcrc_split_merger_kernel through p.gimg.
+template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
     constexpr int BM = 16 * FT;                 // frames per workgroup
@@ -77,7 +120,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     float *gf = reinterpret_cast<float *>(smem + lp.gf);
     f4 *slab = reinterpret_cast<f4 *>(smem + lp.slab);
 
-    const int r0 = blockIdx.x * BM;
+    const int split = SPLIT ? p.split_b : 1;
+    const int tile = SPLIT ? (int)blockIdx.x / split : (int)blockIdx.x;
+    const int sp = SPLIT ? (int)blockIdx.x - tile * split : 0;
+    const int r0 = p.row_first + tile * BM;
     const int tbase = r0 - kShift;
 
     LCRC_STAMP(p, wave, lane, 0);
@@ -175,8 +221,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     {
         const int K = p.net[0].n_inp;            // nbanks * 11
         const float normc = p.normc;
-        const int n_rows = p.n_rows;
-        float *const dbg_in0 = p.dbg_in0, *const dbg_in1 = p.dbg_in1;
+        const int n_rows = p.n_rows, row_end = p.row_end;
+        float *const dbg_in0 = p.dbg_in0, *const dbg_in1 = p.dbg_in1;    // (probes: whole-range launches only)
         const int g = lane >> 4, c = lane & 15;
         float basis[4];
 #pragma unroll
@@ -258,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
                         for (int reg = 0; reg < 4; reg++) {
                             const int fr = 16 * f + 4 * g + reg;
-                            if (r0 + fr < n_rows) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
+                            if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
                         }
                 }
             }
@@ -279,7 +325,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     {
         // kernel arguments used per value live in locals: fields of `p` are re-read from the kernarg
         // segment (a scalar load + wait) behind every memory fence and barrier
-        const int O0 = p.net[0].n_out, O1 = p.net[1].n_out, n_rows = p.n_rows, merger_inp = nm.n_inp;
+        const int O0 = p.net[0].n_out, O1 = p.net[1].n_out, n_rows = p.row_end, merger_inp = nm.n_inp;
         float *const dbg_p0 = p.dbg_p0, *const dbg_p1 = p.dbg_p1, *const dbg_g = p.dbg_g;
         const bool probes = dbg_p0 || dbg_p1 || dbg_g;              // NULL in production
         auto epi = [&](int n, int i, int o, float q, bool valid) {
@@ -294,13 +340,58 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             v *= mdev[kofs + o];
             if (valid) xf_store(gf, nkqm, i, kofs + o, v);
         };
+        if constexpr (SPLIT) {
+            // ---- band phase of the split-hidden path: this workgroup's slice of both nets' hidden tiles ----
+            constexpr int NTH = NW * 64;
+            const int grp = wave / 2, wig = wave % 2;           // waves 0,1: left context; 2,3: right context
+            const NetDev &nd = p.net[grp];
+            const int hbeg = min(nd.nht, sp * p.tps_b), hend = min(nd.nht, hbeg + p.tps_b);
+            const int tpw = (hend - hbeg + 1) / 2;
+            const int ht0 = hbeg + wig * tpw;
+            const int slab_f4 = FT * n_ot * 64;
+            f4 *const slab23 = reinterpret_cast<f4 *>(smem + lp.slab23);
+            {
+                f4 acc[NOT][FT];
+                hidden_range<KS1, NOT, EXACT, FT>(nd, reinterpret_cast<const f4 *>(xf) + (size_t)grp * (FT * nkq1 * 64), ht0,
+                                                  min(hend, ht0 + tpw), sp == 0 && wig == 0, lane, acc);
+                __syncthreads();                                 // slab23 lies over the operand images
+                store_partial<NOT, EXACT, FT>((grp == 0 ? slab : slab23) + wig * slab_f4, EXACT ? NOT : nd.n_ot, lane, acc);
+                __syncthreads();
+            }
+            // the workgroup's partial tiles (wave 0 + wave 1 per net) leave as whole 1-KiB wave stores
+            f4 *const mine = reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * 2 * slab_f4;
+            for (int i = tid; i < 2 * slab_f4; i += NTH) {
+                const int gq = i >= slab_f4 ? 1 : 0, j = i - gq * slab_f4;
+                const f4 *b = gq ? slab23 : slab;
+                mine[i] = b[j] + b[slab_f4 + j];
+            }
+            int *const ticket = reinterpret_cast<int *>(smem + lp.total);
+            if (!split_arrive(p.cnt + 2 * tile, split, ticket, tid)) return;
+            // last arriver: add the tile's partials in slice order, then softmax + ln() as in the fused kernel
+            const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)tile * split * 2 * slab_f4;
+            for (int i = tid; i < 2 * slab_f4; i += NTH) {
+                const int gq = i >= slab_f4 ? 1 : 0, j = i - gq * slab_f4;
+                (gq ? slab23 : slab)[j] = split_sum(first + i, (size_t)2 * slab_f4, split);
+            }
+            __syncthreads();
+            const float *s01 = reinterpret_cast<const float *>(slab), *s23 = reinterpret_cast<const float *>(slab23);
+            const float *const P[2][4] = {{s01, s01, s01, s01}, {s23, s23, s23, s23}};
+            softmax_rows<NOT, NW, FT, 2, 1>(p, p.net, P, lane, wave, epi);
+            __syncthreads();
+            f4 *const dst = reinterpret_cast<f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
+            const f4 *const src = reinterpret_cast<const f4 *>(gf);
+            for (int i = tid; i < FT * nkqm * 64; i += NTH) dst[i] = src[i];
+            return;
+        } else {
         // (the sequential alternative -- one band net after the other on four waves -- was 1.6-3 % slower in
         //  same-GPU A/B runs, profiles/r01_ab_runs.txt)
         run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
                                             reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
+        }
     }
 
+    if constexpr (!SPLIT) {
     // ---- stage 3: merger; posteriors are gathered as contiguous rows in LDS (slab 0 is
     //      free again) and leave as one linear, 16-byte-per-lane copy ----
     {
@@ -323,15 +414,89 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
                                             reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
-        const int rows = min(BM, p.n_rows - r0);
+        const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;
-        float *dst = p.post + (size_t)r0 * O;      // 16*O*4 bytes per frame tile: 16-byte aligned
+        float *dst = p.post + (size_t)(r0 - p.row_first) * O;      // 16*O*4 bytes per frame tile: 16-byte aligned
         const int n4 = total >> 2;
         for (int i = tid; i < n4; i += NT)
             reinterpret_cast<f4 *>(dst)[i] = reinterpret_cast<const f4 *>(outbuf)[i];
         for (int i = (n4 << 2) + tid; i < total; i += NT) dst[i] = outbuf[i];
     }
+    }
     LCRC_STAMP(p, wave, lane, 11);
+}
+
+
+// Merger phase of the split-hidden path: p.split_m workgroups per frame tile, each on tps_m hidden tiles of the
+// merger (its four waves share them); the last arriver adds the partial tiles in slice order, runs the
+// softmax and the writer path and stores the tile's posteriors.
+template <int KSM, int NOT, int NW, bool EXACT, int FT>
+__global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcParams p)
+{
+    constexpr int BM = 16 * FT, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NetDev &nm = p.net[2];
+    const int nkqm = EXACT ? (KSM + 3) / 4 : nm.nkq;
+    const int n_ot = EXACT ? NOT : p.n_ot_slab;
+    const int slab_f4 = FT * n_ot * 64;
+    f4 *const gf = reinterpret_cast<f4 *>(smem);
+    f4 *const slab = gf + FT * nkqm * 64;                       // four wave slabs
+    int *const ticket = reinterpret_cast<int *>(slab + 4 * slab_f4);
+    const int split = p.split_m;
+    const int tile = (int)blockIdx.x / split, sp = (int)blockIdx.x - tile * split;
+    const int r0 = p.row_first + tile * BM;
+
+    {
+        const f4 *const src = reinterpret_cast<const f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
+        for (int i = tid; i < FT * nkqm * 64; i += NT) gf[i] = src[i];
+    }
+    __syncthreads();
+    {
+        const int hbeg = min(nm.nht, sp * p.tps_m), hend = min(nm.nht, hbeg + p.tps_m);
+        const int tpw = (hend - hbeg + NW - 1) / NW;
+        const int ht0 = hbeg + wave * tpw;
+        f4 acc[NOT][FT];
+        hidden_range<KSM, NOT, EXACT, FT>(nm, gf, min(hend, ht0), min(hend, ht0 + tpw), sp == 0 && wave == 0, lane, acc);
+        store_partial<NOT, EXACT, FT>(slab + wave * slab_f4, EXACT ? NOT : nm.n_ot, lane, acc);
+        __syncthreads();
+    }
+    f4 *const mine = reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * slab_f4;
+    for (int i = tid; i < slab_f4; i += NT)
+        mine[i] = (slab[i] + slab[slab_f4 + i]) + (slab[2 * slab_f4 + i] + slab[3 * slab_f4 + i]);
+    if (!split_arrive(p.cnt + 2 * tile + 1, split, ticket, tid)) return;
+    const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)tile * split * slab_f4;
+    for (int i = tid; i < slab_f4; i += NT) slab[i] = split_sum(first + i, (size_t)slab_f4, split);
+    __syncthreads();
+
+    const int O = nm.n_out;
+    float *outbuf = reinterpret_cast<float *>(slab + slab_f4);   // slabs 1.. are free
+    const int f0 = p.out_func[0], f1 = p.out_func[1], be = p.out_be;
+    float c0[3], c1[3], l0[2], l1[2];
+    for (int i = 0; i < 3; i++) { c0[i] = p.out_c[0][i]; c1[i] = p.out_c[1][i]; }
+    for (int i = 0; i < 2; i++) { l0[i] = p.out_l[0][i]; l1[i] = p.out_l[1][i]; }
+    const bool transform = (f0 | f1 | be) != 0;
+    auto epi = [&](int, int i, int o, float q, bool valid) {
+        if (transform) {                     // posterior writer path: softening, byte order
+            q = soften(f0, c0, l0, q);
+            q = soften(f1, c1, l1, q);
+            if (be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
+        }
+        if (valid) outbuf[i * O + o] = q;
+    };
+    const float *s0 = reinterpret_cast<const float *>(slab);
+    const float *const P[1][4] = {{s0, s0, s0, s0}};
+    softmax_rows<NOT, NW, FT, 1, 1>(p, &nm, P, lane, wave, epi);
+    __syncthreads();
+    const int rows = min(BM, p.row_end - r0);
+    const int total = rows * O;
+    float *dst = p.post + (size_t)(r0 - p.row_first) * O;
+    const int n4 = total >> 2;
+    for (int i = tid; i < n4; i += NT)
+        reinterpret_cast<f4 *>(dst)[i] = reinterpret_cast<const f4 *>(outbuf)[i];
+    for (int i = (n4 << 2) + tid; i < total; i += NT) dst[i] = outbuf[i];
 }
 
 // ---- variants --------------------------------------------------------------------------
@@ -346,11 +511,14 @@ struct Variant {
     const char *name;
     int ks1, ksm, n_ot;    // 0,0,0 = generic
     const void *fn[2];     // [FT - 1]: 16- and 32-frame workgroups
+    const void *split_band, *split_merger;   // split-hidden path, 16-frame tiles
 };
 
 #define LCRC_KERNEL(KS1, KSM, NOT, EX) \
-    {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1>), \
-     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 2>)}
+    {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, false>), \
+     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 2, false>)}, \
+    reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, true>), \
+    reinterpret_cast<const void *>(&lcrc_split_merger_kernel<KSM, NOT, kNW, EX, 1>)
 
 const Variant kVariants[] = {
     {"cz_42_69_9", 42, 69, 9, LCRC_KERNEL(42, 69, 9, true)},
@@ -359,6 +527,7 @@ const Variant kVariants[] = {
     {"en_64_60_8", 64, 60, 8, LCRC_KERNEL(64, 60, 8, true)},
     {"generic", 0, 0, 0, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false)},
 };
+constexpr int kNVariants = sizeof kVariants / sizeof kVariants[0];
 
 const Variant *pick(const NetDev *nets)
 {
@@ -368,7 +537,7 @@ const Variant *pick(const NetDev *nets)
             return &v;
     if (nets[0].ksteps <= kGenKS1 && nets[1].ksteps == nets[0].ksteps && nets[2].ksteps <= kGenKSM &&
         nets[0].n_ot <= kGenNOT && nets[1].n_ot <= kGenNOT && nets[2].n_ot <= kGenNOT)
-        return &kVariants[sizeof kVariants / sizeof kVariants[0] - 1];
+        return &kVariants[kNVariants - 1];
     return nullptr;
 }
 
@@ -386,6 +555,46 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
     return v->name;
 }
 
+void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes)
+{
+    const size_t slab = (size_t)lcrc_n_ot_slab(nets) * 1024u;          // one 16-frame partial tile
+    *part_bytes = (size_t)wgs * 2 * slab;
+    *gimg_bytes = (size_t)wgs * nets[2].nkq * 1024u;
+    *cnt_bytes = (size_t)wgs * 2 * sizeof(unsigned);
+}
+
+namespace {
+
+// > 64 KiB of dynamic LDS has to be granted per function and per device: once, not per launch
+// (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
+hipError_t grant_lds(const void *fn, int vi, int slot, int dev)
+{
+    static std::atomic<bool> granted[kNVariants][4][64] = {};
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached && granted[vi][slot][dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && cached) granted[vi][slot][dev] = true;
+    return e;
+}
+
+// Workgroups per frame tile of the split-hidden path for a launch of `tiles` 16-frame tiles, 1 = fused kernel.
+// Automatic choice: launches whose 16-frame tiles would leave at least half of the CUs idle spread every
+// tile's hidden dimension over as many workgroups as CUs allow, up to kSplitMax (beyond it the last
+// arriver's slab reads cost more than the shorter hidden slices save).
+constexpr int kSplitMax = 12;
+int choose_split(const LcrcParams &p, int tiles, int n_cu)
+{
+    if (!p.part || !p.gimg || !p.cnt || p.split_hint == 1 || tiles <= 0) return 1;
+    if (p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g || p.stamps) return 1;   // probes: fused kernel only
+    int s = n_cu / tiles;
+    if (p.split_hint > 1) s = p.split_hint;          // forced: may oversubscribe the CUs (tuning)
+    else s = min(s, kSplitMax);
+    s = min(s, p.split_cap_wgs / tiles);
+    return s < 2 ? 1 : s;
+}
+
+}  // namespace
+
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name)
 {
     const Variant *v = pick(p.net);
@@ -394,10 +603,11 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     if (!fits32 && lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
         return hipErrorInvalidValue;
     if (variant_name) *variant_name = v->name;
-    if (p.n_rows <= 0) return hipSuccess;
-    // > 64 KiB of dynamic LDS has to be granted per function and per device: once, not per launch
-    // (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
-    static std::atomic<bool> granted[sizeof kVariants / sizeof kVariants[0]][2][64] = {};
+    LcrcParams args = p;
+    if (args.row_end == 0) { args.row_first = 0; args.row_end = p.n_rows; }
+    if (args.row_first < 0 || args.row_end > p.n_rows || args.row_first > args.row_end) return hipErrorInvalidValue;
+    const int rows = args.row_end - args.row_first;
+    if (p.n_rows <= 0 || rows <= 0) return hipSuccess;
     static std::atomic<int> cus[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -409,24 +619,44 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         if (e != hipSuccess) return e;
         if (cached) cus[dev] = n_cu;
     }
+    const int vi = (int)(v - kVariants);
+    args.n_ot_slab = lcrc_n_ot_slab(p.net);
+    void *kargs[] = {&args};
+    const dim3 block(kNW * 64);
+
+    // ---- split-hidden path: two launches (band phase, merger phase) on 16-frame tiles ----
+    const int tiles16 = (rows + 15) / 16;
+    const int split = p.tile_frames == 32 ? 1 : choose_split(p, tiles16, n_cu);
+    if (split > 1) {
+        const int nht_b = max(p.net[0].nht, p.net[1].nht), nht_m = p.net[2].nht;
+        // at least one hidden tile per wave: two waves per band net, four on the merger
+        const int sb = max(1, min(split, nht_b / 2)), sm = max(1, min(split, nht_m / 4));
+        args.tps_b = (nht_b + sb - 1) / sb;
+        args.split_b = (nht_b + args.tps_b - 1) / args.tps_b;      // no empty slices
+        args.tps_m = (nht_m + sm - 1) / sm;
+        args.split_m = (nht_m + args.tps_m - 1) / args.tps_m;
+        const LdsPlan lp = lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, args.n_ot_slab);
+        e = grant_lds(v->split_band, vi, 2, dev);
+        if (e != hipSuccess) return e;
+        e = grant_lds(v->split_merger, vi, 3, dev);
+        if (e != hipSuccess) return e;
+        e = hipLaunchKernel(v->split_band, dim3(tiles16 * args.split_b), block, kargs, lp.total + 16, stream);
+        if (e != hipSuccess) return e;
+        return hipLaunchKernel(v->split_merger, dim3(tiles16 * args.split_m), block, kargs,
+                               lcrc_split_merger_lds(p.net[2].nkq, args.n_ot_slab), stream);
+    }
+
     // 32-frame workgroups load every weight fragment once per 32 frames; 16-frame workgroups twice as
     // often, but there are twice as many of them: they win while the 32-frame grid would leave at
     // least half of the CUs without work.
-    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
+    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
     if (!fits32) ft = 1;
-    const int vi = (int)(v - kVariants);
     const void *fn = v->fn[ft - 1];
-    if (!cached || !granted[vi][ft - 1][dev]) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        if (cached) granted[vi][ft - 1][dev] = true;
-    }
+    e = grant_lds(fn, vi, ft - 1, dev);
+    if (e != hipSuccess) return e;
     const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
     const int bm = 16 * ft;
-    const dim3 grid((p.n_rows + bm - 1) / bm), block(kNW * 64);
-    LcrcParams args = p;
-    args.n_ot_slab = lcrc_n_ot_slab(p.net);
-    void *kargs[] = {&args};
+    const dim3 grid((rows + bm - 1) / bm);
     return hipLaunchKernel(fn, grid, block, kargs, lp.total, stream);
 }
 

@@ -340,6 +340,116 @@ struct RingLoop {
     }
 };
 
+// Layer-2 partial sums of ONE wave over the hidden tiles [ht0, ht1) of net `nd` (an empty range gives the
+// bias or zeros): acc[ot][f][rr] = O^T[16ot + 4g + rr][16f + (lane&15)], started from the output bias
+// (PrepareBiases nn.cpp:857) when with_b2.
+template <int KS, int NOT, bool EXACT, int FT>
+__device__ __forceinline__ void hidden_range(const NetDev &nd, const f4 *XF, int ht0, int ht1, bool with_b2, int lane,
+                                             f4 (&acc)[NOT][FT])
+{
+    const int n_ot = EXACT ? NOT : nd.n_ot;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NOT; ot++) {
+        f4 b = {0.f, 0.f, 0.f, 0.f};
+        if (with_b2 && (EXACT || ot < n_ot))
+            b = *reinterpret_cast<const f4 *>(nd.b2 + 16 * ot + 4 * g);
+#pragma unroll
+        for (int f = 0; f < FT; f++) acc[ot][f] = b;
+    }
+    RingLoop<KS, NOT, FT, EXACT> loop;
+    // pointers into locals: kernarg fields would be re-read behind every memory fence
+    loop.w1 = reinterpret_cast<const f4 *>(nd.w1p);
+    loop.w2 = reinterpret_cast<const f4 *>(nd.w2p);
+    loop.b1 = nd.b1; loop.XF = XF; loop.lane = lane;
+    loop.hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+    loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
+    loop.run(acc, ht0, ht1);
+}
+
+// One wave's partial tile into its LDS slab ([ot][f][64] float4)
+template <int NOT, bool EXACT, int FT>
+__device__ __forceinline__ void store_partial(f4 *slab, int n_ot, int lane, const f4 (&acc)[NOT][FT])
+{
+    f4 *s = slab + lane;
+#pragma unroll
+    for (int ot = 0; ot < NOT; ot++)
+        if (EXACT || ot < n_ot) {
+#pragma unroll
+            for (int f = 0; f < FT; f++) s[(ot * FT + f) * 64] = acc[ot][f];
+        }
+}
+
+// Softmax (nn.cpp:822-855) in registers on all threads over output tiles that lie in LDS slabs: group g's
+// pre-activations are the sum of its NPART partial slabs P[g][0..NPART) -- 1: as is, 2: p0 + p1,
+// 4: (p0 + p1) + (p2 + p3), a fixed order.  LPF lanes share a (net, frame) row, each holds every LPF-th
+// output.  Element (o, frame) of a slab: o = 16ot + 4g + rr, frame = 16f + c  ->  float index
+// ((FT*ot + f)*64 + 16g + c)*4 + rr.  Ends like run_net (epi called, one __syncthreads() before the calls).
+template <int NOT, int NW, int FT, int GROUPS, int NPART, typename Params, typename Epi>
+__device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *nets, const float *const (&P)[GROUPS][4],
+                                             int lane, int wave, Epi epi)
+{
+    constexpr int BM = 16 * FT;
+    constexpr int LPF = NW * 64 / (GROUPS * BM);   // lanes cooperating on one row
+    constexpr int NV = 16 * NOT / LPF;             // values per lane
+    static_assert(LPF == 4 || LPF == 8 || LPF == 16, "softmax lane groups are 4, 8 or 16 wide");
+    static_assert(NPART == 1 || NPART == 2 || NPART == 4, "1, 2 or 4 partial slabs");
+    const int tid = wave * 64 + lane;
+    const int row = tid / LPF, part = tid % LPF;
+    const int rg = GROUPS == 1 ? 0 : row / BM;     // wave-uniform: a wave's rows belong to one net
+    const int frame = GROUPS == 1 ? row : row % BM;
+    const float *sa = P[rg][0], *sb = P[rg][NPART > 1 ? 1 : 0];
+    const float *sc = P[rg][NPART > 2 ? 2 : 0], *sd = P[rg][NPART > 2 ? 3 : 0];
+    // o = part + LPF*j: because LPF is a multiple of 4 and part < LPF <= 16, the slab index of o splits
+    // into a per-thread part and a COMPILE-TIME part of j (no carries between the bit fields), so the
+    // reads below are base + immediate offset
+    const int pbase = ((frame >> 4) * 64 + (frame & 15)) * 4 + ((part >> 2) & 3) * 64 + (part & 3);
+    const int O = nets[rg].n_out;
+    float v[NV];
+    float m = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int o = part + LPF * j;
+        // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
+        // unconditionally so the LDS reads are issued back to back, select afterwards
+        const int idx = pbase + ((LPF * j) >> 4) * (256 * FT) + (((LPF * j) >> 2) & 3) * 64;
+        float t = sa[idx];
+        if (NPART >= 2) t += sb[idx];
+        if (NPART == 4) t += sc[idx] + sd[idx];        // waves (0 + 1) + (2 + 3): a fixed order
+        v[j] = o < O ? t : -FLT_MAX;
+        m = fmaxf(m, v[j]);
+    }
+    m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
+    // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly (pairs, then
+    // quads, then halves of 8, then the two halves), whatever LPF is: with fewer than 16 lanes per row a
+    // lane carries 16 / LPF of the partials and the last butterfly steps become plain adds -- so every
+    // geometry (16- or 32-frame workgroups, one or two nets at a time) produces the same bits.
+    constexpr int PPL = 16 / LPF;                  // partials per lane
+    float ps[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; q++) ps[q] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
+        v[j] = part + LPF * j < O ? e : 0.0f;
+        ps[j % PPL] += v[j];
+    }
+#pragma unroll
+    for (int q = 0; q < PPL; q++) ps[q] = allreduce<LPF>(ps[q], [](float a, float b) { return a + b; });
+    float sum;
+    if constexpr (PPL == 1) sum = ps[0];
+    else if constexpr (PPL == 2) sum = ps[0] + ps[1];
+    else sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    const float scale = 1.0f / sum;
+    __syncthreads();                          // slabs are free again (the epilogue may reuse them)
+    LCRC_STAMP(prm, wave, lane, 13);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int o = part + LPF * j;
+        epi(rg, frame, o, v[j] * scale, o < O);   // o may be a pad output (>= O): loads only, no store
+    }
+}
+
 // Runs GROUPS nets of the same shape class at once, each on NW / GROUPS waves (GROUPS = 1: one net on all
 // waves; GROUPS = 2: the two band classifiers of LCRC side by side on wave pairs -- one hidden loop, one
 // softmax phase and no fold round instead of two of each).  nets[g] / XF + g * xf_stride belong to group g.
@@ -358,10 +468,14 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     constexpr int WPG = NW / GROUPS;             // waves per net
     const int grp = GROUPS == 1 ? 0 : wave / WPG, wig = GROUPS == 1 ? wave : wave % WPG;
     const NetDev &nd = nets[grp];
-    const f4 *XF = XFbase + (size_t)grp * xf_stride;
     const int n_ot = EXACT ? NOT : nd.n_ot;
+    const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
+    const f4 *XF = XFbase + (size_t)grp * xf_stride;
     const int g = lane >> 4;
 
+    // (this is hidden_range() + store_partial(), spelled out: as calls they compile to the same arithmetic
+    //  but hipcc's register allocation of the 32-frame variants gets worse -- 57 instead of 1 AGPR copies
+    //  for cz_42_69_9, accvgpr moves inside the merger's loop, 2 % slower in same-GPU A/B runs)
     // layer-2 accumulators: acc[ot][f][rr] = O^T[16ot + 4g + rr][16f + (lane&15)]
     f4 acc[NOT][FT];
 #pragma unroll
@@ -390,7 +504,6 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
-    const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
     {
         // No fold round: every wave publishes its partial tile in a slab of its own and the softmax adds
         // them while it reads (two per net when two nets share the waves, four otherwise).  slab23 may lie over
@@ -407,68 +520,13 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         __syncthreads();
     }
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
-    // Softmax (nn.cpp:822-855) in registers on all threads: LPF lanes share a (net, frame) row, each
-    // holds every LPF-th output.  Element (o, frame) of a slab: o = 16ot + 4g + rr,
-    // frame = 16f + c  ->  float index ((FT*ot + f)*64 + 16g + c)*4 + rr.
-    {
-        constexpr int BM = 16 * FT;
-        constexpr int LPF = NW * 64 / (GROUPS * BM);   // lanes cooperating on one row
-        constexpr int NV = 16 * NOT / LPF;             // values per lane
-        static_assert(LPF == 4 || LPF == 8 || LPF == 16, "softmax lane groups are 4, 8 or 16 wide");
-        const int tid = wave * 64 + lane;
-        const int row = tid / LPF, part = tid % LPF;
-        const int rg = GROUPS == 1 ? 0 : row / BM;     // wave-uniform: a wave's rows belong to one net
-        const int frame = GROUPS == 1 ? row : row % BM;
-        const float *sa = reinterpret_cast<const float *>(rg == 0 ? slab01 : slab23);
-        const float *sb = sa + slab_f4 * 4;
-        const float *sc = reinterpret_cast<const float *>(slab23), *sd = sc + slab_f4 * 4;   // GROUPS == 1
-        // o = part + LPF*j: because LPF is a multiple of 4 and part < LPF <= 16, the slab index of o splits
-        // into a per-thread part and a COMPILE-TIME part of j (no carries between the bit fields), so the
-        // reads below are base + immediate offset
-        const int pbase = ((frame >> 4) * 64 + (frame & 15)) * 4 + ((part >> 2) & 3) * 64 + (part & 3);
-        const int O = nets[rg].n_out;
-        float v[NV];
-        float m = -FLT_MAX;
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const int o = part + LPF * j;
-            // o < 16*NOT always addresses the slab (pad outputs hold zero weights' sums): read
-            // unconditionally so the LDS reads are issued back to back, select afterwards
-            const int idx = pbase + ((LPF * j) >> 4) * (256 * FT) + (((LPF * j) >> 2) & 3) * 64;
-            float t = sa[idx] + sb[idx];
-            if (GROUPS == 1) t += sc[idx] + sd[idx];       // waves (0 + 1) + (2 + 3): a fixed order
-            v[j] = o < O ? t : -FLT_MAX;
-            m = fmaxf(m, v[j]);
-        }
-        m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
-        // The sum is grouped as 16 strided partials (o mod 16) combined by a fixed butterfly (pairs, then
-        // quads, then halves of 8, then the two halves), whatever LPF is: with fewer than 16 lanes per row a
-        // lane carries 16 / LPF of the partials and the last butterfly steps become plain adds -- so every
-        // geometry (16- or 32-frame workgroups, one or two nets at a time) produces the same bits.
-        constexpr int PPL = 16 / LPF;                  // partials per lane
-        float ps[PPL];
-#pragma unroll
-        for (int q = 0; q < PPL; q++) ps[q] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
-            v[j] = part + LPF * j < O ? e : 0.0f;
-            ps[j % PPL] += v[j];
-        }
-#pragma unroll
-        for (int q = 0; q < PPL; q++) ps[q] = allreduce<LPF>(ps[q], [](float a, float b) { return a + b; });
-        float sum;
-        if constexpr (PPL == 1) sum = ps[0];
-        else if constexpr (PPL == 2) sum = ps[0] + ps[1];
-        else sum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        const float scale = 1.0f / sum;
-        __syncthreads();                          // slabs are free again (the epilogue may reuse them)
-        LCRC_STAMP(prm, wave, lane, 13);
-#pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const int o = part + LPF * j;
-            epi(rg, frame, o, v[j] * scale, o < O);   // o may be a pad output (>= O): loads only, no store
-        }
+    const float *s01 = reinterpret_cast<const float *>(slab01), *s23 = reinterpret_cast<const float *>(slab23);
+    if constexpr (GROUPS == 2) {
+        const float *const P[2][4] = {{s01, s01 + slab_f4 * 4, s01, s01}, {s23, s23 + slab_f4 * 4, s23, s23}};
+        softmax_rows<NOT, NW, FT, 2, 2>(prm, nets, P, lane, wave, epi);
+    } else {
+        const float *const P[1][4] = {{s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4}};
+        softmax_rows<NOT, NW, FT, 1, 4>(prm, nets, P, lane, wave, epi);
     }
     __syncthreads();
 }

@@ -79,6 +79,7 @@ def test_synthetic_goldens_all_shapes(capi, tmp_path):
         nets = modelgen.write_model_dir(str(d), nb, hid, nout, seed=seed)
         assert bytes(g[name + "/digest"]).hex() == modelgen.nets_digest(nets)
         ctx = capi.Lcrc(str(d), nb)
+        ctx.set_hidden_split(1)            # fused kernel only: batching must not change a single bit
         seen.add(ctx.kernel_name)
         off = g[name + "/off"]
         mel, want = g[name + "/mel"], g[name + "/post"]
@@ -138,6 +139,124 @@ def test_streaming_push_matches_traps_semantics(capi, oracle_mod, tmp_path):
         assert np.abs(a - b).max() < TOL
         pos += n
         assert ctx.delay() == o.delay()
+
+
+def test_streaming_bunches_of_five_over_a_long_stream(capi, oracle_mod, tmp_path):
+    """the shipped bunch_size=5 (PHN_*/config:11, traps.cpp:518-535) over a stream long enough to wrap and to
+    regrow the pinned strip: every bunch equals the whole-utterance rows it corresponds to (window ending at
+    pushed frame i is centred at i - 15) and the oracle's ring buffer on spot checks"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 64, 24, seed=13)
+    o = oracle_mod.Oracle(d, 15)
+    ctx = capi.Lcrc(d, 15)
+    n = 4700                                            # > the strip's 4096 rows: one wrap
+    mel = modelgen.synth_mel(n, 15, seed=5)
+    whole = ctx.posteriors(mel)
+    ctx.reset()
+    o.reset()
+    got = []
+    for pos in range(0, n, 5):
+        a = ctx.push(mel[pos:pos + 5])
+        got.append(a)
+        if pos < 100 or pos % 1000 == 0:
+            b = o.push(mel[pos:pos + 5], needed=True)
+            assert np.abs(a - b).max() < TOL, pos
+        else:
+            o.push(mel[pos:pos + 5], needed=False)
+    got = np.concatenate(got)
+    assert np.abs(got[15:] - whole[:n - 15]).max() < 1e-5
+    assert ctx.delay() == min(9999, n - 1)
+    # a bunch larger than the strip makes it grow, history kept
+    big = modelgen.synth_mel(9000, 15, seed=6)
+    a = ctx.push(big)
+    joined = np.concatenate([mel, big])
+    want = ctx.posteriors(joined[n - 30:])[15:15 + 9000]
+    assert np.abs(a - want).max() < 1e-5
+    # pushes that are not needed only advance the history
+    assert ctx.push(big[:7], needed=False) is None
+    b = ctx.push(big[7:12])
+    want = ctx.posteriors(np.concatenate([big[-30:], big[:12]]))[15 + 7:15 + 12]
+    assert np.abs(b - want).max() < 1e-5
+
+
+def test_split_hidden_path(capi, oracle_mod, tmp_path):
+    """small launches spread every frame tile's hidden dimension over several workgroups (two launches, partial
+    output tiles added by the last arriver in slice order): against the oracle and against the fused kernel for
+    the shipped shapes and the generic kernel, every launch size class, forced and automatic splits; each
+    setting is deterministic, the fused setting is bit-identical however the frames are batched"""
+    cases = [(model_dir("PHN_CZ_SPDAT_LCRC_N1500"), 15, "cz_42_69_9"), (model_dir("PHN_EN_TIMIT_LCRC_N500"), 23, "en_64_60_8"),
+             (model_dir("PHN_HU_SPDAT_LCRC_N1500"), 15, "hu_42_93_12"), (model_dir("PHN_RU_SPDAT_LCRC_N1500"), 15, "ru_42_80_10")]
+    for idx, (nb, hid, nout, hm) in enumerate([(11, 70, 33, 70), (13, 40, 100, 61), (7, 1, 3, 5), (23, 300, 200, 320)]):
+        d = str(tmp_path / ("g%d" % idx))
+        modelgen.write_model_dir(d, nb, hid, nout, seed=40 + idx, hidden_merger=hm)
+        cases.append((d, nb, "generic"))
+    for d, nb, name in cases:
+        ctx = capi.Lcrc(d, nb)
+        assert ctx.kernel_name == name
+        o = oracle_mod.Oracle(d, nb)
+        mel = modelgen.synth_mel(2100, nb, seed=3)
+        for n in (1, 5, 16, 17, 100, 700, 2048, 2100):
+            ctx.set_hidden_split(1)
+            fused = ctx.posteriors(mel[:n])
+            if n <= 100:
+                assert np.abs(fused - o.posteriors(mel[:n])).max() < TOL, (name, n)
+            for split in (0, 2, 5, 12, 64):
+                ctx.set_hidden_split(split)
+                got = ctx.posteriors(mel[:n])
+                assert np.abs(got - fused).max() < 2e-5, (name, n, split, np.abs(got - fused).max())
+                assert np.abs(got.sum(axis=1) - 1).max() < 1e-5
+                assert np.array_equal(ctx.posteriors(mel[:n]), got), "deterministic for a given setting"
+        # ragged batches incl. empty utterances; the writer path runs in the split path's epilogue too
+        lens = [0, 3, 40, 0, 17, 1, 64]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        bm = mel[:int(off[-1])]
+        want = o.posteriors_batch(bm, off)
+        for split in (0, 1, 7):
+            ctx.set_hidden_split(split)
+            assert np.abs(ctx.posteriors_batch(bm, off) - want).max() < TOL, (name, split)
+        ctx.set_hidden_split(0)
+        ctx.configure_output(("log",), big_endian=True)
+        with np.errstate(divide="ignore"):
+            lw = np.log(want)
+        got = ctx.posteriors_batch(bm, off).view(">f4").astype(np.float32)
+        ok = np.isfinite(lw) & (want > 1e-30)
+        assert np.abs(got[ok] - lw[ok]).max() < 1e-3
+        ctx.configure_output(())
+        with pytest.raises(capi.LcrcError):
+            ctx.set_hidden_split(-1)
+        ctx.close()
+
+
+def test_row_ranges(capi, oracle_mod, tmp_path):
+    """lcrc_posteriors_rows: only a row range of a strip is computed, the rest is context -- bit-identical to
+    the same rows of the whole strip (fused kernel), so a long file cut into chunks with 15-frame halos gives
+    the whole file's posteriors; edge replication applies at the strip's ends only"""
+    for d, nb in ((model_dir("PHN_CZ_SPDAT_LCRC_N1500"), 15), (None, 9)):
+        if d is None:
+            d = str(tmp_path / "m")
+            modelgen.write_model_dir(d, nb, 50, 21, seed=2)
+        ctx = capi.Lcrc(d, nb)
+        mel = modelgen.synth_mel(600, nb, seed=12)
+        ctx.set_hidden_split(1)
+        whole = ctx.posteriors(mel)
+        for first, count in ((0, 600), (0, 1), (599, 1), (15, 5), (16, 31), (100, 333), (37, 0)):
+            got = ctx.posteriors_rows(mel, first, count)
+            assert got.shape == (count, ctx.n_out)
+            assert np.array_equal(got, whole[first:first + count]), (first, count)
+        # chunks of 128 rows with halos == the whole utterance
+        parts = []
+        for a in range(0, 600, 128):
+            b = min(600, a + 128)
+            lo, hi = max(0, a - 15), min(600, b + 15)
+            parts.append(ctx.posteriors_rows(mel[lo:hi], a - lo, b - a))
+        assert np.array_equal(np.concatenate(parts), whole)
+        ctx.set_hidden_split(0)                          # small ranges take the split path: same values to the last bits
+        for first, count in ((15, 5), (100, 333), (0, 600)):
+            got = ctx.posteriors_rows(mel, first, count)
+            assert np.abs(got - whole[first:first + count]).max() < 2e-5
+        with pytest.raises(capi.LcrcError):
+            ctx.posteriors_rows(mel, 590, 20)
+        ctx.close()
 
 
 def test_extreme_inputs_saturate_like_the_reference(capi, oracle_mod, tmp_path):
@@ -209,6 +328,7 @@ def test_baseline_batch_sizes(capi, oracle_mod, system, batch):
     nb = spec["nbanks"]
     mel = modelgen.synth_mel(batch, nb, seed=77, mean_norm=spec["sent_mean_norm"])
     ctx = capi.Lcrc(model_dir(system), nb)
+    ctx.set_hidden_split(1)                # the bit-for-bit comparisons below span launch sizes
     o = oracle_mod.Oracle(model_dir(system), nb)
     post = ctx.posteriors(mel)
     assert np.isfinite(post).all() and (post >= 0).all()
@@ -232,6 +352,7 @@ def test_sharded_file_list_shape(capi, oracle_mod, tmp_path):
     """configs[3]-like: the shipped HU weights, a list of ragged 3-15 s utterances in multi-utterance launches"""
     d = model_dir("PHN_HU_SPDAT_LCRC_N1500")
     ctx = capi.Lcrc(d, 15)
+    ctx.set_hidden_split(1)                # as the CLI does: outputs independent of the packing into launches
     assert ctx.kernel_name == "hu_42_93_12"
     o = oracle_mod.Oracle(d, 15)
     rng = np.random.default_rng(9)
@@ -349,6 +470,7 @@ def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
         d = str(tmp_path / name)
         modelgen.write_model_dir(d, nb, hid, nout, seed=21)
         ctx = capi.Lcrc(d, nb)
+        ctx.set_hidden_split(1)
         assert ctx.kernel_name == name
         o = oracle_mod.Oracle(d, nb)
         lens = [1, 15, 16, 17, 31, 32, 33, 0, 47, 100]
