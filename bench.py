@@ -157,6 +157,166 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     return out
 
 
+def time_launches(ctx, stream, d_mel, d_post, n, reps):
+    """average ms per launch of `reps` launches of n frames, one HIP event pair on the launch stream"""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        ctx.posteriors_device(d_mel.data_ptr(), n, d_post.data_ptr(), stream=stream.cuda_stream)
+    e1.record(stream)
+    stream.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def small_launch_legs(capi, modelgen, dev, stream):
+    """The small-launch regime, beside the headline: roofline fraction of 2048- and 4096-frame launches (the
+    launcher picks 16-frame workgroups and, below half of the CUs, the split-hidden kernels), for CZ and for EN
+    at its own BASELINE size (configs[1]); and the streaming entry (Traps::CalcFeaturesBunched semantics,
+    traps.cpp:518-535) at the shipped bunch_size=5 (PHN_*/config:11) and at 512."""
+    import ctypes as C
+    import torch
+    out = {}
+    for system in ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"):
+        mdir = os.path.join(ROOT, "tests", "golden", "models", system)
+        if not os.path.isdir(mdir):
+            continue
+        spec = modelgen.SYSTEMS[system]
+        nb = spec["nbanks"]
+        ctx = capi.Lcrc(mdir, nb, device=dev.index)
+        ctx.set_timing(False)
+        fpf = algorithmic_flops_per_frame([ctx.net_dims(i) for i in range(3)])
+        d_mel = torch.from_numpy(modelgen.synth_mel(4096, nb, seed=7, mean_norm=spec["sent_mean_norm"])).to(dev)
+        d_post = torch.empty((4096, ctx.n_out), dtype=torch.float32, device=dev)
+        tag = system.split("_")[1].lower()
+        for n in (2048, 4096):
+            time_launches(ctx, stream, d_mel, d_post, n, 30)
+            ms = time_launches(ctx, stream, d_mel, d_post, n, 200)
+            out["%s_%d" % (tag, n)] = {"kernel_ms": round(ms, 4), "frames_per_s": round(n / ms * 1e3, 1),
+                                       "frac": round(n * fpf / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        if tag == "cz":
+            # streaming: raw ctypes calls on preallocated buffers (what a C caller pays), wall clock
+            L, h = ctx.L, ctx.h
+            push = L.lcrc_push
+            push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            for bunch in (5, 512):
+                mel = modelgen.synth_mel(bunch * 64, nb, seed=11)
+                post = np.empty((bunch, ctx.n_out), np.float32)
+                ptrs = [mel[i * bunch:].ctypes.data for i in range(64)]
+                ctx.reset()
+                push(h, mel.ctypes.data, 15, None, 0)
+                for i in range(32):
+                    push(h, ptrs[i], bunch, post.ctypes.data, 1)
+                calls, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 1.0:
+                    for i in range(64):
+                        if push(h, ptrs[i], bunch, post.ctypes.data, 1) != 0:
+                            raise RuntimeError("lcrc_push failed")
+                    calls += 64
+                dt = time.perf_counter() - t0
+                out["push_bunch%d" % bunch] = {"value": round(calls * bunch / dt, 1), "unit": "frames/s",
+                                               "us_per_call": round(dt / calls * 1e6, 2),
+                                               "what": "lcrc_reset/lcrc_push(n=%d, needed=1): host frames in, host "
+                                                       "posteriors out, synchronous (PCIe-inclusive)" % bunch}
+            push.argtypes = [C.c_void_p, capi._f32p, C.c_int, C.c_void_p, C.c_int]
+        ctx.close()
+    return out
+
+
+def alaw_encode(x):
+    """A-law bytes by nearest-value search in the 256-entry expansion table (srec.cpp:769
+    decodes as 8 * table[b])"""
+    def expand(b):
+        a = b ^ 0x55
+        mant, seg = (a & 0x0F) << 4, (a & 0x70) >> 4
+        mant = mant + 8 if seg == 0 else (mant + 0x108) << (seg - 1)
+        return float(mant if a & 0x80 else -mant)
+    table = np.array([expand(b) for b in range(256)], np.float32)
+    order = np.argsort(table)
+    srt = table[order]
+    idx = np.clip(np.searchsorted(srt, x), 1, 255)
+    pick = np.where(np.abs(x - srt[idx - 1]) <= np.abs(srt[idx] - x), idx - 1, idx)
+    return order[pick].astype(np.uint8)
+
+
+def config2_alaw_signal(frames=BATCH):
+    """BASELINE configs[2]'s input as SURVEY.md 8(d) cfg3 defines it: 8 kHz, (frames-1)*80+200 samples,
+    0.3 full-scale mix of 5 sines (200-3400 Hz) + Gaussian noise sigma 1000, seed 1235, A-law"""
+    n = (frames - 1) * 80 + 200
+    rng = np.random.default_rng(1235)
+    t = np.arange(n) / 8000.0
+    sig = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n)
+    return alaw_encode(np.clip(sig, -32768, 32767).astype(np.float32)).tobytes()
+
+
+def wave_path_leg(capi, mdir, nb, gpu):
+    """bytes in -> posteriors out through the GPU front-end (lcrc_wave_to_posteriors), PCIe-inclusive"""
+    raw = config2_alaw_signal()
+    ctx = capi.Lcrc(mdir, nb, device=gpu)
+    ctx.configure_frontend(wave_format="alaw", sent_mean_norm=True)
+    frames = ctx.frontend_frames(len(raw))
+    post, _ = ctx.wave_to_posteriors([raw])
+    reps, t0 = 20, time.perf_counter()
+    for _ in range(reps):
+        ctx.wave_to_posteriors([raw])
+    dt = (time.perf_counter() - t0) / reps
+    ok = bool(np.abs(post.sum(axis=1) - 1).max() < 1e-5)
+    ctx.close()
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_call": round(dt * 1e3, 4), "frames": frames,
+            "bytes_in": len(raw), "rows_sum_to_one": ok,
+            "what": "configs[2] input per SURVEY 8(d) cfg3 (A-law, 5 sines + noise, seed 1235): "
+                    "lcrc_wave_to_posteriors(): A-law decode + mel bank + sentence mean norm + posteriors on the GPU, "
+                    "host bytes in, host posteriors out, synchronous"}
+
+
+def cli_e2e_leg(mdir, n_files, gpu):
+    """The drop-in CLI end to end on a bounded synthetic list: raw 8 kHz lin16 files of 3-15 s -> MLF on disk
+    (file reads, front-end, posteriors, host Viterbi, output), host front-end and GPU front-end (-F)."""
+    import subprocess
+    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+    if not os.path.exists(exe):
+        return {"error": "phnrec_amd/bin/phnrec is not built"}
+    rng = np.random.default_rng(1236)
+    n_base = 16 * 8000
+    t = np.arange(n_base) / 8000.0
+    base = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n_base)
+    base = np.clip(base, -32768, 32767).astype("<i2")
+    out = {"files": n_files, "cores_usable": usable_cpus(),
+           "what": "phnrec -c PHN_CZ -l list -m out.mlf: raw lin16 8 kHz files of 3-15 s (slices of one synthetic "
+                   "signal) -> MLF; wall clock of the list loop as the CLI reports it (PHNREC_STATS), process start-up "
+                   "and model load excluded"}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        names, frames = [], 0
+        for i in range(n_files):
+            n = int(rng.uniform(3.0, 15.0) * 8000)
+            o = int(rng.integers(0, n_base - n))
+            p = os.path.join(td, "f%05d.raw" % i)
+            base[o:o + n].tofile(p)
+            names.append(p)
+            frames += (n - 200) // 80 + 1
+        lst = os.path.join(td, "list.scp")
+        with open(lst, "w") as f:
+            f.write("".join(n + "\n" for n in names))
+        out["frames"] = frames
+        env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=str(gpu))
+        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"])):
+            try:
+                t0 = time.perf_counter()
+                pr = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "out.mlf")] + extra, env=env,
+                                    capture_output=True, text=True, timeout=300)
+                wall = time.perf_counter() - t0
+                stats = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")]
+                if pr.returncode != 0 or not stats:
+                    out[key] = {"error": "rc=%d %s" % (pr.returncode, pr.stderr.strip()[-200:])}
+                    continue
+                kv = dict(tok.split("=", 1) for tok in stats[-1].replace("(", "").replace(")", "").split() if "=" in tok)
+                out[key] = {"value": float(kv["frames_per_s"]), "unit": "frames/s", "list_wall_s": float(kv["wall_s"]),
+                            "process_wall_s": round(wall, 3), "xrt": float(kv["xRT"])}
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+    return out
+
+
 def stub_main(args, ranks):
     """Launcher self-test: everything of the N-rank harness except the GPU (see --stub)."""
     from phnrec_amd import distrun
@@ -182,9 +342,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    # default warm-up: the device needs ~100 launches (~25 ms of load) to reach its steady clock after idling
-    # (0.236 ms per launch at launch 11-20, 0.210 ms from launch ~100 on; profiles/README.md)
     ap.add_argument("--warmup", type=int, default=100)
+    # Disclosed pre-heat, OUTSIDE warmup/steps: after idling the device needs ~100 launches (~25 ms of load) to
+    # reach its steady clock (0.236 ms per launch at launch 11-20, 0.210 ms from launch ~100 on; profiles/README.md).
+    # The line states it ("preheat_launches") and also carries the cold figure of the first launches
+    # ("roofline.cold"), so a short --warmup neither hides nor includes the ramp silently.  0 switches it off.
+    ap.add_argument("--preheat", type=int, default=300)
+    ap.add_argument("--cli-files", type=int, default=2000, help="files of the cli_e2e leg (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the small-launch / push / wave / CLI legs")
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -266,6 +431,10 @@ def main():
         def sync():
             torch.cuda.synchronize(dev)
 
+        # cold figure: the first 20 launches of this process (code load, clock ramp), then the disclosed pre-heat
+        cold_ms = time_launches(ctx, stream, d_mel, d_post, args.batch, 20)
+        if args.preheat > 0:
+            time_launches(ctx, stream, d_mel, d_post, args.batch, args.preheat)
         elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=red_dev)
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         kernel_ms = ranks.max_float(kernel_ms, device=red_dev)
@@ -275,17 +444,22 @@ def main():
         line = None
         if ranks.rank == 0:
             achieved = args.batch * flops_frame / (kernel_ms * 1e-3) / 1e12
-            traffic = None
+            # HBM bytes per launch are NOT measured by this run: PMC counters need rocprofv3 around the process.
+            # The figure is the committed PMC pass of the same workload; its source says which round and how.
+            traffic, traffic_source = None, None
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(pmc):
                 try:
                     with open(pmc) as f:
-                        traffic = json.load(f).get("bytes_per_launch")
+                        rec = json.load(f)
+                    traffic = rec.get("bytes_per_launch")
+                    traffic_source = "profiles/hbm_traffic.json (not measured by this run): " + str(rec.get("source"))
                 except Exception:
                     traffic = None
             line = {
                 "metric": "frames/sec (LCRC posterior path)", "value": round(fps, 1), "unit": "frames/s",
                 "n_gpus": len(set(dmap)), "steps": args.steps, "warmup": args.warmup,
+                "preheat_launches": args.preheat,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
@@ -301,8 +475,14 @@ def main():
                 "xrt": round(100.0 / (fps / max(1, ranks.world)), 8),
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                             "traffic": traffic, "kernel_ms": round(kernel_ms, 4),
-                             "flop_per_frame": flops_frame,
+                             "traffic": traffic, "traffic_source": traffic_source,
+                             "kernel_ms": round(kernel_ms, 4), "flop_per_frame": flops_frame,
+                             "launches_timed": "%d launches after %d pre-heat + %d warm-up launches"
+                                               % (args.steps, args.preheat + 20, args.warmup),
+                             # the same kernel straight after start-up: launches 1-20 of this process
+                             "cold": {"launches": "1-20", "kernel_ms": round(cold_ms, 4),
+                                      "frac": round(args.batch * flops_frame / (cold_ms * 1e-3) / 1e12
+                                                    / PEAK_F32_MFMA_TFLOPS, 4)},
                              # secondary figure: HBM-side bytes (PMC, per launch) over the live kernel time,
                              # against the ~8 TB/s HBM3E peak -- the kernel is nowhere near memory-bound
                              "hbm_gbps": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
@@ -320,6 +500,20 @@ def main():
                 line["host_path"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
                                      "ms_per_call": round(dt * 1e3, 4),
                                      "what": "lcrc_posteriors(): memcpy to pinned + H2D + kernel + D2H + memcpy, synchronous"}
+            if ranks.world == 1 and not args.no_extras:
+                for key, leg in (("small_launches", lambda: small_launch_legs(capi, modelgen, dev, stream)),
+                                 ("wave_path", lambda: wave_path_leg(capi, mdir, nb, gpu)),
+                                 ("cli_e2e", lambda: cli_e2e_leg(mdir, args.cli_files, gpu) if args.cli_files > 0 else None)):
+                    try:
+                        val = leg()
+                    except Exception as e:      # side legs are reported when they can be measured, never fatal
+                        val = {"error": repr(e)}
+                    if val is not None:
+                        line[key] = val
+                if isinstance(line.get("small_launches"), dict):
+                    for k in ("push_bunch5", "push_bunch512"):
+                        if k in line["small_launches"]:
+                            line[k] = line["small_launches"].pop(k)
             if ranks.world == 1 and not args.no_cpu:
                 gpu_post = d_post.cpu().numpy()
                 line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds)

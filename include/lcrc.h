@@ -158,6 +158,13 @@ typedef struct lcrc_frontend {
 } lcrc_frontend;
 
 int lcrc_frontend_configure(lcrc_ctx *ctx, const lcrc_frontend *cfg);
+/* Order of the column sums of the sentence mean normalisation (srec.cpp:1500-1511, matrix.h:2101-2116).
+ * 0 (default): a fixed-shape tree per utterance (256-row blocks from the utterance's first row, strided lane
+ * sums folded by halves, block sums added in order) -- deterministic, independent of what else is in the call,
+ * a few microseconds for any length; the mean differs from the reference's by ~1e-7 relative.
+ * 1: the reference's sequential f32 sums in frame order, bit for bit (a dependent add chain: ~13 ns per frame
+ * of the longest utterance). */
+int lcrc_set_mean_order(lcrc_ctx *ctx, int sequential);
 /* frames a file of n_bytes yields: len > vs ? (len - vs)/step + 1 : 1   (srec.cpp:945) */
 int lcrc_frontend_frames(const lcrc_ctx *ctx, long long n_bytes);
 /* bytes: the raw files back to back (no header parsing, like the reference); byte_off[n_utts+1].
@@ -250,6 +257,10 @@ int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
  * every launch uses the fused kernel and a frame's posteriors are bit-identical however it is batched
  * (the CLI sets this); k > 1 = at most k workgroups per tile. */
 int lcrc_set_hidden_split(lcrc_ctx *ctx, int workgroups_per_tile);
+/* Test hook: the nth (0 = next) staging-buffer allocation of this process from now on fails as if the
+ * device / pinned memory were exhausted; -1 switches the injection off.  The failing call returns
+ * LCRC_E_NOMEM, leaves no half-allocated buffer group behind, and the context stays usable. */
+int lcrc_debug_fail_alloc(int nth);
 /* Name of the kernel variant selected for this model ("cz_11_18_9", "generic", ...) */
 const char *lcrc_kernel_name(const lcrc_ctx *ctx);
 

@@ -18,11 +18,11 @@ SYMBOLS = [
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
-    "lcrc_frontend_configure", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
+    "lcrc_frontend_configure", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
@@ -142,6 +142,8 @@ def load():
     L.lcrc_set_timing.argtypes = [vp, C.c_int]
     L.lcrc_set_tile_frames.argtypes = [vp, C.c_int]
     L.lcrc_set_hidden_split.argtypes = [vp, C.c_int]
+    L.lcrc_set_mean_order.argtypes = [vp, C.c_int]
+    L.lcrc_debug_fail_alloc.argtypes = [C.c_int]
     L.lcrc_posteriors_rows.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
     _lib = L
     return L
@@ -271,6 +273,10 @@ class Lcrc:
         fe = Frontend({"lin16": 1, "alaw": 2}[wave_format], sample_freq, vector_size, vector_step, nbanks_full,
                       lower_freq, higher_freq, preem_coef, scale, dc_shift, int(z_mean_source), int(sent_mean_norm))
         self._check(self.L.lcrc_frontend_configure(self.h, C.byref(fe)))
+
+    def set_mean_order(self, sequential):
+        """False (default): fixed-shape tree sums; True: the reference's sequential column sums"""
+        self._check(self.L.lcrc_set_mean_order(self.h, int(sequential)))
 
     def frontend_frames(self, n_bytes):
         n = self.L.lcrc_frontend_frames(self.h, n_bytes)

@@ -24,9 +24,12 @@ struct FrontendParams {
 };
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
-// means: device scratch [n_utts][nbanks]
-hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks, float *means,
-                           hipStream_t stream);
+// Sentence mean normalisation.  means: device scratch [n_utts][nbanks].  block_off [n_utts + 1] (first
+// 256-row block of each utterance, meannorm_blocks(rows) blocks each) and partial [n_blocks][nbanks] select the
+// fixed-shape tree sum; block_off == NULL the reference's sequential sums.
+int meannorm_blocks(int rows);
+hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_off, int n_blocks, float *partial,
+                           int n_utts, int n_rows, int nbanks, float *means, hipStream_t stream);
 
 }  // namespace phnrec
 #endif

@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
     }
 }
 
-// offlinenorm/sent_mean_norm (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116): column sums are
-// SEQUENTIAL f32 sums over the frames (the order is part of the result), mean = sum * (1.0f / rows),
-// x += -mean.  colmean_kernel: one workgroup per utterance streams the rows through LDS with coalesced
+// offlinenorm/sent_mean_norm (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116): the reference's column sums
+// are SEQUENTIAL f32 sums over the frames, mean = sum * (1.0f / rows), x += -mean.  That exact order is kept
+// as an option (lcrc_set_mean_order(ctx, 1)); the default is the tree below.  colmean_kernel: one workgroup per utterance streams the rows through LDS with coalesced
 // loads and lane b adds column b in frame order; submean_kernel: one thread per row subtracts.
 constexpr int kNormLdsFloats = 15360;           // 60 KiB of rows per LDS chunk (1024 rows of 15 banks)
 __global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
@@ -191,6 +191,71 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const in
     if ((int)threadIdx.x < nbanks) means[(size_t)u * nbanks + threadIdx.x] = sum * (1.0f / (float)rows);
 }
 
+// The default order of the column sums: a FIXED-SHAPE TREE per utterance instead of the reference's dependent
+// chain (107 us for one 8192-frame utterance; the mean moves by ~1e-7 relative, posteriors by << 1e-4).  Rows
+// are grouped in blocks of kMeanBlock rows counted from the utterance's first row; within a block, row lane q of
+// Q = 256 / B' (B' = nbanks rounded up to a power of two) adds rows q, q+Q, ... in order, the Q lane sums are
+// folded by halves (q += q + Q/2, ...), and colmean_finish_kernel adds an utterance's block sums in block order.
+// The shape depends on the utterance's own length and nbanks only: batching never changes a mean.
+constexpr int kMeanBlock = 256;
+__global__ __launch_bounds__(256) void colmean_block_kernel(const float *mel, const int *frame_off, const int *block_off,
+                                                            int n_utts, int nbanks, float *partial)
+{
+    __shared__ float fold[256];
+    const int blk = blockIdx.x;
+    int lo = 0, hi = n_utts;                    // largest u with block_off[u] <= blk
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (block_off[mid] <= blk) lo = mid; else hi = mid;
+    }
+    const int first = frame_off[lo] + (blk - block_off[lo]) * kMeanBlock;
+    const int rows = min(kMeanBlock, frame_off[lo + 1] - first);
+    const int bp = nbanks <= 16 ? 16 : nbanks <= 32 ? 32 : 64, Q = 256 / bp;
+    const int b = threadIdx.x % bp, q = threadIdx.x / bp;
+    const float *x = mel + (size_t)first * nbanks + b;
+    float sum = 0.0f;
+    if (b < nbanks) {
+        int r = q;
+        for (; r + 7 * Q < rows; r += 8 * Q) {         // eight independent loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = x[(size_t)(r + k * Q) * nbanks];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[k];
+        }
+        for (; r < rows; r += Q) sum += x[(size_t)r * nbanks];
+    }
+    fold[threadIdx.x] = sum;
+    __syncthreads();
+    for (int h = Q / 2; h >= 1; h >>= 1) {
+        if (q < h) fold[threadIdx.x] += fold[threadIdx.x + h * bp];
+        __syncthreads();
+    }
+    if (q == 0 && b < nbanks) partial[(size_t)blk * nbanks + b] = fold[threadIdx.x];
+}
+
+__global__ void colmean_finish_kernel(const float *partial, const int *frame_off, const int *block_off, int n_utts,
+                                      int nbanks, float *means)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_utts * nbanks) return;
+    const int u = i / nbanks, b = i - u * nbanks;
+    const int rows = frame_off[u + 1] - frame_off[u];
+    if (rows <= 0) return;
+    float sum = 0.0f;
+    const int k0 = block_off[u], k1 = block_off[u + 1];
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {                 // eight independent loads in flight, added in block order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = partial[(size_t)(k + q) * nbanks + b];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sum += v[q];
+    }
+    for (; k < k1; k++) sum += partial[(size_t)k * nbanks + b];
+    means[(size_t)u * nbanks + b] = sum * (1.0f / (float)rows);
+}
+
 __global__ void submean_kernel(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks,
                                const float *means)
 {
@@ -216,12 +281,21 @@ hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t meannorm_launch(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks, float *means,
-                           hipStream_t stream)
+int meannorm_blocks(int rows) { return (rows + kMeanBlock - 1) / kMeanBlock; }
+
+hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_off, int n_blocks, float *partial,
+                           int n_utts, int n_rows, int nbanks, float *means, hipStream_t stream)
 {
     if (n_utts <= 0 || n_rows <= 0) return hipSuccess;
-    const size_t lds = (size_t)(kNormLdsFloats / nbanks) * nbanks * sizeof(float);
-    colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
+    if (nbanks > 64) return hipErrorInvalidValue;
+    if (block_off == nullptr) {                 // the reference's sequential sums (lcrc_set_mean_order)
+        const size_t lds = (size_t)(kNormLdsFloats / nbanks) * nbanks * sizeof(float);
+        colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
+    } else {
+        colmean_block_kernel<<<n_blocks, 256, 0, stream>>>(mel, frame_off, block_off, n_utts, nbanks, partial);
+        colmean_finish_kernel<<<(n_utts * nbanks + 255) / 256, 256, 0, stream>>>(partial, frame_off, block_off, n_utts,
+                                                                                  nbanks, means);
+    }
     submean_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, frame_off, n_utts, n_rows, nbanks, means);
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -64,8 +65,10 @@ struct lcrc_ctx {
     unsigned char *d_bytes = nullptr, *h_bytes = nullptr;
     long long *d_soff = nullptr, *h_soff = nullptr;
     int *d_foff = nullptr, *h_foff = nullptr;
-    float *d_means = nullptr;
-    size_t cap_bytes = 0, cap_fe_utts = 0;
+    float *d_means = nullptr, *d_mean_part = nullptr;
+    size_t cap_bytes = 0, cap_fe_utts = 0, cap_mean_blocks = 0;
+    int mean_blocks = 0;                 // blocks of the last staged batch (tree mean)
+    bool mean_sequential = false;        // lcrc_set_mean_order
     // streaming state (lcrc_push): the pushed frames live in a pinned, device-mapped strip whose last 30 rows
     // are the history (Traps::be_mat minus its newest slot); the kernel reads the strip and writes the
     // posteriors of a push in place (zero-copy), so a push costs no allocation and no copy command
@@ -175,27 +178,72 @@ int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
     return LCRC_OK;
 }
 
+// Test hook (lcrc_debug_fail_alloc): the n-th buffer allocation from now on fails with out-of-memory.
+std::atomic<int> g_fail_alloc{-1};
+bool inject_alloc_failure()
+{
+    int v = g_fail_alloc.load();
+    while (v >= 0) {
+        if (g_fail_alloc.compare_exchange_weak(v, v - 1)) return v == 0;
+    }
+    return false;
+}
+hipError_t dev_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    return inject_alloc_failure() ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+}
+hipError_t pinned_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    return inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
+void free_frame_staging(lcrc_ctx *c)
+{
+    if (c->d_mel) (void)hipFree(c->d_mel);
+    if (c->d_post) (void)hipFree(c->d_post);
+    if (c->h_mel) (void)hipHostFree(c->h_mel);
+    if (c->h_post) (void)hipHostFree(c->h_post);
+    c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
+    c->cap_rows = 0;
+}
+
+void free_offset_staging(lcrc_ctx *c)
+{
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->h_off) (void)hipHostFree(c->h_off);
+    c->d_off = c->h_off = nullptr;
+    c->cap_utts = 0;
+}
+
+// Staging buffers of the host-pointer entry points.  A failed allocation leaves the group it belongs to
+// EMPTY (nothing half-allocated, capacity 0): the call fails with LCRC_E_NOMEM and a later call starts over.
 int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
 {
     if (rows > c->cap_rows) {
-        size_t cap = rows + rows / 4 + 64;
-        if (c->d_mel) { (void)hipFree(c->d_mel); (void)hipFree(c->d_post); (void)hipHostFree(c->h_mel); (void)hipHostFree(c->h_post); }
-        c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
-        c->cap_rows = 0;
+        const size_t cap = rows + rows / 4 + 64;
+        free_frame_staging(c);
         const size_t O = c->nets[2].n_out;
-        HIP_TRY(c, hipMalloc((void **)&c->d_mel, cap * c->nbanks * sizeof(float)));
-        HIP_TRY(c, hipMalloc((void **)&c->d_post, cap * O * sizeof(float)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_post, cap * O * sizeof(float), hipHostMallocDefault));
+        if (dev_alloc((void **)&c->d_mel, cap * c->nbanks * sizeof(float)) != hipSuccess ||
+            dev_alloc((void **)&c->d_post, cap * O * sizeof(float)) != hipSuccess ||
+            pinned_alloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float)) != hipSuccess ||
+            pinned_alloc((void **)&c->h_post, cap * O * sizeof(float)) != hipSuccess) {
+            free_frame_staging(c);
+            (void)hipGetLastError();
+            return fail(c, LCRC_E_NOMEM, "cannot allocate staging buffers for " + std::to_string(cap) + " frames");
+        }
         c->cap_rows = cap;
     }
     if (utts + 1 > c->cap_utts) {
-        size_t cap = utts + utts / 4 + 64;
-        if (c->d_off) { (void)hipFree(c->d_off); (void)hipHostFree(c->h_off); }
-        c->d_off = c->h_off = nullptr;
-        c->cap_utts = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_off, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_off, cap * sizeof(int), hipHostMallocDefault));
+        const size_t cap = utts + utts / 4 + 64;
+        free_offset_staging(c);
+        if (dev_alloc((void **)&c->d_off, cap * sizeof(int)) != hipSuccess ||
+            pinned_alloc((void **)&c->h_off, cap * sizeof(int)) != hipSuccess) {
+            free_offset_staging(c);
+            (void)hipGetLastError();
+            return fail(c, LCRC_E_NOMEM, "cannot allocate staging buffers for " + std::to_string(cap) + " utterances");
+        }
         c->cap_utts = cap;
     }
     return LCRC_OK;
@@ -679,12 +727,8 @@ void lcrc_destroy(lcrc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->allocs) (void)hipFree(p);
-    if (c->d_mel) (void)hipFree(c->d_mel);
-    if (c->d_post) (void)hipFree(c->d_post);
-    if (c->d_off) (void)hipFree(c->d_off);
-    if (c->h_mel) (void)hipHostFree(c->h_mel);
-    if (c->h_post) (void)hipHostFree(c->h_post);
-    if (c->h_off) (void)hipHostFree(c->h_off);
+    free_frame_staging(c);
+    free_offset_staging(c);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
     if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
     if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
@@ -701,6 +745,7 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->d_foff) (void)hipFree(c->d_foff);
     if (c->h_foff) (void)hipHostFree(c->h_foff);
     if (c->d_means) (void)hipFree(c->d_means);
+    if (c->d_mean_part) (void)hipFree(c->d_mean_part);
     if (c->h_ring) (void)hipHostFree(c->h_ring);
     if (c->h_pushout) (void)hipHostFree(c->h_pushout);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -914,10 +959,22 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     }
     const int unit = c->fe.wave_format == 1 ? 2 : 1;
     c->h_foff[0] = 0;
+    int *const h_boff = c->h_foff + n_utts + 1;      // block offsets of the tree mean, behind the frame offsets
+    h_boff[0] = 0;
     for (int u = 0; u < n_utts; u++) {               // h_soff: [start of u ...][sample count of u ...]
         c->h_soff[u] = start[u] / unit;
         c->h_soff[n_utts + u] = fe_samples(c, len[u]);
-        c->h_foff[u + 1] = c->h_foff[u] + lcrc_frontend_frames(c, len[u]);
+        const int fr = lcrc_frontend_frames(c, len[u]);
+        c->h_foff[u + 1] = c->h_foff[u] + fr;
+        h_boff[u + 1] = h_boff[u] + meannorm_blocks(fr);
+    }
+    c->mean_blocks = h_boff[n_utts];
+    if ((size_t)c->mean_blocks > c->cap_mean_blocks) {
+        if (c->d_mean_part) (void)hipFree(c->d_mean_part);
+        c->d_mean_part = nullptr; c->cap_mean_blocks = 0;
+        const size_t cap = (size_t)c->mean_blocks + c->mean_blocks / 4 + 64;
+        HIP_TRY(c, hipMalloc((void **)&c->d_mean_part, cap * 64 * sizeof(float)));
+        c->cap_mean_blocks = cap;
     }
     for (int u = 0; u < n_utts; u++) frame_off[u] = c->h_foff[u];
     if (n_utts >= 0) frame_off[n_utts] = c->h_foff[n_utts];
@@ -927,7 +984,7 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)extent, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_soff, c->h_soff, (size_t)(2 * n_utts) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(2 * n_utts + 2) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     FrontendParams p;
     memset(&p, 0, sizeof p);
     p.bytes = c->d_bytes; p.sample_start = c->d_soff; p.frame_off = c->d_foff; p.mel = c->d_mel;
@@ -986,7 +1043,9 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
 static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
 {
     const bool copy_post = c->readback || c->dec_P <= 0;
-    if (c->fe.sent_mean_norm) HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, n_utts, rows, c->nbanks, c->d_means, c->stream));
+    if (c->fe.sent_mean_norm)
+        HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, c->mean_sequential ? nullptr : c->d_foff + n_utts + 1, c->mean_blocks,
+                                   c->d_mean_part, n_utts, rows, c->nbanks, c->d_means, c->stream));
     int rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
     rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
@@ -1203,6 +1262,19 @@ int lcrc_posteriors_rows(lcrc_ctx *c, const float *mel, int n_rows, int row_firs
     HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)row_count * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(post, c->h_post, (size_t)row_count * O * sizeof(float));
+    return LCRC_OK;
+}
+
+int lcrc_debug_fail_alloc(int nth)
+{
+    g_fail_alloc = nth;
+    return LCRC_OK;
+}
+
+int lcrc_set_mean_order(lcrc_ctx *c, int sequential)
+{
+    if (!c) return LCRC_E_ARG;
+    c->mean_sequential = sequential != 0;
     return LCRC_OK;
 }
 

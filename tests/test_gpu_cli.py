@@ -43,6 +43,65 @@ def test_bundled_utterance_end_to_end(system, tmp_path):
     assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_params_in_posteriors_out(system, tmp_path):
+    """-s par: the hot path in its most direct CLI form (srec.cpp:1136-1145: the input is the reference's own
+    HTK parameter dump, the front-end is skipped) -> -t post vs the reference's posterior dump, -t str vs its
+    label file; and -s post -> -t str (decoder only) from the reference's posterior dump"""
+    mel = os.path.join(GOLD, system, "test.mel")
+    lop = tmp_path / "t.lop"
+    run("-c", model_dir(system), "-s", "par", "-i", mel, "-t", "post", "-o", lop)
+    got, want = read_htk(str(lop)), read_htk(os.path.join(GOLD, system, "test.lop"))
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+    rec = tmp_path / "t.rec"
+    run("-c", model_dir(system), "-s", "par", "-i", mel, "-t", "str", "-o", rec)
+    _labels_match(rec, os.path.join(GOLD, system, "test.rec"))
+    rec2 = tmp_path / "t2.rec"
+    run("-c", model_dir(system), "-s", "post", "-i", os.path.join(GOLD, system, "test.lop"), "-o", rec2)
+    _labels_match(rec2, os.path.join(GOLD, system, "test.rec"))
+    # a list of parameter files into an MLF
+    lst = tmp_path / "l.txt"
+    lst.write_text("%s\n%s\n" % (mel, mel))
+    mlf = tmp_path / "o.mlf"
+    run("-c", model_dir(system), "-s", "par", "-l", lst, "-m", mlf)
+    lines = mlf.read_text().splitlines()
+    gold = [l.split() for l in open(os.path.join(GOLD, system, "test.rec")) if len(l.split()) == 4]
+    body = [l.split() for l in lines if len(l.split()) == 4]
+    assert lines[0] == "#!MLF!#" and len(body) == 2 * len(gold)
+    # (an MLF prints a zero time as "0", a label file as "000000": srec.cpp:137-161 vs phndec.cpp:230)
+    key = lambda rows: [(int(r[0]), int(r[1]), r[2]) for r in rows]
+    assert key(body[:len(gold)]) == key(gold) and key(body[len(gold):]) == key(gold)
+
+
+def test_posterior_softening_through_the_cli(tmp_path):
+    """posteriors/softening_func = log / igor / gmm_bypass (srec.cpp:164-176,1062-1070): `-t post` dumps against
+    the REFERENCE CLI's dumps for the same configs (tools/make_golden_softening.py); the functions run in the
+    kernel's epilogue, the dump is the kernel's big-endian output written as is"""
+    import shutil
+    from tools.make_golden_softening import CASES
+    raw = tmp_path / "x.raw"
+    raw.write_bytes(open(os.path.join(GOLD, "test.raw"), "rb").read()[:20000])
+    for name, value in CASES.items():
+        d = tmp_path / name
+        shutil.copytree(model_dir(CZ), d)
+        cfg, section = (d / "config").read_text().splitlines(True), None
+        for i, line in enumerate(cfg):
+            if line.startswith("["):
+                section = line.strip()
+            if section == "[posteriors]" and line.startswith("softening_func="):
+                cfg[i] = "softening_func=%s\n" % value
+        (d / "config").write_text("".join(cfg))
+        want = read_htk(os.path.join(GOLD, "cli", "soft_%s.lop" % name))
+        for extra in ([], ["-F"]):
+            lop = tmp_path / (name + ".lop")
+            run("-c", d, "-i", raw, "-t", "post", "-o", lop, *extra)
+            got = read_htk(str(lop))
+            assert got.shape == want.shape
+            # log-type functions turn the RELATIVE error of a posterior (up to ~5e-5 at p ~ 1e-10, far inside
+            # the 1e-4 absolute bar) into an absolute one
+            assert np.abs(got - want).max() < 1e-3, (name, extra, np.abs(got - want).max())
+
+
 def test_file_list_batched_over_the_gpu(tmp_path):
     raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
     pieces = {"utt_a": raw, "utt_b": raw[:20000], "utt_c": raw[:3000]}

@@ -80,6 +80,41 @@ def test_wave_to_posteriors(capi, system):
             assert np.abs(post[foff[k]:foff[k + 1]] - w).max() < 1e-4, name
 
 
+def test_sentence_mean_orders(capi, oracle_mod):
+    """lcrc_set_mean_order: the default fixed-shape tree sums vs the reference's sequential sums (srec.cpp:1500-1511,
+    matrix.h:2101-2116).  Both stay within the bar of the reference's dumps; the tree is batch-invariant (an
+    utterance's posteriors do not depend on what else is in the call); on a long utterance (many 256-row blocks)
+    both agree with the oracle fed with numpy's own mean-normalised features"""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    want = read_htk(os.path.join(GOLD, CZ, "test.lop"))
+    ctx = _ctx(capi, CZ)
+    ctx.set_hidden_split(1)
+    got = {}
+    for seq in (False, True):
+        ctx.set_mean_order(seq)
+        got[seq], _ = ctx.wave_to_posteriors([raw])
+        assert np.abs(got[seq] - want).max() < 1e-4
+    assert np.abs(got[False] - got[True]).max() < 5e-5
+    ctx.set_mean_order(False)
+    blobs = [raw[:30000], raw, raw[:100], raw[:50001]]
+    post, foff = ctx.wave_to_posteriors(blobs)
+    assert np.array_equal(post[foff[1]:foff[2]], got[False]), "batching must not change an utterance's mean"
+    alone, _ = ctx.wave_to_posteriors([raw[:50001]])
+    assert np.array_equal(post[foff[3]:foff[4]], alone)
+    # a long utterance: 12 copies of the file = 8990 frames = 36 blocks
+    long_raw = raw * 12
+    mel, _ = ctx.wave_to_mel([long_raw])
+    norm = (mel.astype(np.float64) - mel.astype(np.float64).mean(axis=0)).astype(np.float32)
+    o = oracle_mod.Oracle(model_dir(CZ), 15)
+    rows = slice(4000, 4064)
+    ref = o.posteriors(norm[4000 - 15:4064 + 15])[15:15 + 64]
+    for seq in (False, True):
+        ctx.set_mean_order(seq)
+        p, _ = ctx.wave_to_posteriors([long_raw])
+        assert p.shape[0] == mel.shape[0]
+        assert np.abs(p[rows] - ref).max() < 1e-4, seq
+
+
 def test_front_end_options_vs_host_front_end(capi, tmp_path):
     """pre-emphasis, z_mean_source, dc_shift, scale: the host CLI's front-end (itself bit-identical to the
     reference's) is the comparison"""

@@ -292,6 +292,34 @@ def test_api_errors(capi, tmp_path):
         ctx.posteriors_batch(np.zeros((4, 15), np.float32), np.array([0, 3, 2, 4], np.int32))
 
 
+def test_allocation_failure_leaves_the_context_usable(capi, tmp_path):
+    """lcrc_debug_fail_alloc: each of the staging allocations of a host-pointer call fails in turn (device and
+    pinned, frame and offset buffers); the call returns LCRC_E_NOMEM, nothing stays half-allocated, and the
+    next call on the same context succeeds with the right result"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 48, 20, seed=8)
+    ctx = capi.Lcrc(d, 15)
+    mel = modelgen.synth_mel(300, 15, seed=4)
+    off = np.array([0, 100, 300], np.int32)
+    want = ctx.posteriors_batch(mel, off)
+    try:
+        for nth in range(6):                            # 4 frame buffers + 2 offset buffers
+            big_mel = np.concatenate([mel] * 2 ** (nth + 1))          # twice any earlier call: both groups regrow
+            big_off = np.arange(0, big_mel.shape[0] + 1, 10, dtype=np.int32)
+            big_off = np.concatenate([big_off, np.full(300 * 2 ** nth, big_off[-1], np.int32)])   # + empty utterances
+            ctx.L.lcrc_debug_fail_alloc(nth)
+            with pytest.raises(capi.LcrcError) as e:
+                ctx.posteriors_batch(big_mel, big_off)
+            assert e.value.code == capi.LCRC_E_NOMEM, (nth, str(e.value))
+            ctx.L.lcrc_debug_fail_alloc(-1)
+            assert np.array_equal(ctx.posteriors_batch(mel, off), want), nth
+            got = ctx.posteriors_batch(big_mel, big_off)
+            assert got.shape[0] == big_mel.shape[0] and np.abs(got.sum(axis=1) - 1).max() < 1e-5
+    finally:
+        ctx.L.lcrc_debug_fail_alloc(-1)
+    ctx.close()
+
+
 def test_device_pointer_entry_and_determinism(capi, tmp_path):
     import torch
     d = str(tmp_path / "m")
@@ -323,7 +351,11 @@ def _spot_check(ctx, o, mel, post, starts, width=48):
 
 @pytest.mark.parametrize("system,batch", [("PHN_EN_TIMIT_LCRC_N500", 4096), ("PHN_CZ_SPDAT_LCRC_N1500", 8192)])
 def test_baseline_batch_sizes(capi, oracle_mod, system, batch):
-    """configs[1] (EN, 4096 frames) and configs[2] (CZ, 8192 frames) at full size"""
+    """configs[1] (EN, 4096 frames) and configs[2] (CZ, 8192 frames) at full size.  The oracle takes ~0.6 ms per
+    frame, so only 4 x 48 rows (first, an early, a middle, the last window) are compared with it directly; the
+    rest of the batch is covered by size-independent properties: every row is a distribution, the launch is
+    idempotent, cutting the batch changes only the rows within 15 frames of the cut, and each part equals the
+    stand-alone run of that part bit for bit"""
     spec = modelgen.SYSTEMS[system]
     nb = spec["nbanks"]
     mel = modelgen.synth_mel(batch, nb, seed=77, mean_norm=spec["sent_mean_norm"])
@@ -460,6 +492,30 @@ def test_posterior_writer_path_on_device(capi, tmp_path):
     assert np.array_equal(ctx.posteriors_batch(mel, off), plain)
     with pytest.raises(capi.LcrcError):
         ctx.configure_output(("log", "log", "log"))
+
+
+def test_writer_path_vs_reference_dumps(capi):
+    """lcrc_output_configure against the REFERENCE CLI's `-t post` dumps with posteriors/softening_func = log,
+    igor (two parameter sets), gmm_bypass (tools/make_golden_softening.py; srec.cpp:164-176,1062-1070): waveform
+    in, softened big-endian posteriors out, fused kernel and split-hidden path"""
+    from tools.make_golden_softening import CASES
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()[:20000]
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    ctx = capi.Lcrc(model_dir(system), 15)
+    ctx.configure_frontend(wave_format="lin16", sent_mean_norm=True)
+    for name, value in CASES.items():
+        f = value.split()
+        stage = f[0] if f[0] != "igor" else ("igor", float(f[1]), float(f[2]), float(f[3]))
+        want = read_htk(os.path.join(GOLD, "cli", "soft_%s.lop" % name))
+        for split in (1, 0):
+            ctx.set_hidden_split(split)
+            ctx.configure_output((stage,), big_endian=True)
+            got, _ = ctx.wave_to_posteriors([raw])
+            got = got.view(">f4").astype(np.float32)
+            # log-type functions turn the RELATIVE error of a posterior (up to ~5e-5 at p ~ 1e-10, far inside
+            # the 1e-4 absolute bar) into an absolute one
+            assert got.shape == want.shape and np.abs(got - want).max() < 1e-3, (name, split)
+    ctx.close()
 
 
 def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
