@@ -92,7 +92,10 @@ __device__ __forceinline__ f4 split_sum(const f4 *src, size_t stride, int n_part
 //                each runs stages 0/1 and its slice of the band nets' hidden tiles; the last arriver of a tile
 //                adds the partial output tiles, runs the band softmax and hands the merger's operand image to
 //                lcrc_split_merger_kernel through p.gimg.
-template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT>
+// PROBES = true: the diagnostic instantiation behind lcrc_posteriors_probe (stage outputs to global memory);
+//                the production kernels carry no trace of it (as run-time branches the probe stores cost ~30 % of
+//                the band nets' epilogue: their 64-bit address arithmetic was executed for every value).
+template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false>
 __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
     constexpr int BM = 16 * FT;                 // frames per workgroup
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             const int n = it >= nb ? 1 : 0, b = it - n * nb;
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (FT * nkq1 * 256);
-            float *dbg = n == 0 ? dbg_in0 : dbg_in1;
+            float *dbg = PROBES ? (n == 0 ? dbg_in0 : dbg_in1) : nullptr;
             gather(it + NW, xn);
             const int k = b * kNCoef + cc;
             const float mk = mean[k], dk = dev[k];
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                         img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                     }
                 }
-                if (dbg) {                       // stage probe (NULL in production): one uniform branch per item
+                if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
 #pragma unroll
                     for (int f = 0; f < FT; f++)
 #pragma unroll
@@ -327,18 +330,45 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         // segment (a scalar load + wait) behind every memory fence and barrier
         const int O0 = p.net[0].n_out, O1 = p.net[1].n_out, n_rows = p.row_end, merger_inp = nm.n_inp;
         float *const dbg_p0 = p.dbg_p0, *const dbg_p1 = p.dbg_p1, *const dbg_g = p.dbg_g;
-        const bool probes = dbg_p0 || dbg_p1 || dbg_g;              // NULL in production
-        auto epi = [&](int n, int i, int o, float q, bool valid) {
+        const bool probes = PROBES && (dbg_p0 || dbg_p1 || dbg_g);  // diagnostic instantiation only
+        // Row epilogue: a lane's NV band posteriors of frame i (outputs o = part + LPF*j of net n) become
+        // merger inputs k = n*O0 + o.  Straight-line and batched: all ln() first, then the normalisation
+        // constants of all values requested from LDS at once, then the (predicated) stores into the operand
+        // image.  (One basic block per value -- the obvious form -- exposed an LDS round trip per value and ran
+        // 14-16 K cycles per 32-frame tile instead of ...)
+        auto epi = [&](int n, int i, int part, auto lpf, const auto &q, int O) {
+            constexpr int LPF = decltype(lpf)::value;
+            constexpr int NV = sizeof(q) / sizeof(float);
             const int kofs = n * O0;
-            const float gl = q > 0.0f ? logf(q) : 0.0f;             // sLn dspc.h:155-160
-            if (probes && valid && r0 + i < n_rows) {
-                float *dp = n == 0 ? dbg_p0 : dbg_p1;
-                if (dp) dp[(size_t)(r0 + i) * (n == 0 ? O0 : O1) + o] = q;
-                if (dbg_g) dbg_g[(size_t)(r0 + i) * merger_inp + kofs + o] = gl;
+            const int kb = kofs + part;                              // k of value j = kb + LPF*j
+            float gl[NV], mk[NV], dk[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) {                           // (reads past n_inp stay inside the padded arrays)
+                mk[j] = mmean[kb + LPF * j];
+                dk[j] = mdev[kb + LPF * j];
             }
-            float v = gl - mmean[kofs + o];                          // Normalize nn.cpp:702-716
-            v *= mdev[kofs + o];
-            if (valid) xf_store(gf, nkqm, i, kofs + o, v);
+#pragma unroll
+            for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? logf(q[j]) : 0.0f;     // sLn dspc.h:155-160
+            if (PROBES && probes && r0 + i < n_rows) {
+                float *dp = n == 0 ? dbg_p0 : dbg_p1;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    const int o = part + LPF * j;
+                    if (o < O && dp) dp[(size_t)(r0 + i) * (n == 0 ? O0 : O1) + o] = q[j];
+                    if (o < O && dbg_g) dbg_g[(size_t)(r0 + i) * merger_inp + kofs + o] = gl[j];
+                }
+            }
+            // B-image address of (frame i, input k), see xf_store: LPF is a multiple of 4, so k & 3 is the
+            // lane's own constant and only (k >> 2) moves with j
+            float *const img = gf + ((i >> 4) * nkqm * 64 + (i & 15) + 16 * (kb & 3)) * 4;
+            const int t0 = kb >> 2;
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                float v = gl[j] - mk[j];                             // Normalize nn.cpp:702-716
+                v *= dk[j];
+                const int t = t0 + (LPF / 4) * j;
+                if (part + LPF * j < O) img[(t >> 2) * 256 + (t & 3)] = v;
+            }
         };
         if constexpr (SPLIT) {
             // ---- band phase of the split-hidden path: this workgroup's slice of both nets' hidden tiles ----
@@ -375,8 +405,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
             __syncthreads();
             const float *s01 = reinterpret_cast<const float *>(slab), *s23 = reinterpret_cast<const float *>(slab23);
-            const float *const P[2][4] = {{s01, s01, s01, s01}, {s23, s23, s23, s23}};
-            softmax_rows<NOT, NW, FT, 2, 1>(p, p.net, P, lane, wave, epi);
+            softmax_rows<NOT, NW, FT, 2, 1>(p, p.net, s01, s01, s01, s01, s23, s23, lane, wave, epi);
             __syncthreads();
             f4 *const dst = reinterpret_cast<f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
             const f4 *const src = reinterpret_cast<const f4 *>(gf);
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             if (valid) outbuf[i * O + o] = q;
         };
         run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
-                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, per_value(epi));
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;
@@ -487,8 +516,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
         if (valid) outbuf[i * O + o] = q;
     };
     const float *s0 = reinterpret_cast<const float *>(slab);
-    const float *const P[1][4] = {{s0, s0, s0, s0}};
-    softmax_rows<NOT, NW, FT, 1, 1>(p, &nm, P, lane, wave, epi);
+    softmax_rows<NOT, NW, FT, 1, 1>(p, &nm, s0, s0, s0, s0, s0, s0, lane, wave, per_value(epi));
     __syncthreads();
     const int rows = min(BM, p.row_end - r0);
     const int total = rows * O;
@@ -512,13 +540,15 @@ struct Variant {
     int ks1, ksm, n_ot;    // 0,0,0 = generic
     const void *fn[2];     // [FT - 1]: 16- and 32-frame workgroups
     const void *split_band, *split_merger;   // split-hidden path, 16-frame tiles
+    const void *probe;     // 16-frame workgroups with the stage probes (lcrc_posteriors_probe)
 };
 
 #define LCRC_KERNEL(KS1, KSM, NOT, EX) \
     {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, false>), \
      reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 2, false>)}, \
     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, true>), \
-    reinterpret_cast<const void *>(&lcrc_split_merger_kernel<KSM, NOT, kNW, EX, 1>)
+    reinterpret_cast<const void *>(&lcrc_split_merger_kernel<KSM, NOT, kNW, EX, 1>), \
+    reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, false, true>)
 
 const Variant kVariants[] = {
     {"cz_42_69_9", 42, 69, 9, LCRC_KERNEL(42, 69, 9, true)},
@@ -569,7 +599,7 @@ namespace {
 // (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
 hipError_t grant_lds(const void *fn, int vi, int slot, int dev)
 {
-    static std::atomic<bool> granted[kNVariants][4][64] = {};
+    static std::atomic<bool> granted[kNVariants][5][64] = {};
     const bool cached = dev >= 0 && dev < 64;
     if (cached && granted[vi][slot][dev]) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -651,8 +681,10 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     // least half of the CUs without work.
     int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
     if (!fits32) ft = 1;
-    const void *fn = v->fn[ft - 1];
-    e = grant_lds(fn, vi, ft - 1, dev);
+    const bool probes = p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g;
+    if (probes) ft = 1;
+    const void *fn = probes ? v->probe : v->fn[ft - 1];
+    e = grant_lds(fn, vi, probes ? 4 : ft - 1, dev);
     if (e != hipSuccess) return e;
     const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
     const int bm = 16 * ft;

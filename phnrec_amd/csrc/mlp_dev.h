@@ -380,13 +380,36 @@ __device__ __forceinline__ void store_partial(f4 *slab, int n_ot, int lane, cons
         }
 }
 
+// Epilogues receive a lane's NV posteriors of one (net, frame) row at once: q[j] belongs to output
+// o = part + LPF * j (valid while o < O; pad outputs carry 0), so that an epilogue can batch its LDS reads and
+// transcendental work over the values instead of running one basic block per value.  per_value() adapts a simple
+// per-value function `f(group, frame, o, posterior, valid)`.
+template <int V>
+struct IntTag { static constexpr int value = V; };
+
+template <typename F>
+struct PerValueEpilogue {
+    F f;
+    template <int LPF, int NV>
+    __device__ __forceinline__ void operator()(int rg, int frame, int part, IntTag<LPF>, const float (&q)[NV], int O) const
+    {
+#pragma unroll
+        for (int j = 0; j < NV; j++) f(rg, frame, part + LPF * j, q[j], part + LPF * j < O);
+    }
+};
+template <typename F>
+__device__ __forceinline__ PerValueEpilogue<F> per_value(F f) { return PerValueEpilogue<F>{f}; }
+
 // Softmax (nn.cpp:822-855) in registers on all threads over output tiles that lie in LDS slabs: group g's
 // pre-activations are the sum of its NPART partial slabs P[g][0..NPART) -- 1: as is, 2: p0 + p1,
 // 4: (p0 + p1) + (p2 + p3), a fixed order.  LPF lanes share a (net, frame) row, each holds every LPF-th
 // output.  Element (o, frame) of a slab: o = 16ot + 4g + rr, frame = 16f + c  ->  float index
 // ((FT*ot + f)*64 + 16g + c)*4 + rr.  Ends like run_net (epi called, one __syncthreads() before the calls).
+// (the slab pointers are passed one by one and group 1's are selected with ?: -- through an array of
+//  pointers hipcc loses the LDS address space and reads the slabs with flat loads)
 template <int NOT, int NW, int FT, int GROUPS, int NPART, typename Params, typename Epi>
-__device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *nets, const float *const (&P)[GROUPS][4],
+__device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *nets, const float *a0, const float *a1,
+                                             const float *a2, const float *a3, const float *b0, const float *b1,
                                              int lane, int wave, Epi epi)
 {
     constexpr int BM = 16 * FT;
@@ -398,8 +421,9 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
     const int row = tid / LPF, part = tid % LPF;
     const int rg = GROUPS == 1 ? 0 : row / BM;     // wave-uniform: a wave's rows belong to one net
     const int frame = GROUPS == 1 ? row : row % BM;
-    const float *sa = P[rg][0], *sb = P[rg][NPART > 1 ? 1 : 0];
-    const float *sc = P[rg][NPART > 2 ? 2 : 0], *sd = P[rg][NPART > 2 ? 3 : 0];
+    static_assert(GROUPS == 1 || NPART <= 2, "two groups: one or two partial slabs each");
+    const float *sa = rg == 0 ? a0 : b0, *sb = rg == 0 ? a1 : b1;
+    const float *sc = a2, *sd = a3;
     // o = part + LPF*j: because LPF is a multiple of 4 and part < LPF <= 16, the slab index of o splits
     // into a per-thread part and a COMPILE-TIME part of j (no carries between the bit fields), so the
     // reads below are base + immediate offset
@@ -444,10 +468,8 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
     __syncthreads();                          // slabs are free again (the epilogue may reuse them)
     LCRC_STAMP(prm, wave, lane, 13);
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-        const int o = part + LPF * j;
-        epi(rg, frame, o, v[j] * scale, o < O);   // o may be a pad output (>= O): loads only, no store
-    }
+    for (int j = 0; j < NV; j++) v[j] *= scale;
+    epi(rg, frame, part, IntTag<LPF>(), v, O);    // values of pad outputs (o >= O) are 0: loads only, no store
 }
 
 // Runs GROUPS nets of the same shape class at once, each on NW / GROUPS waves (GROUPS = 1: one net on all
@@ -456,10 +478,10 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 // slab01: two slabs of FT * n_ot_slab KiB; slab23: two more (with GROUPS = 2 they may alias the nets' B
 // images and anything else that is dead once every wave has left its hidden loop; with GROUPS = 1 they must
 // be free when the first wave leaves its loop).
-// On return `epi(group, frame, o, posterior, valid)` has been called with valid == true once for every
-// (group, frame, output) by SOME thread (calls with valid == false carry a pad output index o in
-// [n_out, 16 * n_ot): they may load from arrays padded to the output tiles but must not store), and a
-// __syncthreads() has been passed.
+// On return the row epilogue `epi(group, frame, part, IntTag<LPF>, q[NV], n_out)` (see PerValueEpilogue) has
+// been called by every thread: each (group, frame, output < n_out) is covered once by SOME thread; pad
+// outputs o in [n_out, 16 * n_ot) may be used for loads from arrays padded to the output tiles but must not
+// be stored.  A __syncthreads() has been passed.
 template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, typename Params, typename Epi>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
@@ -521,13 +543,10 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     }
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
     const float *s01 = reinterpret_cast<const float *>(slab01), *s23 = reinterpret_cast<const float *>(slab23);
-    if constexpr (GROUPS == 2) {
-        const float *const P[2][4] = {{s01, s01 + slab_f4 * 4, s01, s01}, {s23, s23 + slab_f4 * 4, s23, s23}};
-        softmax_rows<NOT, NW, FT, 2, 2>(prm, nets, P, lane, wave, epi);
-    } else {
-        const float *const P[1][4] = {{s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4}};
-        softmax_rows<NOT, NW, FT, 1, 4>(prm, nets, P, lane, wave, epi);
-    }
+    if constexpr (GROUPS == 2)
+        softmax_rows<NOT, NW, FT, 2, 2>(prm, nets, s01, s01 + slab_f4 * 4, s01, s01, s23, s23 + slab_f4 * 4, lane, wave, epi);
+    else
+        softmax_rows<NOT, NW, FT, 1, 4>(prm, nets, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi);
     __syncthreads();
 }
 

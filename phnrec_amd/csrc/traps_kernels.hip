@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         if (valid) outbuf[i * O + o] = q;
     };
     run_net<KS, NOT, NW, false, 1, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab + 2 * n_ot * 64, n_ot,
-                                      lane, wave, epi);
+                                      lane, wave, per_value(epi));
     const int rows = min(BM, p.n_rows - r0);
     for (int idx = tid; idx < rows * O; idx += NT) {
         const int i = idx / O, o = idx - i * O;
