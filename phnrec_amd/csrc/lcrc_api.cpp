@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,8 @@ struct lcrc_ctx {
     float normc31 = 0.f;
     float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
     size_t cap_feat_rows = 0;
+    bool traps_unfused = false;          // PHNREC_TRAPS_UNFUSED=1: 1BT_DCT as features + MLP launches (A/B, tests)
+    const char *mlp_variant = "none";    // kernel of the last merger launch (1BT_DCT / 1BT / 3BT)
     // staging for the host-pointer entry points (grown on demand)
     float *d_mel = nullptr, *d_post = nullptr;
     int *d_off = nullptr;
@@ -265,13 +268,15 @@ void fill_output_transform(const lcrc_ctx *c, int *func, float (*oc)[4], float (
     *be = c->out_be;
 }
 
-// 1BT_DCT / 1BT / 3BT: features -> [band nets ->] merger, as separate launches on the same stream
+// 1BT_DCT: ONE launch (the merger's kernel computes its C0 / DCT input rows from the mel tile it stages).
+// 1BT / 3BT: features -> band nets (one launch, grid.y = band) -> merger, on the same stream.
 int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
                  hipStream_t s)
 {
     if (n_rows <= 0) return LCRC_OK;
     const size_t Km = c->nets[2].n_inp;
-    if ((size_t)n_rows > c->cap_feat_rows) {
+    const bool fused_dct = c->system == SYS_1BT_DCT && !c->traps_unfused;
+    if (!fused_dct && (size_t)n_rows > c->cap_feat_rows) {
         const size_t cap = (size_t)n_rows + n_rows / 4 + 64;
         if (c->d_feat) (void)hipFree(c->d_feat);
         if (c->d_minp) (void)hipFree(c->d_minp);
@@ -291,10 +296,11 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     f.hamming = c->d_hamm31; f.costab = c->d_costab31; f.normc = c->normc31;
     f.out = c->d_feat;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
-    HIP_TRY(c, traps_features_launch(f, s));
+    if (!fused_dct) HIP_TRY(c, traps_features_launch(f, s));
     MlpParams m;
     memset(&m, 0, sizeof m);
     m.n_rows = n_rows;
+    m.tile_frames = c->tile_frames;
     const float *merger_in = c->d_feat;
     if (c->system != SYS_1BT_DCT) {
         m.net = c->band_max;                 // one launch, grid.y = band
@@ -308,10 +314,11 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     }
     m.net = c->nets[2];
     m.in = merger_in; m.in_ld = (long)Km;
+    if (fused_dct) { m.dct = f; m.in = nullptr; }
     m.out = d_post; m.out_ld = c->nets[2].n_out;
     m.neg_log = 0;
     fill_output_transform(c, m.out_func, m.out_c, m.out_l, &m.out_be);
-    HIP_TRY(c, mlp_launch(m, s));
+    HIP_TRY(c, mlp_launch(m, s, &c->mlp_variant));
     if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
     return LCRC_OK;
 }
@@ -669,6 +676,10 @@ int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system
     }
     auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
     c->system = sys;
+    {
+        const char *e = getenv("PHNREC_TRAPS_UNFUSED");
+        c->traps_unfused = e && *e == '1';
+    }
     c->trap_bands = trap_bands;
     c->shift = shift;
     c->use_hamming = hamming != 0;

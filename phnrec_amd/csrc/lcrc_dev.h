@@ -142,11 +142,16 @@ struct MlpParams {
     float out_l[2][2];
     int out_be;
     unsigned long long *stamps;   // unused (keeps run_net's diagnostic hooks compiling)
+    // 1BT_DCT fused: when dct.mel != NULL the net's input rows are not read from `in` but computed in the
+    // kernel from the mel tile -- the C0 / DCT projection of every band's clamped 31-point trajectory, exactly
+    // the arithmetic of traps_features_kernel mode 1 (traps.cpp:180-283, dspc.h:206-233)
+    TrapsFeatParams dct;
+    int tile_frames;     // 0 = by launch size, 16 / 32 forced
 };
 
 constexpr int kMlpKS = 256, kMlpNOT = 13;   // <= 1024 inputs, <= 208 outputs per net
 hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream);
-hipError_t mlp_launch(const MlpParams &p, hipStream_t stream);
+hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **variant = nullptr);
 bool mlp_supports(const NetDev &net);
 
 // ---- phoneme-loop Viterbi decoder (phndec_kernels.hip; "next" row f3, optional) ---------------------

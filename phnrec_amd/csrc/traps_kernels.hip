@@ -68,10 +68,25 @@ __global__ __launch_bounds__(256) void traps_features_kernel(const TrapsFeatPara
     }
 }
 
-// LDS: [mean | dev] (2 * 16 * nkq floats), B image [nkq][64] float4, four slabs [n_ot][64] float4
-__host__ __device__ inline unsigned mlp_lds_bytes(int nkq, int n_ot)
+// LDS: [mean | dev] (2 * 16 * nkq floats), B image [ft][nkq][64] float4, four slabs [n_ot][ft][64] float4, and
+// for the fused 1BT_DCT input: mel tile [(16 ft + 30)][nbanks], row bounds [2][16 ft], DCT basis [shift][31],
+// Hamming window [32]
+struct MlpLds {
+    unsigned nrm, xf, slab, tile, rowinfo, costab, hamming, total;
+};
+__host__ __device__ inline MlpLds mlp_lds_plan(int nkq, int n_ot, int ft, int dct_banks, int dct_shift)
 {
-    return 2u * 16u * nkq * 4u + (unsigned)nkq * 1024u + 4u * (unsigned)n_ot * 1024u;
+    MlpLds l;
+    unsigned o = 0;
+    l.nrm = o;     o += 2u * 16u * nkq * 4u;
+    l.xf = o;      o += (unsigned)ft * nkq * 1024u;
+    l.slab = o;    o += 4u * (unsigned)ft * n_ot * 1024u;
+    l.tile = o;    o += dct_banks ? lcrc_round16((16u * ft + 2u * kShift) * dct_banks * 4u) : 0u;
+    l.rowinfo = o; o += dct_banks ? 2u * 16u * ft * 4u : 0u;
+    l.costab = o;  o += dct_banks ? lcrc_round16((unsigned)dct_shift * kTrapLen * 4u) : 0u;
+    l.hamming = o; o += dct_banks ? 32u * 4u : 0u;
+    l.total = o;
+    return l;
 }
 
 // A NetDev read from device memory at a wave-uniform address, moved into SGPRs field by field: the weight
@@ -96,20 +111,25 @@ __device__ __forceinline__ NetDev uniform_net(const NetDev *g)
     return n;
 }
 
-template <int KS, int NOT, int NW, bool BATCHED>
+// One NeuralNet::Forward over 16*FT rows per workgroup.  EXACT: the k-steps / output tiles are the template
+// values (the shapes of the shipped LCRC band classifiers, which a 1BT_DCT model over the same banks shares);
+// otherwise run-time sizes inside a size class.
+template <int KS, int NOT, int NW, bool BATCHED, int FT, bool EXACT>
 __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = NW * 64, BM = 16;
+    constexpr int NT = NW * 64, BM = 16 * FT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NetDev nd = BATCHED ? uniform_net(p.nets_dev + blockIdx.y) : p.net;
     const float *const in = BATCHED ? p.in + (size_t)blockIdx.y * p.in_net_stride : p.in;
     float *const out = BATCHED ? p.out + __builtin_amdgcn_readfirstlane(p.out_col[blockIdx.y]) : p.out;
-    const int nkq = nd.nkq, n_ot = nd.n_ot, K = nd.n_inp, O = nd.n_out;
-    float *nrm = reinterpret_cast<float *>(smem);
-    float *xf = nrm + 2 * 16 * nkq;
-    f4 *slab = reinterpret_cast<f4 *>(xf + nkq * 256);
+    const int nkq = EXACT ? (KS + 3) / 4 : nd.nkq, n_ot = EXACT ? NOT : nd.n_ot, K = nd.n_inp, O = nd.n_out;
+    const bool dct = !BATCHED && p.dct.mel != nullptr;
+    const MlpLds L = mlp_lds_plan(nkq, n_ot, FT, dct ? p.dct.trap_bands : 0, dct ? p.dct.shift : 0);
+    float *nrm = reinterpret_cast<float *>(smem + L.nrm);
+    float *xf = reinterpret_cast<float *>(smem + L.xf);
+    f4 *slab = reinterpret_cast<f4 *>(smem + L.slab);
     const int r0 = blockIdx.x * BM;
 
     for (int i = tid; i < 16 * nkq; i += NT) {
@@ -119,16 +139,82 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     {
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
         f4 *z = reinterpret_cast<f4 *>(xf);
-        for (int i = tid; i < nkq * 64; i += NT) z[i] = zero;
+        for (int i = tid; i < FT * nkq * 64; i += NT) z[i] = zero;
     }
-    __syncthreads();
-    for (int idx = tid; idx < BM * K; idx += NT) {
-        const int i = idx / K, k = idx - i * K;
-        const int r = r0 + i;
-        float v = r < p.n_rows ? in[(size_t)r * p.in_ld + k] : 0.0f;
-        v = v - nrm[k];                                      // Normalize nn.cpp:702-716
-        v *= nrm[16 * nkq + k];
-        xf_store(xf, nkq, i, k, v);
+    if (dct) {
+        // ---- fused 1BT_DCT input (AddVectorToBEMatrix + CalcInputFeaturesForBandNets, traps.cpp:180-283) ----
+        const TrapsFeatParams &d = p.dct;
+        const int nb = d.nbanks, tb = d.trap_bands, shift = d.shift;
+        float *tile = reinterpret_cast<float *>(smem + L.tile);
+        int *rowlo = reinterpret_cast<int *>(smem + L.rowinfo), *rowhi = rowlo + BM;
+        float *ct = reinterpret_cast<float *>(smem + L.costab), *hm = reinterpret_cast<float *>(smem + L.hamming);
+        const int tbase = r0 - kShift, trows = BM + 2 * kShift;
+        for (int i = tid; i < trows * tb; i += NT) {        // bands >= trap_bands are never used (3BT has no DCT form)
+            const int row = tbase + i / tb, b = i - (i / tb) * tb;
+            tile[i] = (row >= 0 && row < d.n_rows) ? d.mel[(size_t)row * nb + b] : 0.0f;
+        }
+        const int n_dct = shift - (d.add_c0 ? 1 : 0);
+        for (int i = tid; i < n_dct * kTrapLen; i += NT) ct[i] = d.costab[i];
+        if (tid < kTrapLen) hm[tid] = d.hamming[tid];
+        if (tid < BM) {
+            const int r = min(r0 + tid, d.n_rows - 1);
+            int lo = 0, hi = d.n_rows - 1;
+            if (d.off) {                                     // largest u with off[u] <= r
+                int a = 0, e = d.n_utts;
+                while (e - a > 1) {
+                    const int mid = (a + e) >> 1;
+                    if (d.off[mid] <= r) a = mid; else e = mid;
+                }
+                lo = d.off[a];
+                hi = d.off[a + 1] - 1;
+            }
+            rowlo[tid] = lo;
+            rowhi[tid] = hi;
+        }
+        __syncthreads();
+        for (int pair = tid; pair < BM * tb; pair += NT) {
+            const int i = pair / tb, b = pair - i * tb;
+            const int r = min(r0 + i, d.n_rows - 1), lo = rowlo[i], hi = rowhi[i];
+            float x[kTrapLen];
+#pragma unroll
+            for (int tap = 0; tap < kTrapLen; tap++) {
+                const int srow = max(lo, min(hi, r - kShift + tap));
+                float v = tile[(srow - tbase) * tb + b];
+                if (d.use_hamming) v = v * hm[tap];          // sMultVect, traps.cpp:236-243
+                x[tap] = v;
+            }
+            int k = b * shift;
+            if (d.add_c0) {                                  // CalcC0 dspc.h:223-233
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kTrapLen; j++) sum += x[j];
+                sum *= d.normc;
+                float v = sum - nrm[k];                      // Normalize nn.cpp:702-716
+                v *= nrm[16 * nkq + k];
+                xf_store(xf, nkq, i, k, v);
+                k++;
+            }
+            for (int c = 0; c < n_dct; c++, k++) {           // sDCT dspc.h:206-221: sequential f32 sum, then the scale
+                float acc = 0.0f;
+                const float *cc = ct + c * kTrapLen;
+#pragma unroll
+                for (int j = 0; j < kTrapLen; j++) acc += x[j] * cc[j];
+                acc *= d.normc;
+                float v = acc - nrm[k];
+                v *= nrm[16 * nkq + k];
+                xf_store(xf, nkq, i, k, v);
+            }
+        }
+    } else {
+        __syncthreads();
+        for (int idx = tid; idx < BM * K; idx += NT) {
+            const int i = idx / K, k = idx - i * K;
+            const int r = r0 + i;
+            float v = r < p.n_rows ? in[(size_t)r * p.in_ld + k] : 0.0f;
+            v = v - nrm[k];                                      // Normalize nn.cpp:702-716
+            v *= nrm[16 * nkq + k];
+            xf_store(xf, nkq, i, k, v);
+        }
     }
     __syncthreads();
 
@@ -144,8 +230,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         }
         if (valid) outbuf[i * O + o] = q;
     };
-    run_net<KS, NOT, NW, false, 1, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab + 2 * n_ot * 64, n_ot,
-                                      lane, wave, per_value(epi));
+    run_net<KS, NOT, NW, EXACT, FT, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab + 2 * FT * n_ot * 64, n_ot,
+                                       lane, wave, per_value(epi));
     const int rows = min(BM, p.n_rows - r0);
     for (int idx = tid; idx < rows * O; idx += NT) {
         const int i = idx / O, o = idx - i * O;
@@ -155,7 +241,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
 
 bool mlp_supports(const NetDev &net)
 {
-    return net.ksteps <= kMlpKS && net.n_ot <= kMlpNOT && mlp_lds_bytes(net.nkq, net.n_ot) <= 160u * 1024u;
+    return net.ksteps <= kMlpKS && net.n_ot <= kMlpNOT && mlp_lds_plan(net.nkq, net.n_ot, 1, 64, kTrapLen).total <= 160u * 1024u;
 }
 
 hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream)
@@ -166,36 +252,80 @@ hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t mlp_launch(const MlpParams &p, hipStream_t stream)
+namespace {
+
+constexpr int kMlpNW = 4;
+struct MlpVariant {
+    const char *name;
+    int ks, n_ot;            // exact k-steps / output tiles, or the class's maxima
+    bool exact, batched;
+    const void *fn[2];       // [FT - 1]; NULL = not built
+};
+#define MLP_FN(KS, NOT, B, FT, EX) reinterpret_cast<const void *>(&mlp_kernel<KS, NOT, kMlpNW, B, FT, EX>)
+const MlpVariant kMlp[] = {
+    // the band-classifier shapes of the shipped systems (32-frame workgroups; small launches use the classes)
+    {"mlp_42_9", 42, 9, true, false, {nullptr, MLP_FN(42, 9, false, 2, true)}},
+    {"mlp_42_12", 42, 12, true, false, {nullptr, MLP_FN(42, 12, false, 2, true)}},
+    {"mlp_42_10", 42, 10, true, false, {nullptr, MLP_FN(42, 10, false, 2, true)}},
+    {"mlp_64_8", 64, 8, true, false, {nullptr, MLP_FN(64, 8, false, 2, true)}},
+    // size classes (k-steps, output tiles): the loops are unrolled over the class's maxima, so a small net in a
+    // large class would step over mostly empty entries
+    {"mlp_le8_4", 8, 4, false, false, {MLP_FN(8, 4, false, 1, false), MLP_FN(8, 4, false, 2, false)}},
+    {"mlp_le64", 64, kMlpNOT, false, false, {MLP_FN(64, kMlpNOT, false, 1, false), MLP_FN(64, kMlpNOT, false, 2, false)}},
+    {"mlp_le128", 128, kMlpNOT, false, false, {MLP_FN(128, kMlpNOT, false, 1, false), MLP_FN(128, kMlpNOT, false, 2, false)}},
+    {"mlp_le256", kMlpKS, kMlpNOT, false, false, {MLP_FN(kMlpKS, kMlpNOT, false, 1, false), MLP_FN(kMlpKS, kMlpNOT, false, 2, false)}},
+    // many nets in one launch (grid.y = net): the band classifiers of 1BT / 3BT take 31 inputs
+    {"mlp_nets_le8_4", 8, 4, false, true, {MLP_FN(8, 4, true, 1, false), nullptr}},
+    {"mlp_nets_le64", 64, kMlpNOT, false, true, {MLP_FN(64, kMlpNOT, true, 1, false), nullptr}},
+};
+constexpr int kNMlp = sizeof kMlp / sizeof kMlp[0];
+
+}  // namespace
+
+hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **variant)
 {
     // batched form: the caller vouches for every net (mlp_supports) and passes the maxima in net.{ksteps,nkq,n_ot}
     if (!mlp_supports(p.net)) return hipErrorInvalidValue;
     if (p.n_rows <= 0 || (p.nets_dev && p.n_nets <= 0)) return hipSuccess;
-    constexpr int NW = 4;
-    // four size classes of the same kernel (k-steps, output tiles): the loops are unrolled over the class's
-    // maxima, so a small net in a large class would step over mostly empty entries
-    const int cls = (p.net.ksteps <= 8 && p.net.n_ot <= 4) ? 0 : p.net.ksteps <= 64 ? 1 : p.net.ksteps <= 128 ? 2 : 3;
     const bool batched = p.nets_dev != nullptr;
-    const void *fn = batched ? (cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW, true>)
-                                         : reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW, true>))
-                   : cls == 0 ? reinterpret_cast<const void *>(&mlp_kernel<8, 4, NW, false>)
-                   : cls == 1 ? reinterpret_cast<const void *>(&mlp_kernel<64, kMlpNOT, NW, false>)
-                   : cls == 2 ? reinterpret_cast<const void *>(&mlp_kernel<128, kMlpNOT, NW, false>)
-                              : reinterpret_cast<const void *>(&mlp_kernel<kMlpKS, kMlpNOT, NW, false>);
-    if (batched && cls >= 2) return hipErrorInvalidValue;    // band classifiers take 31 inputs
-    static std::atomic<bool> granted[2][4][64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !granted[batched][cls][dev]) {
+    static std::atomic<int> cus[64] = {};
+    const bool cached = dev >= 0 && dev < 64;
+    int n_cu = cached ? cus[dev].load() : 0;
+    if (n_cu == 0) {
+        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        if (cached) cus[dev] = n_cu;
+    }
+    // 32-frame workgroups (every weight fragment serves two frame tiles) once they fill at least half of the CUs
+    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 > n_cu / 2 ? 2 : 1);
+    const int dct_banks = (!batched && p.dct.mel) ? p.dct.trap_bands : 0, dct_shift = dct_banks ? p.dct.shift : 0;
+    if (batched || mlp_lds_plan(p.net.nkq, p.net.n_ot, ft, dct_banks, dct_shift).total > 160u * 1024u) ft = 1;
+    const MlpVariant *v = nullptr;
+    for (const MlpVariant &c : kMlp) {
+        if (c.batched != batched || !c.fn[ft - 1]) continue;
+        if (c.exact ? (c.ks == p.net.ksteps && c.n_ot == p.net.n_ot) : (p.net.ksteps <= c.ks && p.net.n_ot <= c.n_ot)) {
+            v = &c;
+            break;
+        }
+    }
+    if (!v) return hipErrorInvalidValue;                     // (batched nets beyond 64 k-steps: band classifiers take 31 inputs)
+    if (variant) *variant = v->name;
+    const void *fn = v->fn[ft - 1];
+    static std::atomic<bool> granted[kNMlp][2][64] = {};
+    const int vi = (int)(v - kMlp);
+    if (!cached || !granted[vi][ft - 1][dev]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) granted[batched][cls][dev] = true;
+        if (cached) granted[vi][ft - 1][dev] = true;
     }
     MlpParams args = p;
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((p.n_rows + 15) / 16, p.nets_dev ? p.n_nets : 1), dim3(NW * 64), kargs,
-                           mlp_lds_bytes(p.net.nkq, p.net.n_ot), stream);
+    const int bm = 16 * ft;
+    return hipLaunchKernel(fn, dim3((p.n_rows + bm - 1) / bm, batched ? p.n_nets : 1), dim3(kMlpNW * 64), kargs,
+                           mlp_lds_plan(p.net.nkq, p.net.n_ot, ft, dct_banks, dct_shift).total, stream);
 }
 
 }  // namespace phnrec

@@ -570,6 +570,20 @@ def test_other_posterior_systems(capi, oracle_mod, tmp_path):
         assert np.abs(got2 - o.posteriors_batch(mel2, off2)).max() < TOL, name
         assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2)                  # deterministic
         assert np.array_equal(ctx.posteriors_staged(mel2, off2), got2)
+        # 16- and 32-frame workgroups give the same bits; so does 1BT_DCT's separate-launch form (features
+        # kernel + MLP kernel) against the fused default (the projection's arithmetic is the same code)
+        for frames in (16, 32):
+            ctx.set_tile_frames(frames)
+            assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2), (name, frames)
+        ctx.set_tile_frames(0)
+        if system == "1BT_DCT":
+            os.environ["PHNREC_TRAPS_UNFUSED"] = "1"
+            try:
+                ctx2 = capi.Lcrc(d, nb, system=system, add_c0=add_c0, hamming=hamming)
+            finally:
+                del os.environ["PHNREC_TRAPS_UNFUSED"]
+            assert np.array_equal(ctx2.posteriors_batch(mel2, off2), got2), name
+            ctx2.close()
         # streaming form == whole-utterance form (window ending at pushed frame i is centred at i - 15)
         u = mel2[int(off2[2]):int(off2[3])][:60]
         whole = ctx.posteriors(u)

@@ -16,8 +16,12 @@ from phnrec_amd import capi, modelgen  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
     capi.load()
-    for system, kw in (("1BT_DCT", dict(coefs=11)), ("1BT", dict(band_out=24, band_hidden=100))):
+    for system, kw, unfused in (("1BT_DCT", dict(coefs=11), False), ("1BT_DCT", dict(coefs=11), True),
+                                ("1BT", dict(band_out=24, band_hidden=100), False)):
         with tempfile.TemporaryDirectory() as d:
+            os.environ.pop("PHNREC_TRAPS_UNFUSED", None)
+            if unfused:
+                os.environ["PHNREC_TRAPS_UNFUSED"] = "1"   # round 1's form: features kernel + MLP kernel
             modelgen.write_traps_dir(d, system, 15, 1500, 138, seed=5, **kw)
             ctx = capi.Lcrc(d, 15, system=system)
             mel = torch.from_numpy(modelgen.synth_mel(n, 15, seed=1)).cuda()
@@ -35,8 +39,8 @@ def main():
             ms = e0.elapsed_time(e1) / 20
             dims = [ctx.net_dims(i) for i in range((0 if system == "1BT_DCT" else 15) + 1)]
             flop = sum(2 * (a * b + b * c) for a, b, c in dims)
-            print("%-8s %d frames: %.3f ms per batch = %.2f M frames/s; nets %s ...; %.1f TFLOP/s algorithmic = %.0f %% of f32 MFMA peak"
-                  % (system, n, ms, n / ms / 1e3, dims[-1], n * flop / (ms * 1e-3) / 1e12, 100 * n * flop / (ms * 1e-3) / 157.3e12))
+            print("%-8s%s %d frames: %.3f ms per batch = %.2f M frames/s; nets %s ...; %.1f TFLOP/s algorithmic = %.0f %% of f32 MFMA peak"
+                  % (system, " (features + MLP launches)" if unfused else " (one launch)" if system == "1BT_DCT" else "", n, ms, n / ms / 1e3, dims[-1], n * flop / (ms * 1e-3) / 1e12, 100 * n * flop / (ms * 1e-3) / 157.3e12))
             ctx.close()
 
 
