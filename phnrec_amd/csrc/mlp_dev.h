@@ -220,13 +220,14 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
 // of entry i + R (possibly of the next tile) is requested into the slot just consumed: every
 // fragment is requested R groups (>= R * 256 cycles) before its use, and at most R requests
 // are in flight, so the in-order vmcnt waits never drain more than the one fragment needed.
-constexpr int lcrc_ring_size(int f)
+constexpr int lcrc_ring_size(int f, int n_ot = 0)
 {
 #ifdef LCRC_RING_FIXED      // A/B switch (tools/ab_kernel.py)
     return LCRC_RING_FIXED;
 #endif
     int best = 8, pad = 1 << 30;
-    for (int r = 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
+    // (12 or more output tiles: at most 10 slots -- with 12 the 32-frame variants spill accumulators to AGPRs)
+    for (int r = n_ot >= 12 ? 10 : 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
         const int p = (f + r - 1) / r * r - f;
         if (p < pad) { pad = p; best = r; }
     }
@@ -237,7 +238,7 @@ template <int KS, int NOT, int FT, bool EXACT>
 struct RingLoop {
     static constexpr int NKQ = (KS + 3) / 4;
     static constexpr int F = NOT + NKQ;
-    static constexpr int R = lcrc_ring_size(F);
+    static constexpr int R = lcrc_ring_size(F, NOT);
     static constexpr int FP = (F + R - 1) / R * R;
     enum { PRO = 0, MID = 1, LAST = 2 };
 
