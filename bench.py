@@ -317,6 +317,53 @@ def cli_e2e_leg(mdir, n_files, gpu):
     return out
 
 
+def reference_cli_leg(mdir, gpu):
+    """The LITERAL drop-in: the reference's own command line (its phnrec.cpp / srec.cpp / melbanks.cpp / phndec.cpp,
+    compiled from /root/reference in the build container by tests/integration/Makefile) with class Traps forwarding
+    to this library (INTEGRATION.md option (a)).  Single-threaded host code as the reference wrote it; offline,
+    one Traps::CalcFeaturesBunched call per file."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "integration", "_build", "phnrec_ref_lcrc")
+    if not os.path.exists(exe):
+        return None
+    raw = os.path.join(ROOT, "tests", "golden", "test.raw")
+    if not os.path.exists(raw):
+        return None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        blob = open(raw, "rb").read()
+        n_files, per = 40, 8                       # 40 files of 8 x test.raw (59.9 s each, 5990 frames)
+        names = []
+        for i in range(n_files):
+            p = os.path.join(td, "f%03d.raw" % i)
+            with open(p, "wb") as f:
+                f.write(blob * per)
+            names.append(p)
+        lst = os.path.join(td, "list.scp")
+        with open(lst, "w") as f:
+            f.write("".join(n + "\n" for n in names))
+        frames = n_files * ((len(blob) * per // 2 - 200) // 80 + 1)
+        env = dict(os.environ, PHNREC_DEVICE=str(gpu))
+        out = {"files": n_files, "frames": frames,
+               "what": "reference CLI (its own single-threaded front-end, decoder and file loop) over libphnrec_lcrc.so "
+                       "through the Traps binding of INTEGRATION.md; wall clock of the whole process minus that of a "
+                       "1-file run (start-up, model load)"}
+        try:
+            t0 = time.perf_counter()
+            subprocess.run([exe, "-c", mdir, "-i", names[0], "-o", os.path.join(td, "one.rec")], env=env, check=True,
+                           capture_output=True, timeout=120)
+            t_one = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "out.mlf")], env=env, check=True,
+                           capture_output=True, timeout=300)
+            t_all = time.perf_counter() - t0
+            per_file = (t_all - t_one) / (n_files - 1)
+            out.update({"value": round(frames / n_files / per_file, 1), "unit": "frames/s",
+                        "process_wall_s": round(t_all, 3), "one_file_process_wall_s": round(t_one, 3)})
+        except Exception as e:
+            out["error"] = repr(e)
+        return out
+
+
 def stub_main(args, ranks):
     """Launcher self-test: everything of the N-rank harness except the GPU (see --stub)."""
     from phnrec_amd import distrun
@@ -503,7 +550,8 @@ def main():
             if ranks.world == 1 and not args.no_extras:
                 for key, leg in (("small_launches", lambda: small_launch_legs(capi, modelgen, dev, stream)),
                                  ("wave_path", lambda: wave_path_leg(capi, mdir, nb, gpu)),
-                                 ("cli_e2e", lambda: cli_e2e_leg(mdir, args.cli_files, gpu) if args.cli_files > 0 else None)):
+                                 ("cli_e2e", lambda: cli_e2e_leg(mdir, args.cli_files, gpu) if args.cli_files > 0 else None),
+                                 ("dropin_reference_cli", lambda: reference_cli_leg(mdir, gpu))):
                     try:
                         val = leg()
                     except Exception as e:      # side legs are reported when they can be measured, never fatal

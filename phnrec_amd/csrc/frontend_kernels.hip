@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const in
 // chain (107 us for one 8192-frame utterance; the mean moves by ~1e-7 relative, posteriors by << 1e-4).  Rows
 // are grouped in blocks of kMeanBlock rows counted from the utterance's first row; within a block, row lane q of
 // Q = 256 / B' (B' = nbanks rounded up to a power of two) adds rows q, q+Q, ... in order, the Q lane sums are
-// folded by halves (q += q + Q/2, ...), and colmean_finish_kernel adds an utterance's block sums in block order.
+// folded by halves (q += q + Q/2, ...), and submean_tree_kernel adds an utterance's block sums in block order.
 // The shape depends on the utterance's own length and nbanks only: batching never changes a mean.
 constexpr int kMeanBlock = 256;
 __global__ __launch_bounds__(256) void colmean_block_kernel(const float *mel, const int *frame_off, const int *block_off,
@@ -234,26 +234,55 @@ __global__ __launch_bounds__(256) void colmean_block_kernel(const float *mel, co
     if (q == 0 && b < nbanks) partial[(size_t)blk * nbanks + b] = fold[threadIdx.x];
 }
 
-__global__ void colmean_finish_kernel(const float *partial, const int *frame_off, const int *block_off, int n_utts,
-                                      int nbanks, float *means)
+// Second step of the tree: one thread per row; the workgroup first forms the means of the (few) utterances its
+// 256 rows touch -- an utterance's block sums are added in block order, mean = sum * (1.0f / rows) -- in LDS,
+// then every row subtracts.  (A separate "finish" launch for the means cost as much as either other kernel.)
+__global__ __launch_bounds__(256) void submean_tree_kernel(float *mel, const float *partial, const int *frame_off,
+                                                           const int *block_off, int n_utts, int n_rows, int nbanks)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_utts * nbanks) return;
-    const int u = i / nbanks, b = i - u * nbanks;
-    const int rows = frame_off[u + 1] - frame_off[u];
-    if (rows <= 0) return;
-    float sum = 0.0f;
-    const int k0 = block_off[u], k1 = block_off[u + 1];
-    int k = k0;
-    for (; k + 8 <= k1; k += 8) {                 // eight independent loads in flight, added in block order
-        float v[8];
+    __shared__ float wg_means[4 * 64];          // up to 4 utterances x 64 banks cached; later ones are recomputed per row
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    auto utt_of = [&](int row) {
+        int lo = 0, hi = n_utts;                // largest u with frame_off[u] <= row (skips empty utterances)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (frame_off[mid] <= row) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    auto mean_of = [&](int u, int b) {
+        const int rows = frame_off[u + 1] - frame_off[u];
+        const int k0 = block_off[u], k1 = block_off[u + 1];
+        float sum = 0.0f;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {           // eight independent loads in flight, added in block order
+            float v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = partial[(size_t)(k + q) * nbanks + b];
+            for (int q = 0; q < 8; q++) v[q] = partial[(size_t)(k + q) * nbanks + b];
 #pragma unroll
-        for (int q = 0; q < 8; q++) sum += v[q];
+            for (int q = 0; q < 8; q++) sum += v[q];
+        }
+        for (; k < k1; k++) sum += partial[(size_t)k * nbanks + b];
+        return sum * (1.0f / (float)rows);
+    };
+    const int row_first = blockIdx.x * 256, row_last = min(n_rows, row_first + 256) - 1;
+    const int u_first = utt_of(row_first);
+    {
+        const int slot = threadIdx.x / 64, b = threadIdx.x % 64;       // utterance u_first + slot, bank b
+        const int u = u_first + slot;
+        if (b < nbanks && u < n_utts && frame_off[u] <= row_last && frame_off[u + 1] > frame_off[u])
+            wg_means[threadIdx.x] = mean_of(u, b);
     }
-    for (; k < k1; k++) sum += partial[(size_t)k * nbanks + b];
-    means[(size_t)u * nbanks + b] = sum * (1.0f / (float)rows);
+    __syncthreads();
+    if (r >= n_rows) return;
+    const int u = utt_of(r);
+    float *x = mel + (size_t)r * nbanks;
+    if (u - u_first < 4) {
+        const float *m = wg_means + (u - u_first) * 64;
+        for (int b = 0; b < nbanks; b++) x[b] += -m[b];
+    } else {
+        for (int b = 0; b < nbanks; b++) x[b] += -mean_of(u, b);
+    }
 }
 
 __global__ void submean_kernel(float *mel, const int *frame_off, int n_utts, int n_rows, int nbanks,
@@ -293,8 +322,8 @@ hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_of
         colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
     } else {
         colmean_block_kernel<<<n_blocks, 256, 0, stream>>>(mel, frame_off, block_off, n_utts, nbanks, partial);
-        colmean_finish_kernel<<<(n_utts * nbanks + 255) / 256, 256, 0, stream>>>(partial, frame_off, block_off, n_utts,
-                                                                                  nbanks, means);
+        submean_tree_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, partial, frame_off, block_off, n_utts, n_rows, nbanks);
+        return hipGetLastError();
     }
     submean_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, frame_off, n_utts, n_rows, nbanks, means);
     return hipGetLastError();

@@ -233,7 +233,6 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             const int tap = 4 * s4 + g;
             basis[s4] = c == 0 ? 1.0f : (c < kNCoef ? costab[(c - 1) * 16 + tap] : 0.0f);
         }
-        const int items = 2 * nb;                // (net, band) pairs, dealt to the waves
         // per-lane constants of both frame tiles: clamp bounds and centre row
         int rr[FT], lo[FT], hi[FT];
 #pragma unroll
@@ -260,61 +259,65 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                     roff[n][f][s4] = (srow - tbase) * nb;
                 }
             }
-        // The operand values of item i + NW are read (independent LDS gathers) before the MFMAs of item i:
+        // One loop per half context (n = 0: left, 1: right), bands dealt to the waves.  The operand values and the
+        // normalisation constants of band b + NW are requested (independent LDS reads) before the MFMAs of band b:
         // the compiler cannot move LDS reads above the previous item's operand-image stores by itself.
-        auto gather = [&](int it, float (&x)[FT][4]) {
-            const int itc = min(it, items - 1);
-            const int n = itc >= nb ? 1 : 0, b = itc - n * nb;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++)
-#pragma unroll
-                for (int f = 0; f < FT; f++)
-                    x[f][s4] = melT[(n ? roff[1][f][s4] : roff[0][f][s4]) + b] * (n ? wv[1][s4] : wv[0][s4]);
-        };
-        float xw[FT][4], xn[FT][4];
-        gather(wave, xw);
-        for (int it = wave; it < items; it += NW) {
-            const int n = it >= nb ? 1 : 0, b = it - n * nb;
+        for (int n = 0; n < 2; n++) {
             const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
             float *img = xf + (size_t)n * (FT * nkq1 * 256);
             float *dbg = PROBES ? (n == 0 ? dbg_in0 : dbg_in1) : nullptr;
-            gather(it + NW, xn);
-            const int k = b * kNCoef + cc;
-            const float mk = mean[k], dk = dev[k];
-            f4 acc[FT];
+            auto gather = [&](int b, float (&x)[FT][4], float &mk, float &dk) {
+                const int bc = min(b, nb - 1);
 #pragma unroll
-            for (int f = 0; f < FT; f++) acc[f] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++)
+                    for (int f = 0; f < FT; f++) x[f][s4] = melT[roff[n][f][s4] + bc] * wv[n][s4];
+                mk = mean[bc * kNCoef + cc];
+                dk = dev[bc * kNCoef + cc];
+            };
+            float xw[FT][4], xn[FT][4], mk, dk, mkn, dkn;
+            gather(wave, xw, mk, dk);
+            for (int b = wave; b < nb; b += NW) {
+                gather(b + NW, xn, mkn, dkn);
+                const int k = b * kNCoef + cc;
+                f4 acc[FT];
 #pragma unroll
-                for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(xw[f][s4], basis[s4], acc[f]);
-            if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
-                // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
-                const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
+                for (int f = 0; f < FT; f++) acc[f] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int f = 0; f < FT; f++) {
+                for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
-                        float v = val - mk;                              // Normalize nn.cpp:702-716
-                        v *= dk;
-                        img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
-                    }
-                }
-                if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
+                    for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(xw[f][s4], basis[s4], acc[f]);
+                if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
+                    // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
+                    const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
 #pragma unroll
-                    for (int f = 0; f < FT; f++)
+                    for (int f = 0; f < FT; f++) {
 #pragma unroll
                         for (int reg = 0; reg < 4; reg++) {
-                            const int fr = 16 * f + 4 * g + reg;
-                            if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
+                            const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
+                            float v = val - mk;                              // Normalize nn.cpp:702-716
+                            v *= dk;
+                            img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                         }
+                    }
+                    if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
+#pragma unroll
+                        for (int f = 0; f < FT; f++)
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++) {
+                                const int fr = 16 * f + 4 * g + reg;
+                                if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
+                            }
+                    }
                 }
+#pragma unroll
+                for (int f = 0; f < FT; f++)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) xw[f][s4] = xn[f][s4];
+                mk = mkn;
+                dk = dkn;
             }
-#pragma unroll
-            for (int f = 0; f < FT; f++)
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) xw[f][s4] = xn[f][s4];
         }
     }
     __syncthreads();
@@ -616,11 +619,22 @@ int choose_split(const LcrcParams &p, int tiles, int n_cu)
 {
     if (!p.part || !p.gimg || !p.cnt || p.split_hint == 1 || tiles <= 0) return 1;
     if (p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g || p.stamps) return 1;   // probes: fused kernel only
-    int s = n_cu / tiles;
-    if (p.split_hint > 1) s = p.split_hint;          // forced: may oversubscribe the CUs (tuning)
-    else s = min(s, kSplitMax);
+    if (p.split_hint > 1) return max(1, min(p.split_hint, p.split_cap_wgs / tiles));   // forced: may oversubscribe the CUs (tuning)
+    int s = min(n_cu / tiles, kSplitMax);
     s = min(s, p.split_cap_wgs / tiles);
-    return s < 2 ? 1 : s;
+    // at least one hidden tile per wave in both phases, or the extra workgroups only add to the seam
+    s = min(s, max(1, min(max(p.net[0].nht, p.net[1].nht) / 2, p.net[2].nht / 4)));
+    if (s < 2) return 1;
+    // Worth it?  A tile's hidden loops take about h_us on one CU (its MFMA work at ~80 % of a CU's f32 rate);
+    // splitting saves h_us * (1 - 1/s) and pays the seam twice (publish, ticket, slab reads by the last arriver,
+    // the second launch): ~14 us on an idle chip, ~24 us when the split grid fills it (measured,
+    // profiles/r02_small_launch_sweep.txt: EN at 2048 frames is faster fused, CZ 25 us faster split).
+    double macs = 0.0;
+    for (int i = 0; i < 3; i++) macs += (double)p.net[i].n_hid * (p.net[i].n_inp + p.net[i].n_out);
+    const double h_us = 16.0 * 2.0 * macs / 490e3;          // 490 GFLOP/s per CU
+    const double load = (double)tiles * s / n_cu;
+    const double seam_us = 14.0 + 10.0 * (load < 1.0 ? load : 1.0);
+    return h_us * (1.0 - 1.0 / s) >= seam_us ? s : 1;
 }
 
 }  // namespace

@@ -241,6 +241,23 @@ def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
         assert open(f, "rb").read() == blob, f
 
 
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 started plainly (no launcher): the parent starts two ranks itself before touching the GPU;
+    PHNREC_DEVICE_MAP=0,0 puts both on the one GPU of this box (functional run: rendezvous over gloo, labelled
+    oversubscribed); rank 0 prints one line whose rank count is what the process group saw"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PHNREC_DEVICE_MAP"] = "0,0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--preheat", "0", "--no-cpu", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"]["world"] == 2 and line["ranks"]["oversubscribed"] is True
+    assert line["ranks"]["device_map"] == [0, 0] and line["n_gpus"] == 1
+    assert line["value"] > 0 and line["steps"] == 5
+
+
 def test_more_gpus_than_the_box_has_fails_loudly(tmp_path):
     lst = _make_list(tmp_path, "cz", 3, seed=1)
     e = dict(os.environ)
