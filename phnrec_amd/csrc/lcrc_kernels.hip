@@ -49,17 +49,23 @@
 
 namespace phnrec {
 
-// The last-arriver seam of the split-hidden path (guide recipe: plain slab stores, every wave drains its
-// stores, barrier, ONE lane releases at agent scope and draws a ticket; the workgroup that draws the last
-// ticket acquires at agent scope and reads every slab).  Returns true in the workgroup that finishes the tile.
-// Correct for any placement of a tile's workgroups over CUs / XCDs; nobody waits for anybody.
+// The last-arriver seam of the split-hidden path (guide recipe, write-through form: the partial tiles are stored
+// sc1 -- straight through the XCD's L2, so no release fence (an L2 write-back, ~6 us under load) is needed --,
+// every wave drains its stores, barrier, ONE lane draws a ticket with a relaxed agent-scope add; the workgroup that
+// draws the last ticket acquires at agent scope and reads every slab with plain loads).  Returns true in the
+// workgroup that finishes the tile.  Correct for any placement of a tile's workgroups over CUs / XCDs; nobody waits
+// for anybody.
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_through(f4 v, __amdgpu_buffer_rsrc_t rsrc, int index)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rsrc, index * 16, 0, 16);    // aux 16 = sc1
+}
+
 __device__ __forceinline__ bool split_arrive(unsigned *counter, int n_arrivals, int *lds_ticket, int tid)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *lds_ticket = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -391,12 +397,13 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 store_partial<NOT, EXACT, FT>((grp == 0 ? slab : slab23) + wig * slab_f4, EXACT ? NOT : nd.n_ot, lane, acc);
                 __syncthreads();
             }
-            // the workgroup's partial tiles (wave 0 + wave 1 per net) leave as whole 1-KiB wave stores
-            f4 *const mine = reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * 2 * slab_f4;
+            // the workgroup's partial tiles (wave 0 + wave 1 per net) leave as whole 1-KiB write-through wave stores
+            const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * 2 * slab_f4, 0, 2 * slab_f4 * 16, 0x00020000);
             for (int i = tid; i < 2 * slab_f4; i += NTH) {
                 const int gq = i >= slab_f4 ? 1 : 0, j = i - gq * slab_f4;
                 const f4 *b = gq ? slab23 : slab;
-                mine[i] = b[j] + b[slab_f4 + j];
+                store_through(b[j] + b[slab_f4 + j], mine, i);
             }
             int *const ticket = reinterpret_cast<int *>(smem + lp.total);
             if (!split_arrive(p.cnt + 2 * tile, split, ticket, tid)) return;
@@ -495,9 +502,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
         store_partial<NOT, EXACT, FT>(slab + wave * slab_f4, EXACT ? NOT : nm.n_ot, lane, acc);
         __syncthreads();
     }
-    f4 *const mine = reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * slab_f4;
+    const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * slab_f4, 0, slab_f4 * 16, 0x00020000);
     for (int i = tid; i < slab_f4; i += NT)
-        mine[i] = (slab[i] + slab[slab_f4 + i]) + (slab[2 * slab_f4 + i] + slab[3 * slab_f4 + i]);
+        store_through((slab[i] + slab[slab_f4 + i]) + (slab[2 * slab_f4 + i] + slab[3 * slab_f4 + i]), mine, i);
     if (!split_arrive(p.cnt + 2 * tile + 1, split, ticket, tid)) return;
     const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)tile * split * slab_f4;
     for (int i = tid; i < slab_f4; i += NT) slab[i] = split_sum(first + i, (size_t)slab_f4, split);
@@ -626,14 +634,13 @@ int choose_split(const LcrcParams &p, int tiles, int n_cu)
     s = min(s, max(1, min(max(p.net[0].nht, p.net[1].nht) / 2, p.net[2].nht / 4)));
     if (s < 2) return 1;
     // Worth it?  A tile's hidden loops take about h_us on one CU (its MFMA work at ~80 % of a CU's f32 rate);
-    // splitting saves h_us * (1 - 1/s) and pays the seam twice (publish, ticket, slab reads by the last arriver,
-    // the second launch): ~14 us on an idle chip, ~24 us when the split grid fills it (measured,
-    // profiles/r02_small_launch_sweep.txt: EN at 2048 frames is faster fused, CZ 25 us faster split).
+    // splitting saves h_us * (1 - 1/s) and pays the two seams (publish, ticket, slab reads by the last arriver, the
+    // second launch): ~12 us, idle or full chip, with write-through slab stores (measured,
+    // profiles/r02_small_launch_sweep.txt: EN at 2048 frames gains 6 us with two workgroups per tile, CZ 39 us).
     double macs = 0.0;
     for (int i = 0; i < 3; i++) macs += (double)p.net[i].n_hid * (p.net[i].n_inp + p.net[i].n_out);
     const double h_us = 16.0 * 2.0 * macs / 490e3;          // 490 GFLOP/s per CU
-    const double load = (double)tiles * s / n_cu;
-    const double seam_us = 14.0 + 10.0 * (load < 1.0 ? load : 1.0);
+    const double seam_us = 13.0;
     return h_us * (1.0 - 1.0 / s) >= seam_us ? s : 1;
 }
 
