@@ -109,7 +109,9 @@ int lcrc_posteriors_batch(lcrc_ctx *ctx, const float *mel, const int *off, int n
  * = HIP's default stream, as everywhere in HIP).  d_off may be NULL when
  * n_utts == 1 (one utterance of n_rows frames).  Nothing is copied or
  * synchronised; the caller orders the launch against its own work through the
- * stream it passes. */
+ * stream it passes.  Small launches (see lcrc_set_hidden_split) use scratch
+ * buffers of the context: launches of ONE context must not overlap on the
+ * device then -- issue them on one stream, or pin the fused kernel. */
 int lcrc_posteriors_device(lcrc_ctx *ctx, const float *d_mel, const int *d_off, int n_utts,
                            int n_rows, float *d_post, void *hip_stream);
 

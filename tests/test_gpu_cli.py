@@ -241,6 +241,40 @@ def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
         assert open(f, "rb").read() == blob, f
 
 
+def test_bench_line_carries_every_leg():
+    """bench.py in the driver's form (shortened): ONE JSON line with the contract's keys, the roofline object with
+    its disclosed pre-heat / cold figure / traffic source, the CPU baseline, and the side legs that put the
+    streaming entry, the small-launch regime, the waveform entry and the CLI into the driver-run record"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PHNREC_DEVICE_MAP")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--preheat", "10", "--cpu-seconds", "1", "--cli-files", "60"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "preheat_launches"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["preheat_launches"] == 10
+    assert d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0.3 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["cold"]["launches"] == "1-20" and r["traffic_source"].startswith("profiles/hbm_traffic.json")
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] == 1
+    assert c["parity_max_abs_vs_gpu"] < 1e-4
+    assert d["push_bunch5"]["value"] > 50000, "the 50 k frames/s floor at the shipped bunch of 5"
+    assert d["push_bunch512"]["value"] > d["push_bunch5"]["value"]
+    assert set(d["small_launches"]) >= {"cz_2048", "cz_4096", "en_4096"}
+    assert d["wave_path"]["frames"] == 8192 and d["wave_path"]["rows_sum_to_one"] is True
+    assert d["cli_e2e"]["host_frontend"]["value"] > 50000 and d["cli_e2e"]["gpu_frontend_F"]["value"] > 50000
+    if "dropin_reference_cli" in d:
+        assert d["dropin_reference_cli"]["value"] > 50000
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py --gpus 2 started plainly (no launcher): the parent starts two ranks itself before touching the GPU;
     PHNREC_DEVICE_MAP=0,0 puts both on the one GPU of this box (functional run: rendezvous over gloo, labelled
