@@ -343,8 +343,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         // Row epilogue: a lane's NV band posteriors of frame i (outputs o = part + LPF*j of net n) become
         // merger inputs k = n*O0 + o.  Straight-line and batched: all ln() first, then the normalisation
         // constants of all values requested from LDS at once, then the (predicated) stores into the operand
-        // image.  (One basic block per value -- the obvious form -- exposed an LDS round trip per value and ran
-        // 14-16 K cycles per 32-frame tile instead of ...)
+        // image.  (One basic block per value -- the obvious form -- exposed an LDS round trip per value: 14 K
+        // cycles per 32-frame tile against 12.4 K, profiles/r02_ab_runs.txt item 3.)
         auto epi = [&](int n, int i, int part, auto lpf, const auto &q, int O) {
             constexpr int LPF = decltype(lpf)::value;
             constexpr int NV = sizeof(q) / sizeof(float);

@@ -15,6 +15,8 @@
 namespace phnrec {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+// the same in the GLOBAL address space, for pointers rebuilt from scalar registers (scalar_ptr)
+typedef __attribute__((address_space(1))) const f4 gf4;
 
 // In-kernel phase stamps exist only in the DIAGNOSTIC build (make stamps ->
 // libphnrec_lcrc_stamps.so, tools/stamp_profile.py); in the product the macro is empty.
@@ -53,38 +55,67 @@ __device__ __forceinline__ double fexp_d(float y)
 
 __device__ __forceinline__ float fexp_f(float y) { return (float)fexp_d(y); }
 
+// FEXP for y <= 0 (the softmax's arguments v_j - max): the product never reaches +2^31, and below -2^31
+// v_cvt_i32_f64 saturates to INT_MIN, which is x86's value too -- no patch needed.  (NaN gives 0 where x86
+// gives INT_MIN; a NaN row is garbage either way.)
+__device__ __forceinline__ float fexp_nonpos_f(float y)
+{
+    const double a = 1048576.0 / 0.69314718055994530942;
+    const unsigned hi = (unsigned)__double2int_rz(a * (double)y) + 1072632447u;
+    return (float)__hiloint2double((int)hi, 0);
+}
+
 // Loads the first N (1..4) components of a weight fragment.  The last float4 group of
 // layer 1 is only partly used when ksteps % 4 != 0; loading all four components would
 // leave the unused ones as dead registers with a load in flight, and the first reuse
 // of such a register costs an s_waitcnt vmcnt(0) that drains the whole prefetch.
 template <int N>
-__device__ __forceinline__ f4 load_frag(const f4 *p)
+__device__ __forceinline__ f4 load_frag(gf4 *p)
 {
-    f4 v = {0.f, 0.f, 0.f, 0.f};
+    // the components beyond N are never read (the MFMA loop stops at the net's k-steps): they stay UNDEFINED
+    // rather than zero -- zeroing them cost a v_mov per component and hidden tile
     if constexpr (N >= 4) {
-        v = *p;
+        return *p;
     } else if constexpr (N == 3) {
         typedef float f3 __attribute__((ext_vector_type(3)));
-        const f3 t = *reinterpret_cast<const f3 *>(p);
-        v[0] = t[0]; v[1] = t[1]; v[2] = t[2];
+        typedef __attribute__((address_space(1))) const f3 gf3;
+        const f3 t = *(gf3 *)p;
+        return __builtin_shufflevector(t, t, 0, 1, 2, -1);
     } else if constexpr (N == 2) {
         typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 t = *reinterpret_cast<const f2 *>(p);
-        v[0] = t[0]; v[1] = t[1];
+        typedef __attribute__((address_space(1))) const f2 gf2;
+        const f2 t = *(gf2 *)p;
+        return __builtin_shufflevector(t, t, 0, 1, -1, -1);
     } else {
-        v[0] = *reinterpret_cast<const float *>(p);
+        typedef float f1 __attribute__((ext_vector_type(1)));
+        typedef __attribute__((address_space(1))) const f1 gf1;
+        const f1 t = *(gf1 *)p;
+        return __builtin_shufflevector(t, t, 0, -1, -1, -1);
     }
-    return v;
+}
+
+// A wave-uniform pointer forced into SGPRs: address arithmetic on it runs on the scalar unit, and a load
+// `p[imm + lane]` becomes `global_load v, v_lane, s[p] offset:imm` (13-bit immediates: up to 4 fragments of
+// 1 KiB per scalar base; beyond that hipcc otherwise forms 64-bit per-lane addresses on the VALU, which the f32
+// MFMA shares).
+__device__ __forceinline__ gf4 *scalar_ptr(const f4 *p)
+{
+    // (the integer round trip would lose the address space -- flat loads count on both wait counters and drain
+    //  the prefetch -- so the result is typed as a GLOBAL pointer explicitly)
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (gf4 *)(((unsigned long long)hi << 32) | lo);
 }
 
 // ---- one MLP on the workgroup's frames -----------------------------------------------
 // XF: LDS image of the normalised input, [f][kq][lane] float4 where element j of
 //     lane l holds X[frame 16f + (l&15)][k = 16kq + 4j + (l>>4)].
 template <int KS, int NKQ, bool EXACT>
-__device__ __forceinline__ f4 load_w1_frag(const f4 *t, int kq, int lane)
+__device__ __forceinline__ f4 load_w1_frag(gf4 *t, int kq_local, int kq, int lane)
 {
-    // `t` (tile base) stays in SGPRs (saddr addressing); only lane*16 is a vector offset
-    return (EXACT && kq == NKQ - 1) ? load_frag<KS - 4 * (NKQ - 1)>(t + kq * 64 + lane) : t[kq * 64 + lane];
+    // `t` (scalar base of a group of four fragments) stays in SGPRs (saddr addressing); only lane*16 is a vector
+    // offset; kq_local = position in the group, kq = the fragment's k-group (the last one may be partial)
+    return (EXACT && kq == NKQ - 1) ? load_frag<KS - 4 * (NKQ - 1)>(t + kq_local * 64 + lane) : t[kq_local * 64 + lane];
 }
 
 // Sigmoid (nn.cpp:796-820) of the 4*FT pre-activations a lane holds, as a sequence of
@@ -124,9 +155,16 @@ struct SigTile {
         for (int i = 0; i < kN; i++) {
             switch (k) {
             case 0: t[i] = a * (double)x[i]; break;
-            case 1: {                                   // FEXP's integer hi word (see fexp_d)
-                unsigned hi = (unsigned)__double2int_rz(t[i]) + 1072632447u;
-                if (!(x[i] < 0x1.62e43p+10f)) hi = 0x80000000u + 1072632447u;
+            case 1: {
+                // FEXP's integer hi word (see fexp_d) without the compare / select of the out-of-range patch:
+                // i = -(int)trunc(-t).  Truncation is symmetric, so this is (int)trunc(t) in range; for
+                // t >= 2^31 the conversion of -t saturates to INT_MIN and -INT_MIN wraps to INT_MIN = x86's
+                // cvttsd2si value.  (For t <= -2^31, i.e. a hidden pre-activation above +1419 where the
+                // reference's own sigmoid is garbage -- FEXP wraps to -0.97 and 1/(1+e) = 33 --, this gives
+                // INT_MIN + 1: that garbage differs in the last of its 20 mantissa bits.)  The negation rides on
+                // the instruction's source modifier and on sub instead of add: two VALU instructions per value
+                // fewer in the hidden loops.
+                const unsigned hi = 1072632447u - (unsigned)__double2int_rz(-t[i]);
                 t[i] = __hiloint2double((int)hi, 0);
                 break;
             }
@@ -256,10 +294,12 @@ struct RingLoop {
     {
         if (e < NOT) {
             const int ot = EXACT ? e : min(e, n_ot - 1);
-            ring[slot] = w2[((size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) + ot) * 64 + lane];
+            const f4 *tb = w2 + (size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) * 64;
+            if (EXACT) ring[slot] = scalar_ptr(tb + (ot & ~3) * 64)[(ot & 3) * 64 + lane];
+            else ring[slot] = tb[ot * 64 + lane];
         } else if (e - NOT < NKQ) {
             const f4 *tb = w1 + (size_t)min(t + 1, hlast) * (EXACT ? NKQ : nkq) * 64;
-            if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(tb, e - NOT, lane);
+            if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(scalar_ptr(tb + ((e - NOT) & ~3) * 64), (e - NOT) & 3, e - NOT, lane);
             else ring[slot] = tb[min(e - NOT, nkq - 1) * 64 + lane];
         }
     }
@@ -455,7 +495,7 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
     for (int q = 0; q < PPL; q++) ps[q] = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
-        const float e = fexp_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
+        const float e = fexp_nonpos_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
         v[j] = part + LPF * j < O ? e : 0.0f;
         ps[j % PPL] += v[j];
     }
