@@ -296,11 +296,11 @@ struct RingLoop {
             const int ot = EXACT ? e : min(e, n_ot - 1);
             const f4 *tb = w2 + (size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) * 64;
             if (EXACT) ring[slot] = scalar_ptr(tb + (ot & ~3) * 64)[(ot & 3) * 64 + lane];
-            else ring[slot] = tb[ot * 64 + lane];
+            else ring[slot] = scalar_ptr(tb + ot * 64)[lane];
         } else if (e - NOT < NKQ) {
             const f4 *tb = w1 + (size_t)min(t + 1, hlast) * (EXACT ? NKQ : nkq) * 64;
             if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(scalar_ptr(tb + ((e - NOT) & ~3) * 64), (e - NOT) & 3, e - NOT, lane);
-            else ring[slot] = tb[min(e - NOT, nkq - 1) * 64 + lane];
+            else ring[slot] = scalar_ptr(tb + min(e - NOT, nkq - 1) * 64)[lane];
         }
     }
 
