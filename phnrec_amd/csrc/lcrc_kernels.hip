@@ -376,7 +376,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 float v = gl[j] - mk[j];                             // Normalize nn.cpp:702-716
                 v *= dk[j];
                 const int t = t0 + (LPF / 4) * j;
-                if (part + LPF * j < O) img[(t >> 2) * 256 + (t & 3)] = v;
+                // exact variants: outputs below 16 * (NOT - 1) are valid whatever n_out is -- no compare, no branch
+                if ((EXACT && LPF * j + LPF <= 16 * (NOT - 1)) || part + LPF * j < O) img[(t >> 2) * 256 + (t & 3)] = v;
             }
         };
         if constexpr (SPLIT) {
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
             __syncthreads();
             const float *s01 = reinterpret_cast<const float *>(slab), *s23 = reinterpret_cast<const float *>(slab23);
-            softmax_rows<NOT, NW, FT, 2, 1>(p, p.net, s01, s01, s01, s01, s23, s23, lane, wave, epi);
+            softmax_rows<NOT, NW, FT, 2, 1, (EXACT ? 16 * (NOT - 1) : 0)>(p, p.net, s01, s01, s01, s01, s23, s23, lane, wave, epi);
             __syncthreads();
             f4 *const dst = reinterpret_cast<f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
             const f4 *const src = reinterpret_cast<const f4 *>(gf);
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             if (valid) outbuf[i * O + o] = q;
         };
         run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
-                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, per_value(epi));
+                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave,
+                                            per_value(epi, EXACT ? 16 * (NOT - 1) : 0));
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
         if (valid) outbuf[i * O + o] = q;
     };
     const float *s0 = reinterpret_cast<const float *>(slab);
-    softmax_rows<NOT, NW, FT, 1, 1>(p, &nm, s0, s0, s0, s0, s0, s0, lane, wave, per_value(epi));
+    softmax_rows<NOT, NW, FT, 1, 1, (EXACT ? 16 * (NOT - 1) : 0)>(p, &nm, s0, s0, s0, s0, s0, s0, lane, wave,
+                                                                   per_value(epi, EXACT ? 16 * (NOT - 1) : 0));
     __syncthreads();
     const int rows = min(BM, p.row_end - r0);
     const int total = rows * O;

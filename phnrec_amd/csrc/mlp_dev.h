@@ -431,15 +431,16 @@ struct IntTag { static constexpr int value = V; };
 template <typename F>
 struct PerValueEpilogue {
     F f;
+    int ovalid;      // outputs below it are valid whatever O is (0 = unknown)
     template <int LPF, int NV>
     __device__ __forceinline__ void operator()(int rg, int frame, int part, IntTag<LPF>, const float (&q)[NV], int O) const
     {
 #pragma unroll
-        for (int j = 0; j < NV; j++) f(rg, frame, part + LPF * j, q[j], part + LPF * j < O);
+        for (int j = 0; j < NV; j++) f(rg, frame, part + LPF * j, q[j], LPF * j + LPF <= ovalid || part + LPF * j < O);
     }
 };
 template <typename F>
-__device__ __forceinline__ PerValueEpilogue<F> per_value(F f) { return PerValueEpilogue<F>{f}; }
+__device__ __forceinline__ PerValueEpilogue<F> per_value(F f, int ovalid = 0) { return PerValueEpilogue<F>{f, ovalid}; }
 
 // Softmax (nn.cpp:822-855) in registers on all threads over output tiles that lie in LDS slabs: group g's
 // pre-activations are the sum of its NPART partial slabs P[g][0..NPART) -- 1: as is, 2: p0 + p1,
@@ -448,7 +449,9 @@ __device__ __forceinline__ PerValueEpilogue<F> per_value(F f) { return PerValueE
 // ((FT*ot + f)*64 + 16g + c)*4 + rr.  Ends like run_net (epi called, one __syncthreads() before the calls).
 // (the slab pointers are passed one by one and group 1's are selected with ?: -- through an array of
 //  pointers hipcc loses the LDS address space and reads the slabs with flat loads)
-template <int NOT, int NW, int FT, int GROUPS, int NPART, typename Params, typename Epi>
+// OVALID: outputs below it are valid whatever n_out is (exact variants: n_ot == NOT, so n_out > 16 * (NOT - 1)); their
+// pad selects disappear at compile time.
+template <int NOT, int NW, int FT, int GROUPS, int NPART, int OVALID, typename Params, typename Epi>
 __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *nets, const float *a0, const float *a1,
                                              const float *a2, const float *a3, const float *b0, const float *b1,
                                              int lane, int wave, Epi epi)
@@ -481,7 +484,7 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
         float t = sa[idx];
         if (NPART >= 2) t += sb[idx];
         if (NPART == 4) t += sc[idx] + sd[idx];        // waves (0 + 1) + (2 + 3): a fixed order
-        v[j] = o < O ? t : -FLT_MAX;
+        v[j] = (LPF * j + LPF <= OVALID || o < O) ? t : -FLT_MAX;
         m = fmaxf(m, v[j]);
     }
     m = allreduce<LPF>(m, [](float a, float b) { return fmaxf(a, b); });
@@ -496,7 +499,7 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const float e = fexp_nonpos_f(v[j] - m);     // pads: FEXP(-FLT_MAX - m) is computed and discarded
-        v[j] = part + LPF * j < O ? e : 0.0f;
+        v[j] = (LPF * j + LPF <= OVALID || part + LPF * j < O) ? e : 0.0f;
         ps[j % PPL] += v[j];
     }
 #pragma unroll
@@ -584,10 +587,11 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     }
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
     const float *s01 = reinterpret_cast<const float *>(slab01), *s23 = reinterpret_cast<const float *>(slab23);
+    constexpr int OVALID = EXACT ? 16 * (NOT - 1) : 0;
     if constexpr (GROUPS == 2)
-        softmax_rows<NOT, NW, FT, 2, 2>(prm, nets, s01, s01 + slab_f4 * 4, s01, s01, s23, s23 + slab_f4 * 4, lane, wave, epi);
+        softmax_rows<NOT, NW, FT, 2, 2, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s01, s01, s23, s23 + slab_f4 * 4, lane, wave, epi);
     else
-        softmax_rows<NOT, NW, FT, 1, 4>(prm, nets, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi);
+        softmax_rows<NOT, NW, FT, 1, 4, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi);
     __syncthreads();
 }
 
