@@ -438,22 +438,13 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         const int O = nm.n_out;
         float *outbuf = reinterpret_cast<float *>(slab);
         // the writer path's settings in locals (kernarg fields are re-read behind every fence)
-        const int f0 = p.out_func[0], f1 = p.out_func[1], be = p.out_be;
-        float c0[3], c1[3], l0[2], l1[2];
-        for (int i = 0; i < 3; i++) { c0[i] = p.out_c[0][i]; c1[i] = p.out_c[1][i]; }
-        for (int i = 0; i < 2; i++) { l0[i] = p.out_l[0][i]; l1[i] = p.out_l[1][i]; }
-        const bool transform = (f0 | f1 | be) != 0;
-        auto epi = [&](int, int i, int o, float q, bool valid) {
-            if (transform) {                     // posterior writer path: softening, byte order
-                q = soften(f0, c0, l0, q);
-                q = soften(f1, c1, l1, q);
-                if (be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
-            }
-            if (valid) outbuf[i * O + o] = q;
-        };
+        WriterPathEpilogue epi;
+        epi.outbuf = outbuf; epi.O = O; epi.f0 = p.out_func[0]; epi.f1 = p.out_func[1]; epi.be = p.out_be;
+        epi.ovalid = EXACT ? 16 * (NOT - 1) : 0;
+        for (int i = 0; i < 3; i++) { epi.c0[i] = p.out_c[0][i]; epi.c1[i] = p.out_c[1][i]; }
+        for (int i = 0; i < 2; i++) { epi.l0[i] = p.out_l[0][i]; epi.l1[i] = p.out_l[1][i]; }
         run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
-                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave,
-                                            per_value(epi, EXACT ? 16 * (NOT - 1) : 0));
+                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;
@@ -515,22 +506,13 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
 
     const int O = nm.n_out;
     float *outbuf = reinterpret_cast<float *>(slab + slab_f4);   // slabs 1.. are free
-    const int f0 = p.out_func[0], f1 = p.out_func[1], be = p.out_be;
-    float c0[3], c1[3], l0[2], l1[2];
-    for (int i = 0; i < 3; i++) { c0[i] = p.out_c[0][i]; c1[i] = p.out_c[1][i]; }
-    for (int i = 0; i < 2; i++) { l0[i] = p.out_l[0][i]; l1[i] = p.out_l[1][i]; }
-    const bool transform = (f0 | f1 | be) != 0;
-    auto epi = [&](int, int i, int o, float q, bool valid) {
-        if (transform) {                     // posterior writer path: softening, byte order
-            q = soften(f0, c0, l0, q);
-            q = soften(f1, c1, l1, q);
-            if (be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
-        }
-        if (valid) outbuf[i * O + o] = q;
-    };
+    WriterPathEpilogue epi;
+    epi.outbuf = outbuf; epi.O = O; epi.f0 = p.out_func[0]; epi.f1 = p.out_func[1]; epi.be = p.out_be;
+    epi.ovalid = EXACT ? 16 * (NOT - 1) : 0;
+    for (int i = 0; i < 3; i++) { epi.c0[i] = p.out_c[0][i]; epi.c1[i] = p.out_c[1][i]; }
+    for (int i = 0; i < 2; i++) { epi.l0[i] = p.out_l[0][i]; epi.l1[i] = p.out_l[1][i]; }
     const float *s0 = reinterpret_cast<const float *>(slab);
-    softmax_rows<NOT, NW, FT, 1, 1, (EXACT ? 16 * (NOT - 1) : 0)>(p, &nm, s0, s0, s0, s0, s0, s0, lane, wave,
-                                                                   per_value(epi, EXACT ? 16 * (NOT - 1) : 0));
+    softmax_rows<NOT, NW, FT, 1, 1, (EXACT ? 16 * (NOT - 1) : 0)>(p, &nm, s0, s0, s0, s0, s0, s0, lane, wave, epi);
     __syncthreads();
     const int rows = min(BM, p.row_end - r0);
     const int total = rows * O;

@@ -18,6 +18,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // the same in the GLOBAL address space, for pointers rebuilt from scalar registers (scalar_ptr)
 typedef __attribute__((address_space(1))) const f4 gf4;
 
+template <int V>
+struct IntTag { static constexpr int value = V; };
+
 // In-kernel phase stamps exist only in the DIAGNOSTIC build (make stamps ->
 // libphnrec_lcrc_stamps.so, tools/stamp_profile.py); in the product the macro is empty.
 #ifdef LCRC_STAMPS
@@ -232,6 +235,33 @@ __device__ __forceinline__ float soften(int func, const float *c, const float *l
     return v;
 }
 
+// Row epilogue of a merger: posteriors -> [softening stage 1 -> stage 2 -> byte order] -> row i of `outbuf`
+// ([frames][O] floats in LDS, copied to HBM as whole rows afterwards).  One uniform branch per row decides between
+// the plain stores and the writer path (per value it was a scalar compare + branch for each of a lane's values).
+struct WriterPathEpilogue {
+    float *outbuf;
+    int O, f0, f1, be, ovalid;
+    float c0[3], c1[3], l0[2], l1[2];
+    template <int LPF, int NV>
+    __device__ __forceinline__ void operator()(int, int i, int part, IntTag<LPF>, const float (&q)[NV], int) const
+    {
+        float *row = outbuf + i * O + part;
+        if ((f0 | f1 | be) == 0) {
+#pragma unroll
+            for (int j = 0; j < NV; j++)
+                if (LPF * j + LPF <= ovalid || part + LPF * j < O) row[LPF * j] = q[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                float v = soften(f0, c0, l0, q[j]);
+                v = soften(f1, c1, l1, v);
+                if (be) v = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, v)));
+                if (LPF * j + LPF <= ovalid || part + LPF * j < O) row[LPF * j] = v;
+            }
+        }
+    }
+};
+
 // Scatter one value of a net-input row into the MFMA B image.
 __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, float v)
 {
@@ -425,9 +455,6 @@ __device__ __forceinline__ void store_partial(f4 *slab, int n_ot, int lane, cons
 // o = part + LPF * j (valid while o < O; pad outputs carry 0), so that an epilogue can batch its LDS reads and
 // transcendental work over the values instead of running one basic block per value.  per_value() adapts a simple
 // per-value function `f(group, frame, o, posterior, valid)`.
-template <int V>
-struct IntTag { static constexpr int value = V; };
-
 template <typename F>
 struct PerValueEpilogue {
     F f;
