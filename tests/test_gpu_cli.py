@@ -241,6 +241,53 @@ def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
         assert open(f, "rb").read() == blob, f
 
 
+def test_configs3_list_at_scale(tmp_path):
+    """BASELINE configs[3] at its stated size on the one GPU of this box: the shipped HU weights, 10 000 files of
+    3-15 s (slices of one synthetic 8 kHz signal, ~9 M frames), host Viterbi, one MLF -- once with `-g 1`, once as
+    `-g 2` (two logical GPUs on the physical one, PHNREC_DEVICE_MAP): the two MLFs are byte-identical, every file
+    has its entry in list order, and utterances decoded alone give the lines the list run wrote for them"""
+    rng = np.random.default_rng(1236)
+    n_base = 16 * 8000
+    t = np.arange(n_base) / 8000.0
+    base = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n_base)
+    base = np.clip(base, -32768, 32767).astype("<i2")
+    data = tmp_path / "d"
+    data.mkdir()
+    names, frames = [], 0
+    for i in range(10000):
+        n = int(rng.uniform(3.0, 15.0) * 8000)
+        o = int(rng.integers(0, n_base - n))
+        f = data / ("u%05d.raw" % i)
+        base[o:o + n].tofile(f)
+        names.append(str(f))
+        frames += (n - 200) // 80 + 1
+    lst = tmp_path / "list.scp"
+    lst.write_text("".join(n + "\n" for n in names))
+    mlf1, mlf2 = tmp_path / "g1.mlf", tmp_path / "g2.mlf"
+    p1 = run("-c", model_dir(HU), "-l", lst, "-m", mlf1, "-g", 1, env={"PHNREC_STATS": "1"})
+    p2 = run("-c", model_dir(HU), "-l", lst, "-m", mlf2, "-g", 2, env={"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0"})
+    assert "files=10000 frames=%d" % frames in p1.stderr and "files=10000 frames=%d" % frames in p2.stderr
+    a, b = mlf1.read_bytes(), mlf2.read_bytes()
+    assert a == b, "-g 2 must write the bytes -g 1 writes"
+    lines = a.decode().splitlines()
+    heads = [l for l in lines if l.startswith('"')]
+    assert lines[0] == "#!MLF!#" and len(heads) == 10000 and lines.count(".") == 10000
+    assert heads[0] == '"*/u00000.rec"' and heads[-1] == '"*/u09999.rec"'
+    assert heads == sorted(heads), "entries in list order"
+    for i in (0, 4711, 9999):                             # an utterance alone == its entry in the list run
+        rec = tmp_path / "one.rec"
+        run("-c", model_dir(HU), "-i", names[i], "-o", rec)
+        one = [l.split() for l in open(rec) if len(l.split()) == 4]
+        k = lines.index('"*/u%05d.rec"' % i)
+        entry = []
+        for l in lines[k + 1:]:
+            if l == ".":
+                break
+            entry.append(l.split())
+        assert [(int(x[0]), int(x[1]), x[2]) for x in entry] == [(int(x[0]), int(x[1]), x[2]) for x in one], i
+        assert max(abs(float(x[3]) - float(y[3])) for x, y in zip(entry, one)) < 1e-3
+
+
 def test_bench_line_carries_every_leg():
     """bench.py in the driver's form (shortened): ONE JSON line with the contract's keys, the roofline object with
     its disclosed pre-heat / cold figure / traffic source, the CPU baseline, and the side legs that put the
