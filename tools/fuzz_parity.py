@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity run (dev tool, GPU): 60 random LCRC model shapes (1-23 banks, hidden 1-399, 2-208 outputs,
-independent merger hidden size) on ragged batches, 16- and 32-frame workgroups, each against the oracle at the
+independent merger hidden size) on ragged batches, 16- and 32-frame workgroups and forced hidden splits, each against the oracle at the
 1e-4 bar.  usage: fuzz_parity.py [seed]"""
 import os, sys, tempfile, numpy as np
 sys.path.insert(0, os.getcwd())
@@ -26,11 +26,12 @@ for it in range(60):
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         mel = modelgen.synth_mel(int(off[-1]), nb, seed=it, mean_norm=bool(it & 1))
         want = o.posteriors_batch(mel, off)
-        for fr in (16, 32):
+        for fr, split in ((16, 1), (32, 1), (0, 2), (0, 5), (0, 64)):     # fused kernels, then forced hidden splits
             ctx.set_tile_frames(fr)
+            ctx.set_hidden_split(split)
             got = ctx.posteriors_batch(mel, off)
             err = float(np.abs(got - want).max())
             worst = max(worst, err)
-            assert err < 1e-4, (nb, hid, nout, hm, fr, err)
+            assert err < 1e-4, (nb, hid, nout, hm, fr, split, err)
         ctx.close()
 print("fuzz ok, worst max-abs", worst)
