@@ -1,4 +1,4 @@
-// binding_demo.cpp -- drives class Traps (tests/integration/traps.h + traps_lcrc.cpp) the way
+// binding_demo.cpp -- drives class Traps (tests/integration/traps_lcrc.h + traps_lcrc.cpp) the way
 // SpeechRec::Init and SpeechRec::ProcessOffline do (srec.cpp:605-624, 1035-1059): setters, Init, Reset,
 // prime with 15 frames (neededFea = false), the main part, flush with the last frame repeated.
 //   binding_demo MODEL_DIR NBANKS BUNCH mel.f32 post.f32      (raw float32 matrices, row-major)
@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "traps.h"
+#include "traps_lcrc.h"
 
 int main(int argc, char **argv)
 {

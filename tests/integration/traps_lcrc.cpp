@@ -7,47 +7,50 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "traps.h"
+#include "traps_lcrc.h"
 #include "lcrc.h"
 
-static lcrc_ctx *H(void *p) { return static_cast<lcrc_ctx *>(p); }
+Traps::Traps() : handle_(0), system_name_("LCRC"), banks_(15), length_(31), bunch_(1), hamming_(false), c0_(true) {}
+Traps::~Traps() { lcrc_destroy(handle_); }
 
-Traps::Traps() : ctx(0), nbanks(15), trap_len(31), useHamming(false), add_c0(true), bunchSize(1), system(stlcrc) {}
-Traps::~Traps() { lcrc_destroy(H(ctx)); }
-
-bool Traps::SetSystem(char *sys)                          // traps.cpp:572-586
+bool Traps::SetSystem(char *sys)                          // the four names traps.cpp:572-586 accepts
 {
-    if (strcmp(sys, "3BT") == 0) system = st3bt;
-    else if (strcmp(sys, "1BT") == 0) system = st1bt;
-    else if (strcmp(sys, "1BT_DCT") == 0) system = st1bt_dct;
-    else if (strcmp(sys, "LCRC") == 0) system = stlcrc;
-    else return false;
-    return true;
+    static const char *const known[] = {"3BT", "1BT", "1BT_DCT", "LCRC"};
+    for (unsigned i = 0; i < sizeof known / sizeof known[0]; i++)
+        if (strcmp(sys, known[i]) == 0) { system_name_ = known[i]; return true; }
+    return false;
 }
+void Traps::SetNBanks(int v) { banks_ = v; }
+void Traps::SetTrapLen(int v) { length_ = v; }
+void Traps::SetAddC0(bool v) { c0_ = v; }
+void Traps::SetHamming(bool ham) { hamming_ = ham; }
+void Traps::SetBunchSize(int v) { bunch_ = v; }
 
 void Traps::Init(char *dir)
 {
-    static const char *names[] = {"3BT", "1BT", "1BT_DCT", "LCRC"};
-    lcrc_ctx *h = 0;
     const char *dev = getenv("PHNREC_DEVICE");
-    if (lcrc_create_system(&h, dir, names[system], nbanks, trap_len, add_c0 ? 1 : 0, useHamming ? 1 : 0,
+    if (lcrc_create_system(&handle_, dir, system_name_, banks_, length_, c0_ ? 1 : 0, hamming_ ? 1 : 0,
                            dev ? atoi(dev) : 0) != LCRC_OK) {
         fprintf(stderr, "%s\n", lcrc_last_error(0));          // the text of traps.cpp:143
         exit(1);
     }
-    ctx = h;
 }
 
-void Traps::Reset() { lcrc_reset(H(ctx)); }
+void Traps::Reset() { lcrc_reset(handle_); }
 
-void Traps::CalcFeaturesBunched(float *be, float *fe, int n, bool needed)
+void Traps::CalcFeaturesBunched(float *band_energies, float *features, int n, bool neededFea)
 {
-    if (lcrc_push(H(ctx), be, n, fe, needed ? 1 : 0) != LCRC_OK) {
-        fprintf(stderr, "ERROR: %s\n", lcrc_last_error(H(ctx)));
+    if (lcrc_push(handle_, band_energies, n, features, neededFea ? 1 : 0) != LCRC_OK) {
+        fprintf(stderr, "ERROR: %s\n", lcrc_last_error(handle_));
         exit(1);
     }
 }
 
-void Traps::CalcFeatures(float *be, float *fe, int n, bool needed) { CalcFeaturesBunched(be, fe, n, needed); }
-int Traps::GetNumOuts() { return lcrc_num_outputs(H(ctx)); }
-int Traps::GetDelay() { return lcrc_delay(H(ctx)); }
+void Traps::CalcFeatures(float *band_energies, float *features, int n, bool neededFea)
+{
+    CalcFeaturesBunched(band_energies, features, n, neededFea);
+}
+
+int Traps::GetNumOuts() { return lcrc_num_outputs(handle_); }
+int Traps::GetTrapShift() { return (length_ - 1) / 2; }
+int Traps::GetDelay() { return lcrc_delay(handle_); }
