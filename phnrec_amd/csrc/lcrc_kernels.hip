@@ -168,25 +168,26 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         constexpr int MPT = (kTileRows * kMaxBanks + NT - 1) / NT;             // mel values per thread
         constexpr int WPT = (kMaxW1 + NT - 1) / NT, GPT = (kMaxWm + NT - 1) / NT;
         const int w1n = 16 * nkq1, wmn = 16 * nkqm, ntile = kTileRows * nb;
-        const long nmel = (long)p.n_rows * nb;
+        const int nmel = p.n_rows * nb;          // (rows * banks < 2^31: the API bounds a call's frames)
         float mv[MPT], tv, wv[WPT][4], gv[GPT][2];
 #pragma unroll
         for (int q = 0; q < MPT; q++) {
-            const long g = (long)tbase * nb + tid + q * NT;
-            mv[q] = p.mel[max(0L, min(nmel - 1, g))];
+            // 32-bit offsets from the scalar base: `global_load v, v_off, s[mel]` instead of 64-bit per-lane addresses
+            const int g = tbase * nb + tid + q * NT;
+            mv[q] = p.mel[(unsigned)max(0, min(nmel - 1, g))];
         }
         static_assert((KS1 + 3) / 4 <= 16 && (KSM + 3) / 4 <= 26, "staging bounds");
         const float *tsrc = tid < 160 ? p.costab + tid : p.win + (min(tid, 191) - 160);
         tv = *tsrc;
 #pragma unroll
         for (int q = 0; q < WPT; q++) {
-            const int i = min(tid + q * NT, w1n - 1);
+            const unsigned i = (unsigned)min(tid + q * NT, w1n - 1);     // unsigned: 32-bit offset from a scalar base
             wv[q][0] = p.net[0].mean[i]; wv[q][1] = p.net[0].dev[i];
             wv[q][2] = p.net[1].mean[i]; wv[q][3] = p.net[1].dev[i];
         }
 #pragma unroll
         for (int q = 0; q < GPT; q++) {
-            const int i = min(tid + q * NT, wmn - 1);
+            const unsigned i = (unsigned)min(tid + q * NT, wmn - 1);
             gv[q][0] = p.net[2].mean[i]; gv[q][1] = p.net[2].dev[i];
         }
         LCRC_FENCE();
