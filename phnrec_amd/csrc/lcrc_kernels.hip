@@ -101,6 +101,14 @@ __device__ __forceinline__ f4 split_sum(const f4 *src, size_t stride, int n_part
 // PROBES = true: the diagnostic instantiation behind lcrc_posteriors_probe (stage outputs to global memory);
 //                the production kernels carry no trace of it (as run-time branches the probe stores cost ~30 % of
 //                the band nets' epilogue: their 64-bit address arithmetic was executed for every value).
+// Variants whose hidden loops are short (EN: 500 hidden units = 8 / 16 tiles per wave) request the first weight fragments
+// of a loop early (RingLoop::begin): the exposed L2 round trip at a loop's start is 3 % of their 16-frame workgroups.
+// For the 1500-unit systems it is 0.6 %, less than what the longer register lifetimes cost (r01 A/B run 4).
+constexpr bool lcrc_early_requests(int ks1, int ksm, int n_ot, bool exact, bool split)
+{
+    return exact && !split && ks1 == 64 && ksm == 60 && n_ot == 8;
+}
+
 template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false>
 __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
@@ -134,6 +142,17 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int sp = SPLIT ? (int)blockIdx.x - tile * split : 0;
     const int r0 = p.row_first + tile * BM;
     const int tbase = r0 - kShift;
+
+    constexpr bool EARLY = lcrc_early_requests(KS1, KSM, NOT, EXACT, SPLIT);
+    // the waves' loops of the band pair (waves 0,1: net 0; 2,3: net 1) and of the merger, for the early requests
+    RingLoop<KS1, NOT, FT, EXACT> band_loop;
+    RingLoop<KSM, NOT, FT, EXACT> merger_loop;
+    if constexpr (EARLY) {
+        const int grp = wave / 2, wig = wave % 2;
+        const NetDev &nd = p.net[grp];
+        band_loop.setup(nd, reinterpret_cast<const f4 *>(xf) + (size_t)grp * (FT * nkq1 * 64), lane);
+        band_loop.begin(wig * ((nd.nht + 1) / 2));
+    }
 
     LCRC_STAMP(p, wave, lane, 0);
 #ifdef LCRC_STAMPS
@@ -426,8 +445,18 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         } else {
         // (the sequential alternative -- one band net after the other on four waves -- was 1.6-3 % slower in
         //  same-GPU A/B runs, profiles/r01_ab_runs.txt)
-        run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
-                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+        if constexpr (EARLY) {
+            auto begin_merger = [&]() {
+                merger_loop.setup(nm, reinterpret_cast<const f4 *>(gf), lane);
+                merger_loop.begin(wave * ((nm.nht + NW - 1) / NW));
+            };
+            run_net<KS1, NOT, NW, EXACT, FT, 2, true>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+                                                      reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi,
+                                                      &band_loop, begin_merger);
+        } else {
+            run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+                                                reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+        }
         LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
         }
     }
@@ -444,8 +473,12 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         epi.ovalid = EXACT ? 16 * (NOT - 1) : 0;
         for (int i = 0; i < 3; i++) { epi.c0[i] = p.out_c[0][i]; epi.c1[i] = p.out_c[1][i]; }
         for (int i = 0; i < 2; i++) { epi.l0[i] = p.out_l[0][i]; epi.l1[i] = p.out_l[1][i]; }
-        run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
-                                            reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+        if constexpr (EARLY)
+            run_net<KSM, NOT, NW, EXACT, FT, 1, true>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+                                                      reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi, &merger_loop);
+        else
+            run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+                                                reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;

@@ -393,22 +393,47 @@ struct RingLoop {
         LCRC_FENCE();
     }
 
-    __device__ __forceinline__ void run(f4 (&acc)[NOT][FT], int ht0, int ht1)
+    // begin(): the first bias quad and the ring fill for the prologue pass (entries NOT .. NOT+R-1 of pseudo tile
+    // ht0 - 1) are REQUESTED; finish() runs the passes.  run() = both.  Kernels with short hidden loops call begin()
+    // early -- the band nets' at kernel start, the merger's before the band softmax -- so that the first fragments'
+    // L2 round trip (~1.6 K cycles, exposed once per loop) travels behind other work.
+    f4 bias0;
+    __device__ __forceinline__ void begin(int ht0)
     {
         const int g = lane >> 4;
-        f4 bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(ht0, hlast) + 4 * g);
-        // ring fill for the prologue pass: entries NOT .. NOT+R-1 of pseudo tile ht0 - 1
+        bias0 = *reinterpret_cast<const f4 *>(b1 + 16 * min(ht0, hlast) + 4 * g);
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int e = NOT + k;
             request(e % R, e % FP, ht0 - 1 + e / FP);
         }
         LCRC_FENCE();
+    }
+    __device__ __forceinline__ void finish(f4 (&acc)[NOT][FT], int ht0, int ht1)
+    {
+        f4 bias = bias0;
         f4 pre[FT];
         pass<PRO>(acc, pre, bias, ht0 - 1);       // (a wave without tiles computes a dummy)
         for (int ht = ht0; ht < ht1 - 1; ht++) pass<MID>(acc, pre, bias, ht);
         if (ht0 < ht1) pass<LAST>(acc, pre, bias, ht1 - 1);
     }
+    __device__ __forceinline__ void run(f4 (&acc)[NOT][FT], int ht0, int ht1)
+    {
+        begin(ht0);
+        finish(acc, ht0, ht1);
+    }
+    // fields of a net's loop on this wave
+    __device__ __forceinline__ void setup(const NetDev &nd, const f4 *xf_image, int lane_)
+    {
+        w1 = reinterpret_cast<const f4 *>(nd.w1p); w2 = reinterpret_cast<const f4 *>(nd.w2p);
+        b1 = nd.b1; XF = xf_image; lane = lane_;
+        hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+        ks = nd.ksteps; nkq = nd.nkq; n_ot = nd.n_ot;
+    }
+};
+
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
 };
 
 // Layer-2 partial sums of ONE wave over the hidden tiles [ht0, ht1) of net `nd` (an empty range gives the
@@ -553,10 +578,15 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 // been called by every thread: each (group, frame, output < n_out) is covered once by SOME thread; pad
 // outputs o in [n_out, 16 * n_ot) may be used for loads from arrays padded to the output tiles but must not
 // be stored.  A __syncthreads() has been passed.
-template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, typename Params, typename Epi>
+// EARLY: `early` is this wave's loop, set up and begun by the caller (RingLoop::begin) -- its first fragments are already
+// travelling.  hook() runs right after the partial tiles are published, before the softmax (a place to begin() the
+// NEXT net's loop).
+template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, typename Params, typename Epi,
+          typename Hook = NoHook>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
-                                        f4 *__restrict__ slab23, int n_ot_slab, int lane, int wave, Epi epi)
+                                        f4 *__restrict__ slab23, int n_ot_slab, int lane, int wave, Epi epi,
+                                        RingLoop<KS, NOT, FT, EXACT> *early = nullptr, Hook hook = Hook())
 {
     constexpr int WPG = NW / GROUPS;             // waves per net
     const int grp = GROUPS == 1 ? 0 : wave / WPG, wig = GROUPS == 1 ? wave : wave % WPG;
@@ -589,7 +619,9 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     const float *const b1 = nd.b1;
     const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
 
-    {
+    if constexpr (EARLY) {
+        early->finish(acc, ht0, ht1);
+    } else {
         RingLoop<KS, NOT, FT, EXACT> loop;
         loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
         loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
@@ -612,6 +644,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
             }
         __syncthreads();
     }
+    hook();
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
     const float *s01 = reinterpret_cast<const float *>(slab01), *s23 = reinterpret_cast<const float *>(slab23);
     constexpr int OVALID = EXACT ? 16 * (NOT - 1) : 0;
