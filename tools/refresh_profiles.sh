@@ -32,7 +32,7 @@ python3 tools/system_sweep.py 2048 4096 8192 32768 > $OUT/system_sweep.txt 2>&1
 python3 tools/small_launch_sweep.py > $OUT/small_launch_sweep.txt 2>&1
 python3 tools/traps_bench.py > $OUT/traps_bench.txt 2>&1
 echo "sweeps done"
-for u in mfma_rate valu_overlap load_issue cross_wave; do ./tools/ubench/$u; done > $OUT/ubench.txt 2>&1
+for u in mfma_rate valu_overlap load_issue cross_wave mfma_shape; do ./tools/ubench/$u; done > $OUT/ubench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wave_stats -- python3 tools/frontend_bench.py > $OUT/frontend_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/traps_stats -- python3 tools/traps_bench.py > $OUT/traps_prof.txt 2>&1
 python3 tools/cli_throughput.py 2000 > $OUT/cli_throughput.txt 2>&1
