@@ -144,9 +144,12 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int tbase = r0 - kShift;
 
     constexpr bool EARLY = lcrc_early_requests(KS1, KSM, NOT, EXACT, SPLIT);
+    // ... and keep the input images in registers as far as they fit: all of them with 16-frame tiles (64 + 60 registers),
+    // the first 8 k-groups with 32-frame tiles (hipcc does it by itself for the 1500-unit systems' band nets)
+    constexpr int BKQ1 = EARLY ? (FT == 1 ? (KS1 + 3) / 4 : 8) : 0, BKQM = EARLY ? (FT == 1 ? (KSM + 3) / 4 : 8) : 0;
     // the waves' loops of the band pair (waves 0,1: net 0; 2,3: net 1) and of the merger, for the early requests
-    RingLoop<KS1, NOT, FT, EXACT> band_loop;
-    RingLoop<KSM, NOT, FT, EXACT> merger_loop;
+    RingLoop<KS1, NOT, FT, EXACT, BKQ1> band_loop;
+    RingLoop<KSM, NOT, FT, EXACT, BKQM> merger_loop;
     if constexpr (EARLY) {
         const int grp = wave / 2, wig = wave % 2;
         const NetDev &nd = p.net[grp];
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 merger_loop.setup(nm, reinterpret_cast<const f4 *>(gf), lane);
                 merger_loop.begin(wave * ((nm.nht + NW - 1) / NW));
             };
-            run_net<KS1, NOT, NW, EXACT, FT, 2, true>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+            run_net<KS1, NOT, NW, EXACT, FT, 2, true, BKQ1>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi,
                                                       &band_loop, begin_merger);
         } else {
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         for (int i = 0; i < 3; i++) { epi.c0[i] = p.out_c[0][i]; epi.c1[i] = p.out_c[1][i]; }
         for (int i = 0; i < 2; i++) { epi.l0[i] = p.out_l[0][i]; epi.l1[i] = p.out_l[1][i]; }
         if constexpr (EARLY)
-            run_net<KSM, NOT, NW, EXACT, FT, 1, true>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+            run_net<KSM, NOT, NW, EXACT, FT, 1, true, BKQM>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi, &merger_loop);
         else
             run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,

@@ -302,9 +302,13 @@ constexpr int lcrc_ring_size(int f, int n_ot = 0)
     return best;
 }
 
-template <int KS, int NOT, int FT, bool EXACT>
+// BKQ: the first BKQ k-groups of the B (input) image are held in REGISTERS for the whole loop instead of being read
+// from LDS in every hidden tile (a ds_read_b128 among MFMAs costs the wave ~8.5 cycles, tools/ubench/mfma_shape).
+// hipcc does this by itself for the 1500-unit systems' band nets; BKQ makes it explicit where it does not.
+template <int KS, int NOT, int FT, bool EXACT, int BKQ = 0>
 struct RingLoop {
     static constexpr int NKQ = (KS + 3) / 4;
+    static_assert(BKQ <= NKQ, "at most the whole image");
     static constexpr int F = NOT + NKQ;
     static constexpr int R = lcrc_ring_size(F, NOT);
     static constexpr int FP = (F + R - 1) / R * R;
@@ -316,6 +320,7 @@ struct RingLoop {
     int hlast, lane;
     int ks, nkq, n_ot;          // run-time sizes (generic shapes); KS / NKQ / NOT when EXACT
     f4 ring[R];
+    f4 bimg[BKQ > 0 ? BKQ : 1][FT];
 
     // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling.
     // Generic shapes: entries beyond the run-time sizes re-request the last valid fragment (a load
@@ -360,7 +365,7 @@ struct RingLoop {
             bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
         f4 xb[2][FT];
         const int nkq_x = EXACT ? NKQ : nkq;      // row stride of the B image
-        if (MODE != LAST) {
+        if (MODE != LAST && BKQ == 0) {
 #pragma unroll
             for (int f = 0; f < FT; f++) xb[0][f] = XF[f * nkq_x * 64 + lane];
         }
@@ -370,7 +375,7 @@ struct RingLoop {
                 if (EXACT || i < n_ot) gemm2_group<FT>(acc[i], ring[i % R], s);
             } else if (i - NOT < NKQ) {
                 const int kq = i - NOT;
-                if (kq + 1 < NKQ) {                // B fragments of the next group, ahead of the MFMAs
+                if (kq + 1 < NKQ && kq + 1 >= BKQ) {   // B fragments of the next group, ahead of the MFMAs
                     const int kn = EXACT ? kq + 1 : min(kq + 1, nkq - 1);
 #pragma unroll
                     for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * nkq_x + kn) * 64 + lane];
@@ -379,7 +384,8 @@ struct RingLoop {
                 for (int j = 0; j < 4; j++)
                     if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
 #pragma unroll
-                        for (int f = 0; f < FT; f++) nxt[f] = mfma16x16x4(ring[i % R][j], xb[kq & 1][f][j], nxt[f]);
+                        for (int f = 0; f < FT; f++)
+                            nxt[f] = mfma16x16x4(ring[i % R][j], kq < BKQ ? bimg[kq < BKQ ? kq : 0][f][j] : xb[kq & 1][f][j], nxt[f]);
                     }
             }
             const int e = (i + R) % FP, dt = (i + R) / FP;
@@ -411,6 +417,12 @@ struct RingLoop {
     }
     __device__ __forceinline__ void finish(f4 (&acc)[NOT][FT], int ht0, int ht1)
     {
+        if constexpr (BKQ > 0) {                  // the image is complete when finish() is called (begin() may run earlier)
+#pragma unroll
+            for (int kq = 0; kq < BKQ; kq++)
+#pragma unroll
+                for (int f = 0; f < FT; f++) bimg[kq][f] = XF[(f * (EXACT ? NKQ : nkq) + kq) * 64 + lane];
+        }
         f4 bias = bias0;
         f4 pre[FT];
         pass<PRO>(acc, pre, bias, ht0 - 1);       // (a wave without tiles computes a dummy)
@@ -581,12 +593,12 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 // EARLY: `early` is this wave's loop, set up and begun by the caller (RingLoop::begin) -- its first fragments are already
 // travelling.  hook() runs right after the partial tiles are published, before the softmax (a place to begin() the
 // NEXT net's loop).
-template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, typename Params, typename Epi,
-          typename Hook = NoHook>
+template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, int BKQ = 0, typename Params,
+          typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
                                         f4 *__restrict__ slab23, int n_ot_slab, int lane, int wave, Epi epi,
-                                        RingLoop<KS, NOT, FT, EXACT> *early = nullptr, Hook hook = Hook())
+                                        RingLoop<KS, NOT, FT, EXACT, BKQ> *early = nullptr, Hook hook = Hook())
 {
     constexpr int WPG = NW / GROUPS;             // waves per net
     const int grp = GROUPS == 1 ? 0 : wave / WPG, wig = GROUPS == 1 ? wave : wave % WPG;
