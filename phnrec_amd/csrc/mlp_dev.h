@@ -325,7 +325,8 @@ struct RingLoop {
     // request entry e of tile t into slot (e % R); e is a compile-time value after unrolling.
     // Generic shapes: entries beyond the run-time sizes re-request the last valid fragment (a load
     // under a branch would make the compiler drain all requests at the join); they are never consumed.
-    __device__ __forceinline__ void request(int slot, int e, int t)
+    __device__ __forceinline__ void request(int slot, int e, int t) { request(slot, e, t, nkq, n_ot); }
+    __device__ __forceinline__ void request(int slot, int e, int t, int nkq, int n_ot)
     {
         if (e < NOT) {
             const int ot = EXACT ? e : min(e, n_ot - 1);
@@ -348,6 +349,11 @@ struct RingLoop {
         constexpr bool kSkipSig = (LCRC_DBG & 2) != 0;
         constexpr bool kSkipLd = (LCRC_DBG & 4) != 0;
         const int g = lane >> 4;
+        // run-time shapes: the bounds are re-materialised per pass (an empty asm the optimiser cannot see through), so the
+        // ~80 comparisons against them are redone on the scalar unit in every pass instead of being hoisted out of the
+        // hidden loop into as many SGPR pairs, which spilled
+        int nkq = this->nkq, n_ot = this->n_ot;
+        if (!EXACT) asm volatile("" : "+s"(nkq), "+s"(n_ot));
         f4 s[FT], nxt[FT];
         if (MODE != PRO) {
             SigTile<FT> sg;
@@ -382,14 +388,17 @@ struct RingLoop {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (EXACT ? (4 * kq + j < KS) : (4 * kq + j < ks)) {
+                    // run-time shapes: whole k-groups (the weights of k-steps past the net's last one are packed as zeros
+                    // and the image's pads are zero) -- one loop-invariant condition per group, not per k-step: hipcc
+                    // hoists them all into SGPR pairs, and 104 of them spilled
+                    if (EXACT ? (4 * kq + j < KS) : (kq < nkq)) {
 #pragma unroll
                         for (int f = 0; f < FT; f++)
                             nxt[f] = mfma16x16x4(ring[i % R][j], kq < BKQ ? bimg[kq < BKQ ? kq : 0][f][j] : xb[kq & 1][f][j], nxt[f]);
                     }
             }
             const int e = (i + R) % FP, dt = (i + R) / FP;
-            if (!kSkipLd && (MODE != LAST || (dt == 0 && e < NOT))) request(i % R, e, t + dt);
+            if (!kSkipLd && (MODE != LAST || (dt == 0 && e < NOT))) request(i % R, e, t + dt, nkq, n_ot);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE != LAST) {

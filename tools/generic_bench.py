@@ -1,0 +1,32 @@
+import os, sys, tempfile
+sys.path.insert(0, os.getcwd())
+import ctypes as C
+import numpy as np, torch
+from phnrec_amd import capi, modelgen
+def bench(libpath, d, nb, n=8192):
+    capi._load_hip_runtime()
+    L = C.CDLL(libpath)
+    vp = C.c_void_p
+    L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lcrc_posteriors_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lcrc_num_outputs.argtypes = [vp]; L.lcrc_set_timing.argtypes = [vp, C.c_int]
+    L.lcrc_kernel_name.argtypes = [vp]; L.lcrc_kernel_name.restype = C.c_char_p
+    h = vp(); assert L.lcrc_create(C.byref(h), d.encode(), nb, 31, 1, 0) == 0
+    L.lcrc_set_timing(h, 0)
+    no = L.lcrc_num_outputs(h)
+    mel = torch.from_numpy(modelgen.synth_mel(n, nb, seed=1)).cuda(); post = torch.empty((n, no), device="cuda")
+    s = torch.cuda.current_stream()
+    for _ in range(30): L.lcrc_posteriors_device(h, mel.data_ptr(), None, 1, n, post.data_ptr(), s.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(100): L.lcrc_posteriors_device(h, mel.data_ptr(), None, 1, n, post.data_ptr(), s.cuda_stream)
+    e1.record(s); s.synchronize()
+    return e0.elapsed_time(e1) / 100, L.lcrc_kernel_name(h).decode(), post.cpu().numpy()
+for nb, hid, nout in ((16, 1500, 138), (15, 1000, 100), (23, 700, 150)):
+    with tempfile.TemporaryDirectory() as d:
+        modelgen.write_model_dir(d, nb, hid, nout, seed=5)
+        flop = 2 * (2 * (nb * 11 * hid + hid * nout) + (2 * nout * hid + hid * nout))
+        a, ka, pa = bench("phnrec_amd/lib/ab/libcur12.so", d, nb)
+        b, kb, pb = bench("phnrec_amd/lib/libphnrec_lcrc.so", d, nb)
+        print("banks %d hidden %d out %d [%s]: before %.4f ms (%.3f of peak)  after %.4f ms (%.3f)  identical %s"
+              % (nb, hid, nout, kb, a, 8192 * flop / a / 1e-3 / 157.3e12, b, 8192 * flop / b / 1e-3 / 157.3e12, bool(np.array_equal(pa, pb))))
