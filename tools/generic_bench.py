@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Kernel time of the run-time-shape (`generic`) LCRC variant on seeded synthetic models whose shapes match none of the
+shipped systems.  usage: generic_bench.py [LIB_A [LIB_B]]  (paths relative to the repo root; default: the product
+library; with two libraries their outputs are compared too -- see tools/build_ab_lib.sh).  Needs a GPU."""
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 import ctypes as C
@@ -26,7 +30,11 @@ for nb, hid, nout in ((16, 1500, 138), (15, 1000, 100), (23, 700, 150)):
     with tempfile.TemporaryDirectory() as d:
         modelgen.write_model_dir(d, nb, hid, nout, seed=5)
         flop = 2 * (2 * (nb * 11 * hid + hid * nout) + (2 * nout * hid + hid * nout))
-        a, ka, pa = bench("phnrec_amd/lib/ab/libcur12.so", d, nb)
-        b, kb, pb = bench("phnrec_amd/lib/libphnrec_lcrc.so", d, nb)
-        print("banks %d hidden %d out %d [%s]: before %.4f ms (%.3f of peak)  after %.4f ms (%.3f)  identical %s"
-              % (nb, hid, nout, kb, a, 8192 * flop / a / 1e-3 / 157.3e12, b, 8192 * flop / b / 1e-3 / 157.3e12, bool(np.array_equal(pa, pb))))
+        libs = sys.argv[1:3] or ["phnrec_amd/lib/libphnrec_lcrc.so"]
+        res = [bench(l, d, nb) for l in libs]
+        line = "banks %d hidden %d out %d [%s]:" % (nb, hid, nout, res[-1][1])
+        for l, (ms, _, _) in zip(libs, res):
+            line += "  %s %.4f ms (%.3f of peak)" % (os.path.basename(l), ms, 8192 * flop / ms / 1e-3 / 157.3e12)
+        if len(res) == 2:
+            line += "  identical output: %s" % bool(np.array_equal(res[0][2], res[1][2]))
+        print(line)
