@@ -148,7 +148,9 @@ int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
     d.nkq = (d.ksteps + 3) / 4;
     d.nht = (h.n_hid + 15) / 16;
     d.n_ot = (h.n_out + 15) / 16;
-    std::vector<float> w1p((size_t)d.nht * d.nkq * 256, 0.f), w2p((size_t)d.nht * d.n_ot * 256, 0.f);
+    // (+ one all-zero fragment behind each array: the run-time-shape kernels run the MFMA groups of their size class
+    //  unconditionally and point the entries past this net's k-groups / output tiles at it)
+    std::vector<float> w1p(((size_t)d.nht * d.nkq + 1) * 256, 0.f), w2p(((size_t)d.nht * d.n_ot + 1) * 256, 0.f);
     for (int ht = 0; ht < d.nht; ht++)
         for (int kq = 0; kq < d.nkq; kq++)
             for (int l = 0; l < 64; l++)

@@ -566,11 +566,15 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
 namespace {
 
 constexpr int kNW = 4;   // waves per workgroup: one per SIMD (two per SIMD do not pay)
-constexpr int kGenKS1 = 64, kGenKSM = 104, kGenNOT = 13;   // generic: <= 23 banks, <= 208 outputs
+// Run-time-shape ("generic") size classes: every MFMA group of the class runs (zero fragments past the net's own
+// sizes), so a class costs its maxima.  Small: <= 16 banks (176 inputs), <= 144 outputs; large: <= 23 banks, <= 208 outputs.
+constexpr int kGenSKS1 = 44, kGenSKSM = 72, kGenSNOT = 9;
+constexpr int kGenKS1 = 64, kGenKSM = 104, kGenNOT = 13;
 
 struct Variant {
     const char *name;
-    int ks1, ksm, n_ot;    // 0,0,0 = generic
+    int ks1, ksm, n_ot;    // exact: the shape; classes: the maxima
+    bool exact;
     const void *fn[2];     // [FT - 1]: 16- and 32-frame workgroups
     const void *split_band, *split_merger;   // split-hidden path, 16-frame tiles
     const void *probe;     // 16-frame workgroups with the stage probes (lcrc_posteriors_probe)
@@ -584,23 +588,25 @@ struct Variant {
     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, false, true>)
 
 const Variant kVariants[] = {
-    {"cz_42_69_9", 42, 69, 9, LCRC_KERNEL(42, 69, 9, true)},
-    {"hu_42_93_12", 42, 93, 12, LCRC_KERNEL(42, 93, 12, true)},
-    {"ru_42_80_10", 42, 80, 10, LCRC_KERNEL(42, 80, 10, true)},
-    {"en_64_60_8", 64, 60, 8, LCRC_KERNEL(64, 60, 8, true)},
-    {"generic", 0, 0, 0, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false)},
+    {"cz_42_69_9", 42, 69, 9, true, LCRC_KERNEL(42, 69, 9, true)},
+    {"hu_42_93_12", 42, 93, 12, true, LCRC_KERNEL(42, 93, 12, true)},
+    {"ru_42_80_10", 42, 80, 10, true, LCRC_KERNEL(42, 80, 10, true)},
+    {"en_64_60_8", 64, 60, 8, true, LCRC_KERNEL(64, 60, 8, true)},
+    {"generic_44_72_9", kGenSKS1, kGenSKSM, kGenSNOT, false, LCRC_KERNEL(kGenSKS1, kGenSKSM, kGenSNOT, false)},
+    {"generic_64_104_13", kGenKS1, kGenKSM, kGenNOT, false, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false)},
 };
 constexpr int kNVariants = sizeof kVariants / sizeof kVariants[0];
 
 const Variant *pick(const NetDev *nets)
 {
-    for (const Variant &v : kVariants)
-        if (v.ks1 == nets[0].ksteps && v.ks1 == nets[1].ksteps && v.ksm == nets[2].ksteps &&
-            v.n_ot == nets[0].n_ot && v.n_ot == nets[1].n_ot && v.n_ot == nets[2].n_ot)
+    if (nets[1].ksteps != nets[0].ksteps) return nullptr;
+    const int n_ot = lcrc_n_ot_slab(nets);
+    for (const Variant &v : kVariants) {           // exact shapes first, then the smallest class that holds the model
+        if (v.exact ? (v.ks1 == nets[0].ksteps && v.ksm == nets[2].ksteps && v.n_ot == nets[0].n_ot &&
+                       v.n_ot == nets[1].n_ot && v.n_ot == nets[2].n_ot)
+                    : (nets[0].ksteps <= v.ks1 && nets[2].ksteps <= v.ksm && n_ot <= v.n_ot))
             return &v;
-    if (nets[0].ksteps <= kGenKS1 && nets[1].ksteps == nets[0].ksteps && nets[2].ksteps <= kGenKSM &&
-        nets[0].n_ot <= kGenNOT && nets[1].n_ot <= kGenNOT && nets[2].n_ot <= kGenNOT)
-        return &kVariants[kNVariants - 1];
+    }
     return nullptr;
 }
 

@@ -315,6 +315,7 @@ struct RingLoop {
     enum { PRO = 0, MID = 1, LAST = 2 };
 
     const f4 *w1, *w2;
+    const f4 *z1, *z2;          // the all-zero fragment behind w1p / w2p (run-time shapes)
     const float *b1;
     const f4 *XF;
     int hlast, lane;
@@ -329,14 +330,22 @@ struct RingLoop {
     __device__ __forceinline__ void request(int slot, int e, int t, int nkq, int n_ot)
     {
         if (e < NOT) {
-            const int ot = EXACT ? e : min(e, n_ot - 1);
-            const f4 *tb = w2 + (size_t)max(0, min(t, hlast)) * (EXACT ? NOT : n_ot) * 64;
-            if (EXACT) ring[slot] = scalar_ptr(tb + (ot & ~3) * 64)[(ot & 3) * 64 + lane];
-            else ring[slot] = scalar_ptr(tb + ot * 64)[lane];
+            if (EXACT) {
+                const f4 *tb = w2 + (size_t)max(0, min(t, hlast)) * NOT * 64;
+                ring[slot] = scalar_ptr(tb + (e & ~3) * 64)[(e & 3) * 64 + lane];
+            } else {                                   // past this net's output tiles: the zero fragment
+                const f4 *fr = e < n_ot ? w2 + ((size_t)max(0, min(t, hlast)) * n_ot + e) * 64 : z2;
+                ring[slot] = scalar_ptr(fr)[lane];
+            }
         } else if (e - NOT < NKQ) {
-            const f4 *tb = w1 + (size_t)min(t + 1, hlast) * (EXACT ? NKQ : nkq) * 64;
-            if (EXACT) ring[slot] = load_w1_frag<KS, NKQ, true>(scalar_ptr(tb + ((e - NOT) & ~3) * 64), (e - NOT) & 3, e - NOT, lane);
-            else ring[slot] = scalar_ptr(tb + min(e - NOT, nkq - 1) * 64)[lane];
+            const int kq = e - NOT;
+            if (EXACT) {
+                const f4 *tb = w1 + (size_t)min(t + 1, hlast) * NKQ * 64;
+                ring[slot] = load_w1_frag<KS, NKQ, true>(scalar_ptr(tb + (kq & ~3) * 64), kq & 3, kq, lane);
+            } else {                                   // past this net's k-groups: the zero fragment
+                const f4 *fr = kq < nkq ? w1 + ((size_t)min(t + 1, hlast) * nkq + kq) * 64 : z1;
+                ring[slot] = scalar_ptr(fr)[lane];
+            }
         }
     }
 
@@ -378,7 +387,7 @@ struct RingLoop {
 #pragma unroll
         for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
             if (i < NOT) {
-                if (EXACT || i < n_ot) gemm2_group<FT>(acc[i], ring[i % R], s);
+                gemm2_group<FT>(acc[i], ring[i % R], s);      // (run-time shapes: zero weights past the net's output tiles)
             } else if (i - NOT < NKQ) {
                 const int kq = i - NOT;
                 if (kq + 1 < NKQ && kq + 1 >= BKQ) {   // B fragments of the next group, ahead of the MFMAs
@@ -388,10 +397,10 @@ struct RingLoop {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    // run-time shapes: whole k-groups (the weights of k-steps past the net's last one are packed as zeros
-                    // and the image's pads are zero) -- one loop-invariant condition per group, not per k-step: hipcc
-                    // hoists them all into SGPR pairs, and 104 of them spilled
-                    if (EXACT ? (4 * kq + j < KS) : (kq < nkq)) {
+                    // run-time shapes: every k-step of the size class runs (zero weights past the net's last k-step: packed
+                    // zeros inside its last group, the zero fragment for whole groups); a conditionally executed MFMA group
+                    // costs hipcc's allocation a shuffle of the accumulators, 2x the loop time
+                    if (EXACT ? (4 * kq + j < KS) : true) {
 #pragma unroll
                         for (int f = 0; f < FT; f++)
                             nxt[f] = mfma16x16x4(ring[i % R][j], kq < BKQ ? bimg[kq < BKQ ? kq : 0][f][j] : xb[kq & 1][f][j], nxt[f]);
@@ -450,6 +459,7 @@ struct RingLoop {
         b1 = nd.b1; XF = xf_image; lane = lane_;
         hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
         ks = nd.ksteps; nkq = nd.nkq; n_ot = nd.n_ot;
+        z1 = w1 + (size_t)nd.nht * nd.nkq * 64; z2 = w2 + (size_t)nd.nht * nd.n_ot * 64;
     }
 };
 
@@ -481,6 +491,7 @@ __device__ __forceinline__ void hidden_range(const NetDev &nd, const f4 *XF, int
     loop.b1 = nd.b1; loop.XF = XF; loop.lane = lane;
     loop.hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
     loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
+    loop.z1 = loop.w1 + (size_t)nd.nht * nd.nkq * 64; loop.z2 = loop.w2 + (size_t)nd.nht * nd.n_ot * 64;
     loop.run(acc, ht0, ht1);
 }
 
@@ -646,6 +657,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         RingLoop<KS, NOT, FT, EXACT> loop;
         loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
         loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
+        loop.z1 = w1 + (size_t)nd.nht * nd.nkq * 64; loop.z2 = w2 + (size_t)nd.nht * nd.n_ot * 64;
         loop.run(acc, ht0, ht1);
     }
 

@@ -268,9 +268,11 @@ const MlpVariant kMlp[] = {
     {"mlp_42_12", 42, 12, true, false, {nullptr, MLP_FN(42, 12, false, 2, true)}},
     {"mlp_42_10", 42, 10, true, false, {nullptr, MLP_FN(42, 10, false, 2, true)}},
     {"mlp_64_8", 64, 8, true, false, {nullptr, MLP_FN(64, 8, false, 2, true)}},
-    // size classes (k-steps, output tiles): the loops are unrolled over the class's maxima, so a small net in a
-    // large class would step over mostly empty entries
+    // size classes (k-steps, output tiles), first fit: every MFMA group of a class runs (zero fragments past the net's own
+    // sizes), so a net costs its class's maxima
     {"mlp_le8_4", 8, 4, false, false, {MLP_FN(8, 4, false, 1, false), MLP_FN(8, 4, false, 2, false)}},
+    {"mlp_le48_9", 48, 9, false, false, {MLP_FN(48, 9, false, 1, false), MLP_FN(48, 9, false, 2, false)}},
+    {"mlp_le96_9", 96, 9, false, false, {MLP_FN(96, 9, false, 1, false), MLP_FN(96, 9, false, 2, false)}},
     {"mlp_le64", 64, kMlpNOT, false, false, {MLP_FN(64, kMlpNOT, false, 1, false), MLP_FN(64, kMlpNOT, false, 2, false)}},
     {"mlp_le128", 128, kMlpNOT, false, false, {MLP_FN(128, kMlpNOT, false, 1, false), MLP_FN(128, kMlpNOT, false, 2, false)}},
     {"mlp_le256", kMlpKS, kMlpNOT, false, false, {MLP_FN(kMlpKS, kMlpNOT, false, 1, false), MLP_FN(kMlpKS, kMlpNOT, false, 2, false)}},

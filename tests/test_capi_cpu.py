@@ -64,7 +64,7 @@ def test_kernel_variants_for_all_shipped_shapes(tmp_path):
         assert info["kernel"] == kernel and info["lds_bytes"] <= 160 * 1024, (system, info)
     d = str(tmp_path / "odd")
     modelgen.write_model_dir(d, 20, 77, 50, seed=2)
-    assert capi.model_info(d, 20)["kernel"] == "generic"
+    assert capi.model_info(d, 20)["kernel"].startswith("generic_")
 
 
 def test_ascii_and_nbin_models_load_identically(tmp_path, oracle_mod):

@@ -92,7 +92,7 @@ def test_synthetic_goldens_all_shapes(capi, tmp_path):
             assert np.abs(one - want[a:b]).max() < TOL, (name, i)
             assert np.array_equal(one, got[a:b]), "batched and single launches must agree bit for bit"
         ctx.close()
-    assert {"generic", "cz_42_69_9", "hu_42_93_12", "ru_42_80_10", "en_64_60_8"} <= seen, seen
+    assert {"cz_42_69_9", "hu_42_93_12", "ru_42_80_10", "en_64_60_8"} <= seen and any(k.startswith("generic_") for k in seen), seen
 
 
 def test_vs_oracle_random_batches(capi, oracle_mod, tmp_path):
@@ -192,7 +192,7 @@ def test_split_hidden_path(capi, oracle_mod, tmp_path):
         cases.append((d, nb, "generic"))
     for d, nb, name in cases:
         ctx = capi.Lcrc(d, nb)
-        assert ctx.kernel_name == name
+        assert ctx.kernel_name.startswith(name)
         o = oracle_mod.Oracle(d, nb)
         mel = modelgen.synth_mel(2100, nb, seed=3)
         for n in (1, 5, 16, 17, 100, 700, 2048, 2100):
@@ -439,7 +439,7 @@ def test_generic_kernel_shape_sweep(capi, oracle_mod, tmp_path):
         modelgen.write_model_dir(d, nb, hid, nout, seed=100 + idx, hidden_merger=hid + 7 * (idx % 3))
         ctx = capi.Lcrc(d, nb)
         # (23 banks, 120 outputs) has the k-steps / output tiles of the EN variant: hidden size is a run-time value there
-        assert ctx.kernel_name == ("en_64_60_8" if (nb, nout) == (23, 120) else "generic")
+        assert ctx.kernel_name == "en_64_60_8" if (nb, nout) == (23, 120) else ctx.kernel_name.startswith("generic_")
         o = oracle_mod.Oracle(d, nb)
         lens = [int(v) for v in rng.integers(0, 45, size=5)] + [33]
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
@@ -527,7 +527,7 @@ def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
         modelgen.write_model_dir(d, nb, hid, nout, seed=21)
         ctx = capi.Lcrc(d, nb)
         ctx.set_hidden_split(1)
-        assert ctx.kernel_name == name
+        assert ctx.kernel_name.startswith(name)
         o = oracle_mod.Oracle(d, nb)
         lens = [1, 15, 16, 17, 31, 32, 33, 0, 47, 100]
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
