@@ -259,6 +259,16 @@ int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
  * every launch uses the fused kernel and a frame's posteriors are bit-identical however it is batched
  * (the CLI sets this); k > 1 = at most k workgroups per tile. */
 int lcrc_set_hidden_split(lcrc_ctx *ctx, int workgroups_per_tile);
+/* Arithmetic of the LCRC kernels.  LCRC_ARITH_F32 (default): v_mfma_f32_16x16x4_f32, the reference's f32 products
+ * one by one.  LCRC_ARITH_SPLIT_F16: every f32 operand as a (high, low) pair of f16 values and every product as three
+ * exact f16 x f16 MFMA products accumulated in f32 (what is dropped is below 2^-22 of a product -- the size of f32's
+ * own rounding of the sums; measured distance to the reference: the same few 1e-6 as LCRC_ARITH_F32).  The f16 MFMA
+ * runs 16x the f32 MFMA's rate, so the kernel is 2-3x faster; it exists for the shipped LCRC shapes and models whose
+ * weights lie within +-65504 (else LCRC_E_UNSUPPORTED and the setting is unchanged); normalised inputs beyond that
+ * range are clamped to it.  Every launch uses the fused kernel in this mode (as with lcrc_set_hidden_split(h, 1)). */
+#define LCRC_ARITH_F32 0
+#define LCRC_ARITH_SPLIT_F16 1
+int lcrc_set_arithmetic(lcrc_ctx *ctx, int arithmetic);
 /* Test hook: the nth (0 = next) staging-buffer allocation of this process from now on fails as if the
  * device / pinned memory were exhausted; -1 switches the injection off.  The failing call returns
  * LCRC_E_NOMEM, leaves no half-allocated buffer group behind, and the context stays usable. */

@@ -22,11 +22,13 @@ SYMBOLS = [
     "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6
+
+ARITH_F32, ARITH_SPLIT_F16 = 0, 1
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -143,6 +145,7 @@ def load():
     L.lcrc_set_tile_frames.argtypes = [vp, C.c_int]
     L.lcrc_set_hidden_split.argtypes = [vp, C.c_int]
     L.lcrc_set_mean_order.argtypes = [vp, C.c_int]
+    L.lcrc_set_arithmetic.argtypes = [vp, C.c_int]
     L.lcrc_debug_fail_alloc.argtypes = [C.c_int]
     L.lcrc_posteriors_rows.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
     _lib = L
@@ -362,6 +365,10 @@ class Lcrc:
     def set_hidden_split(self, workgroups_per_tile):
         """0 = automatic (default), 1 = never split (bit-identical however frames are batched), k = at most k"""
         self._check(self.L.lcrc_set_hidden_split(self.h, workgroups_per_tile))
+
+    def set_arithmetic(self, arithmetic):
+        """ARITH_F32 (default) or ARITH_SPLIT_F16 (f32 products as three exact f16 MFMA products; shipped LCRC shapes)"""
+        self._check(self.L.lcrc_set_arithmetic(self.h, arithmetic))
 
     def set_timing(self, on):
         self._check(self.L.lcrc_set_timing(self.h, int(on)))

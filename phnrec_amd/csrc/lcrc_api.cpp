@@ -91,6 +91,7 @@ struct lcrc_ctx {
     lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     int out_be = 0;
     int tile_frames = 0;
+    int arith = 0;              // LCRC_ARITH_*
     // decoder on the device ("next" row f3): configuration, label buffers (device + pinned host)
     int dec_P = 0, dec_S = 0, dec_prune = 0;
     float dec_wpen = 0.f;
@@ -135,6 +136,48 @@ hipError_t dev_upload(lcrc_ctx *c, const std::vector<T> &h, const T **out)
     return e;
 }
 
+// Split-f16 form of a net (mlp_dev.h HalfLoop): every weight as a (high, low) f16 pair, high = f16(w), low =
+// f16(w - high), in the A-fragment order of v_mfma_f32_16x16x32_f16 (lane l: row l&15, k-slots 8(l>>4) .. +7):
+//   w1h[(((P*ns + s)*2 + T)*2 + piece)*64 + l][j] = W1[32P + 16T + (l&15)][32s + 8(l>>4) + j]
+//   w2h[((P*n_ot + ot)*2 + piece)*64 + l][j]      = W2[16ot + (l&15)][32P + (j < 4 ? 4(l>>4) + j : 16 + 4(l>>4) + j - 4)]
+// (layer 2's k-slots follow the accumulator layout of the pair's two layer-1 tiles).  A model with a weight
+// beyond f16's range has no such form: w1h stays NULL and lcrc_set_arithmetic refuses.
+int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
+{
+    d.w1h = d.w2h = nullptr;
+    for (float w : h.w1) if (!(fabsf(w) <= 65504.0f)) return LCRC_OK;
+    for (float w : h.w2) if (!(fabsf(w) <= 65504.0f)) return LCRC_OK;
+    std::vector<_Float16> w1h((size_t)d.npairs * ns * 2 * 2 * 64 * 8, (_Float16)0.0f);
+    std::vector<_Float16> w2h((size_t)d.npairs * d.n_ot * 2 * 64 * 8, (_Float16)0.0f);
+    auto put = [](std::vector<_Float16> &a, size_t frag, int l, int j, float w) {
+        const _Float16 hi = (_Float16)w;
+        a[(frag * 64 + l) * 8 + j] = hi;
+        a[((frag + 1) * 64 + l) * 8 + j] = (_Float16)(w - (float)hi);
+    };
+    for (int P = 0; P < d.npairs; P++)
+        for (int s = 0; s < ns; s++)
+            for (int T = 0; T < 2; T++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int hh = 32 * P + 16 * T + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
+                        if (hh < h.n_hid && k < h.n_inp)
+                            put(w1h, (((size_t)P * ns + s) * 2 + T) * 2, l, j, h.w1[(size_t)hh * h.n_inp + k]);
+                    }
+    for (int P = 0; P < d.npairs; P++)
+        for (int ot = 0; ot < d.n_ot; ot++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int g = l >> 4, o = 16 * ot + (l & 15);
+                    const int hh = 32 * P + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
+                    if (o < h.n_out && hh < h.n_hid)
+                        put(w2h, ((size_t)P * d.n_ot + ot) * 2, l, j, h.w2[(size_t)o * h.n_hid + hh]);
+                }
+    const _Float16 *p = nullptr;
+    HIP_TRY(c, dev_upload(c, w1h, &p)); d.w1h = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, w2h, &p)); d.w2h = reinterpret_cast<const float4 *>(p);
+    return LCRC_OK;
+}
+
 // Fragment order of v_mfma_f32_16x16x4_f32's A operand (lane l: row l&15, k-slot l>>4).
 //   w1p[(ht*nkq + kq)*64 + l][j] = W1[16ht + (l&15)][16kq + 4j + (l>>4)]
 //   w2p[(ht*n_ot + ot)*64 + l][r] = W2[16ot + (l&15)][16ht + 4(l>>4) + r]
@@ -167,8 +210,11 @@ int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
                     if (o < h.n_out && hh < h.n_hid)
                         w2p[(((size_t)ht * d.n_ot + ot) * 64 + l) * 4 + r] = h.w2[(size_t)o * h.n_hid + hh];
                 }
-    std::vector<float> b1((size_t)d.nht * 16, 0.f), b2((size_t)d.n_ot * 16, 0.f);
-    std::vector<float> mean((size_t)d.nkq * 16, 0.f), dev((size_t)d.nkq * 16, 1.f);
+    // (b1 padded to whole tile pairs, mean / dev to whole 32-deep k-steps: what the split-f16 kernels stage)
+    const int ns = (h.n_inp + 31) / 32;
+    d.npairs = (d.nht + 1) / 2;
+    std::vector<float> b1((size_t)d.npairs * 32, 0.f), b2((size_t)d.n_ot * 16, 0.f);
+    std::vector<float> mean((size_t)std::max(d.nkq * 16, ns * 32), 0.f), dev(mean.size(), 1.f);
     memcpy(b1.data(), h.b1.data(), sizeof(float) * h.n_hid);
     memcpy(b2.data(), h.b2.data(), sizeof(float) * h.n_out);
     memcpy(mean.data(), h.mean.data(), sizeof(float) * h.n_inp);
@@ -180,7 +226,7 @@ int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
     HIP_TRY(c, dev_upload(c, b2, &d.b2));
     HIP_TRY(c, dev_upload(c, mean, &d.mean));
     HIP_TRY(c, dev_upload(c, dev, &d.dev));
-    return LCRC_OK;
+    return pack_net_h2(c, h, d, ns);
 }
 
 // Test hook (lcrc_debug_fail_alloc): the n-th buffer allocation from now on fails with out-of-memory.
@@ -346,6 +392,7 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     p.n_utts = n_utts; p.n_rows = n_rows; p.nbanks = c->nbanks;
     fill_output_transform(c, p.out_func, p.out_c, p.out_l, &p.out_be);
     p.tile_frames = c->tile_frames;
+    p.arith = c->arith;
     p.stamps = c->d_stamps;
     p.row_first = row_first; p.row_end = row_first + row_count;
     p.part = c->d_part; p.gimg = c->d_gimg; p.cnt = c->d_cnt;
@@ -1296,6 +1343,20 @@ int lcrc_set_hidden_split(lcrc_ctx *c, int workgroups_per_tile)
     if (!c) return LCRC_E_ARG;
     if (workgroups_per_tile < 0 || workgroups_per_tile > 64) return fail(c, LCRC_E_ARG, "lcrc_set_hidden_split: 0 (automatic), 1 (never) .. 64");
     c->split_hint = workgroups_per_tile;
+    return LCRC_OK;
+}
+
+int lcrc_set_arithmetic(lcrc_ctx *c, int arithmetic)
+{
+    if (!c) return LCRC_E_ARG;
+    if (arithmetic != LCRC_ARITH_F32 && arithmetic != LCRC_ARITH_SPLIT_F16)
+        return fail(c, LCRC_E_ARG, "lcrc_set_arithmetic: LCRC_ARITH_F32 or LCRC_ARITH_SPLIT_F16");
+    if (arithmetic == LCRC_ARITH_SPLIT_F16) {
+        if (c->system != SYS_LCRC || !lcrc_has_split_f16(c->nets))
+            return fail(c, LCRC_E_UNSUPPORTED, "lcrc_set_arithmetic: split-f16 kernels exist for the shipped LCRC shapes, "
+                        "weights within +-65504");
+    }
+    c->arith = arithmetic;
     return LCRC_OK;
 }
 

@@ -29,6 +29,10 @@ struct NetDev {
     int nkq;             // ceil(ksteps / 4)  float4 groups of k-steps
     int nht;             // ceil(n_hid / 16)  hidden tiles
     int n_ot;            // ceil(n_out / 16)  output tiles
+    // split-f16 arithmetic (mlp_dev.h HalfLoop; NULL when the model has no such form): fragment pairs (high, low)
+    const float4 *w1h;   // [npairs][ns][2 tiles][2 pieces][64]  A fragments of layer 1 (8 f16 k-values per lane)
+    const float4 *w2h;   // [npairs][not][2 pieces][64]          A fragments of layer 2 (8 hidden units of the pair)
+    int npairs;          // ceil(nht / 2); b1 is padded to 32 * npairs, mean / dev to 32 * ns
 };
 
 struct LcrcParams {
@@ -55,6 +59,7 @@ struct LcrcParams {
     unsigned *cnt;       // [tile][2] arrival tickets (band phase, merger phase); zero between launches
     int split_cap_wgs;   // capacity of `part` in workgroups (`gimg`, `cnt`: as many tiles)
     int tile_frames;     // 0 = choose by launch size, 16 or 32 = forced (lcrc_set_tile_frames)
+    int arith;           // 0 = f32 MFMA, 1 = split-f16 arithmetic (lcrc_set_arithmetic; fused kernel only)
     // posterior writer path (lcrc_output_configure): softening stages and byte order of `post`
     int out_func[2];     // LCRC_SOFT_* per stage (0 = none)
     float out_c[2][4];   // igor: {middle, 1/middle, 1/(1-middle), -} ; out_l: {ln left base, ln right base}
@@ -174,6 +179,8 @@ void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t 
 constexpr int kSplitCapWgs = 512;    // workgroups of a split launch (tiles x split) never exceed this
 // variant that WOULD be selected for these nets (no launch); NULL if unsupported
 const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes);
+// whether the model has split-f16 kernels (a shipped shape, weights within f16's range)
+bool lcrc_has_split_f16(const NetDev *nets);
 
 }  // namespace phnrec
 #endif

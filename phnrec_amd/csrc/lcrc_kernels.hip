@@ -109,9 +109,13 @@ constexpr bool lcrc_early_requests(int ks1, int ksm, int n_ot, bool exact, bool 
     return exact && !split && ks1 == 64 && ksm == 60 && n_ot == 8;
 }
 
-template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false>
+// ARITH = 1: split-f16 arithmetic (mlp_dev.h HalfLoop) -- the operand images hold (high, low) f16 pairs in 32-deep k-steps;
+//            an image's size is counted in 1-KiB units per frame tile like the f32 images' k-groups: nkq = 2 * k-steps.
+template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false, int ARITH = 0>
 __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
+    static_assert(ARITH == 0 || (EXACT && !SPLIT && !PROBES), "split-f16 arithmetic: the fused kernel of the shipped shapes");
+    constexpr int NS1 = (4 * KS1 + 31) / 32, NSM = (4 * KSM + 31) / 32;     // 32-deep k-steps (ARITH = 1)
     constexpr int BM = 16 * FT;                 // frames per workgroup
     constexpr int kTileRows = BM + 2 * kShift;  // mel rows staged
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = p.nbanks;
-    const int nkq1 = EXACT ? (KS1 + 3) / 4 : p.net[0].nkq;
-    const int nkqm = EXACT ? (KSM + 3) / 4 : p.net[2].nkq;
+    const int nkq1 = ARITH ? 2 * NS1 : EXACT ? (KS1 + 3) / 4 : p.net[0].nkq;
+    const int nkqm = ARITH ? 2 * NSM : EXACT ? (KSM + 3) / 4 : p.net[2].nkq;
     const int n_ot = EXACT ? NOT : p.n_ot_slab;
     const LdsPlan lp = lcrc_lds_plan(FT, nb, nkq1, nkqm, n_ot);
 
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int r0 = p.row_first + tile * BM;
     const int tbase = r0 - kShift;
 
-    constexpr bool EARLY = lcrc_early_requests(KS1, KSM, NOT, EXACT, SPLIT);
+    constexpr bool EARLY = ARITH == 0 && lcrc_early_requests(KS1, KSM, NOT, EXACT, SPLIT);
     // ... and keep the input images in registers as far as they fit: all of them with 16-frame tiles (64 + 60 registers),
     // the first 8 k-groups with 32-frame tiles (hipcc does it by itself for the 1500-unit systems' band nets)
     constexpr int BKQ1 = EARLY ? (FT == 1 ? (KS1 + 3) / 4 : 8) : 0, BKQM = EARLY ? (FT == 1 ? (KSM + 3) / 4 : 8) : 0;
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                             const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
                             float v = val - mk;                              // Normalize nn.cpp:702-716
                             v *= dk;
-                            img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
+                            if constexpr (ARITH == 1) h2_img_store(img, h2_img_ofs(NS1, 16 * f + 4 * g + reg, k), v);
+                            else img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                         }
                     }
                     if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
@@ -400,7 +405,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 v *= dk[j];
                 const int t = t0 + (LPF / 4) * j;
                 // exact variants: outputs below 16 * (NOT - 1) are valid whatever n_out is -- no compare, no branch
-                if ((EXACT && LPF * j + LPF <= 16 * (NOT - 1)) || part + LPF * j < O) img[(t >> 2) * 256 + (t & 3)] = v;
+                if ((EXACT && LPF * j + LPF <= 16 * (NOT - 1)) || part + LPF * j < O) {
+                    if constexpr (ARITH == 1) h2_img_store(gf, h2_img_ofs(NSM, i, kb + LPF * j), v);
+                    else img[(t >> 2) * 256 + (t & 3)] = v;
+                }
             }
         };
         if constexpr (SPLIT) {
@@ -457,8 +465,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi,
                                                       &band_loop, begin_merger);
         } else {
-            run_net<KS1, NOT, NW, EXACT, FT, 2>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
-                                                reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+            run_net<KS1, NOT, NW, EXACT, FT, 2, false, 0, ARITH>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+                                                                 reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         }
         LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
         }
@@ -480,8 +488,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             run_net<KSM, NOT, NW, EXACT, FT, 1, true, BKQM>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi, &merger_loop);
         else
-            run_net<KSM, NOT, NW, EXACT, FT, 1>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
-                                                reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
+            run_net<KSM, NOT, NW, EXACT, FT, 1, false, 0, ARITH>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+                                                                 reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
         const int total = rows * O;
@@ -578,6 +586,7 @@ struct Variant {
     const void *fn[2];     // [FT - 1]: 16- and 32-frame workgroups
     const void *split_band, *split_merger;   // split-hidden path, 16-frame tiles
     const void *probe;     // 16-frame workgroups with the stage probes (lcrc_posteriors_probe)
+    const void *h2[2];     // split-f16 arithmetic, [FT - 1] (shipped shapes only)
 };
 
 #define LCRC_KERNEL(KS1, KSM, NOT, EX) \
@@ -587,13 +596,17 @@ struct Variant {
     reinterpret_cast<const void *>(&lcrc_split_merger_kernel<KSM, NOT, kNW, EX, 1>), \
     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, EX, 1, false, true>)
 
+#define LCRC_KERNEL_H2(KS1, KSM, NOT) \
+    {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 1, false, false, 1>), \
+     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 2, false, false, 1>)}
+
 const Variant kVariants[] = {
-    {"cz_42_69_9", 42, 69, 9, true, LCRC_KERNEL(42, 69, 9, true)},
-    {"hu_42_93_12", 42, 93, 12, true, LCRC_KERNEL(42, 93, 12, true)},
-    {"ru_42_80_10", 42, 80, 10, true, LCRC_KERNEL(42, 80, 10, true)},
-    {"en_64_60_8", 64, 60, 8, true, LCRC_KERNEL(64, 60, 8, true)},
-    {"generic_44_72_9", kGenSKS1, kGenSKSM, kGenSNOT, false, LCRC_KERNEL(kGenSKS1, kGenSKSM, kGenSNOT, false)},
-    {"generic_64_104_13", kGenKS1, kGenKSM, kGenNOT, false, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false)},
+    {"cz_42_69_9", 42, 69, 9, true, LCRC_KERNEL(42, 69, 9, true), LCRC_KERNEL_H2(42, 69, 9)},
+    {"hu_42_93_12", 42, 93, 12, true, LCRC_KERNEL(42, 93, 12, true), LCRC_KERNEL_H2(42, 93, 12)},
+    {"ru_42_80_10", 42, 80, 10, true, LCRC_KERNEL(42, 80, 10, true), LCRC_KERNEL_H2(42, 80, 10)},
+    {"en_64_60_8", 64, 60, 8, true, LCRC_KERNEL(64, 60, 8, true), LCRC_KERNEL_H2(64, 60, 8)},
+    {"generic_44_72_9", kGenSKS1, kGenSKSM, kGenSNOT, false, LCRC_KERNEL(kGenSKS1, kGenSKSM, kGenSNOT, false), {nullptr, nullptr}},
+    {"generic_64_104_13", kGenKS1, kGenKSM, kGenNOT, false, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false), {nullptr, nullptr}},
 };
 constexpr int kNVariants = sizeof kVariants / sizeof kVariants[0];
 
@@ -624,6 +637,12 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
     return v->name;
 }
 
+bool lcrc_has_split_f16(const NetDev *nets)
+{
+    const Variant *v = pick(nets);
+    return v && v->h2[0] && nets[0].w1h && nets[1].w1h && nets[2].w1h;
+}
+
 void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes)
 {
     const size_t slab = (size_t)lcrc_n_ot_slab(nets) * 1024u;          // one 16-frame partial tile
@@ -638,7 +657,7 @@ namespace {
 // (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
 hipError_t grant_lds(const void *fn, int vi, int slot, int dev)
 {
-    static std::atomic<bool> granted[kNVariants][5][64] = {};
+    static std::atomic<bool> granted[kNVariants][7][64] = {};
     const bool cached = dev >= 0 && dev < 64;
     if (cached && granted[vi][slot][dev]) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -702,6 +721,22 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     args.n_ot_slab = lcrc_n_ot_slab(p.net);
     void *kargs[] = {&args};
     const dim3 block(kNW * 64);
+
+    // ---- split-f16 arithmetic (lcrc_set_arithmetic): the fused kernel at every launch size ----
+    if (p.arith == 1) {
+        const bool probes = p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g || p.stamps;
+        if (!v->h2[0] || !p.net[0].w1h || !p.net[1].w1h || !p.net[2].w1h || probes) return hipErrorInvalidValue;
+        const int nk1 = 2 * ((4 * v->ks1 + 31) / 32), nkm = 2 * ((4 * v->ksm + 31) / 32);
+        int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
+        if (lcrc_lds_plan(2, p.nbanks, nk1, nkm, args.n_ot_slab).total > 160u * 1024u) ft = 1;
+        const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, nk1, nkm, args.n_ot_slab);
+        if (lp.total > 160u * 1024u) return hipErrorInvalidValue;
+        e = grant_lds(v->h2[ft - 1], vi, 4 + ft, dev);
+        if (e != hipSuccess) return e;
+        if (variant_name) *variant_name = v->name;
+        const int bm = 16 * ft;
+        return hipLaunchKernel(v->h2[ft - 1], dim3((rows + bm - 1) / bm), block, kargs, lp.total, stream);
+    }
 
     // ---- split-hidden path: two launches (band phase, merger phase) on 16-frame tiles ----
     const int tiles16 = (rows + 15) / 16;

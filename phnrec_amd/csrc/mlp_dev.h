@@ -36,9 +36,17 @@ struct IntTag { static constexpr int value = V; };
 #define LCRC_STAMP(p, wave, lane, idx) do { } while (0)
 #endif
 
+#ifndef LCRC_DBG
+#define LCRC_DBG 0
+#endif
 __device__ __forceinline__ f4 mfma16x16x4(float a, float b, f4 c)
 {
+#if (LCRC_DBG & 8)      // ablation: one 4-cycle FMA in place of the 32-cycle MFMA (what the weight stream alone allows)
+    c[0] = __builtin_fmaf(a, b, c[0]);
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // ---- FEXP (fexp.h:14-21) ----------------------------------------------------------
@@ -270,7 +278,7 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
 }
 
 // compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
-// weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads
+// weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads, 8 = no MFMAs
 #ifndef LCRC_DBG
 #define LCRC_DBG 0
 #endif
@@ -463,6 +471,198 @@ struct RingLoop {
     }
 };
 
+// ---- split-f16 arithmetic (lcrc_set_arithmetic(h, LCRC_ARITH_SPLIT_F16)) -------------------------------------------
+// An f32 product a*b is evaluated as three f16 MFMA products with f32 accumulation:
+//     a = ah + al,  b = bh + bl   (ah = f16(a), al = f16(a - ah): 22 significant bits),   a*b ~ al*bh + ah*bl + ah*bh
+// Every f16 x f16 product is exact in f32, so what is lost is the operands' 2^-22 tails and al*bl (2^-22 relative): the
+// size of f32's own rounding of the running sum.  (tools/ubench/split_f16.hip: a two-layer product lands as close to
+// f64 as v_mfma_f32_16x16x4_f32 does; f16 subnormals are not flushed by the MFMA.)  v_mfma_f32_16x16x32_f16 retires
+// 16x the FLOPs per cycle of the f32 MFMA, so a product costs 3/16 of it -- and, unlike the f32 MFMA, it leaves the VALU
+// free for half of its cycles.  Weights are split on the host (pack_net_h2), inputs when they are written into the
+// operand image, hidden activations in registers.  Operands beyond +-65504 do not exist in f16: the host refuses models
+// with such weights, inputs are clamped there (a normalised feature of that size saturates every sigmoid anyway).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float kHalfMax = 65504.0f;
+
+__device__ __forceinline__ f4 mfma_h(const f4 &a, const f4 &b, f4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+// Operand image of a net's input: [frame tile f][k-step s][piece][lane] 16-byte fragments; element j of lane l's
+// fragment is X[frame 16f + (l&15)][k = 32s + 8(l>>4) + j], piece 0 = high part, 1 = low part.
+// Byte offset of the high part of (frame i, input k) in an image of `ns` k-steps; the low part lies 1024 bytes on.
+__device__ __forceinline__ int h2_img_ofs(int ns, int i, int k)
+{
+    return ((((i >> 4) * ns + (k >> 5)) * 2) * 64 + 16 * ((k >> 3) & 3) + (i & 15)) * 16 + 2 * (k & 7);
+}
+__device__ __forceinline__ void h2_img_store(void *img, int ofs, float v)
+{
+    v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs) = hi;
+    *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs + 1024) = lo;
+}
+
+constexpr int h2_ring_size(int f, int ft)
+{
+    // entries hold a fragment pair (high, low: 8 registers) and feed 3 * FT MFMAs of 16 cycles: the ring has to be deeper
+    // the fewer frames a workgroup has
+    const int lo = ft >= 2 ? 8 : 14, hi = ft >= 2 ? 12 : 20;
+    int best = lo, pad = 1 << 30;
+    for (int r = hi; r >= lo; r--) {
+        const int p = (f + r - 1) / r * r - f;
+        if (p < pad) { pad = p; best = r; }
+    }
+    return best;
+}
+
+// Hidden loop on tile PAIRS (32 hidden units): the layer-1 results of two 16-row tiles are, lane for lane, the B
+// operand of one 32-deep layer-2 step -- k-slot 8g + j of lane (g, c) is hidden unit 32P + (j < 4 ? 4g + j : 16 + 4g + j - 4),
+// which is how pack_net_h2 orders W2's columns.  Same ring discipline as RingLoop; per pair P the entries are
+//     e <  NOT            W2(P)[e]            3*FT MFMAs (low x high, high x low, high x high)
+//     e <  NOT + 2*NS     W1(P+1)[s][T]       s = (e-NOT)/2 k-step, T = (e-NOT)%2 tile of the pair
+template <int KS, int NOT, int FT>
+struct HalfLoop {
+    static constexpr int NS = (4 * KS + 31) / 32;
+    static constexpr int F = NOT + 2 * NS;
+    static constexpr int R = h2_ring_size(F, FT);
+    static constexpr int FP = (F + R - 1) / R * R;
+    enum { PRO = 0, MID = 1, LAST = 2 };
+
+    const f4 *w1, *w2;
+    const float *b1;
+    const f4 *XF;
+    int plast, lane;
+    f4 ring[R][2];
+
+    __device__ __forceinline__ void request(int slot, int e, int P)
+    {
+        if (e < NOT) {
+            gf4 *sp = scalar_ptr(w2 + ((size_t)max(0, min(P, plast)) * NOT + (e & ~1)) * 128);
+            ring[slot][0] = sp[(e & 1) * 128 + lane];
+            ring[slot][1] = sp[(e & 1) * 128 + 64 + lane];
+        } else if (e - NOT < 2 * NS) {
+            const int q = e - NOT;
+            gf4 *sp = scalar_ptr(w1 + ((size_t)min(P + 1, plast) * (2 * NS) + (q & ~1)) * 128);
+            ring[slot][0] = sp[(q & 1) * 128 + lane];
+            ring[slot][1] = sp[(q & 1) * 128 + 64 + lane];
+        }
+    }
+
+    template <int MODE>
+    __device__ __forceinline__ void pass(f4 (&acc)[NOT][FT], f4 (&pre)[2 * FT], f4 (&bias)[2], int P)
+    {
+        const int g = lane >> 4;
+        f4 sh[FT], sl[FT], nxt[2 * FT];
+        if (MODE != PRO) {
+            SigTile<2 * FT> sg;
+            sg.begin(pre);
+#pragma unroll
+            for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k);
+            f4 s[2 * FT];
+            sg.finish(s);
+#pragma unroll
+            for (int f = 0; f < FT; f++) {
+                h8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = s[(j >> 2) * FT + f][j & 3];
+                    const _Float16 a = (_Float16)v;
+                    hi[j] = a;
+                    lo[j] = (_Float16)(v - (float)a);
+                }
+                sh[f] = __builtin_bit_cast(f4, hi);
+                sl[f] = __builtin_bit_cast(f4, lo);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int f = 0; f < FT; f++) nxt[t * FT + f] = bias[t];
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE != LAST) {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                bias[t] = *reinterpret_cast<const f4 *>(b1 + 32 * min(P + 2, plast) + 16 * t + 4 * g);
+        }
+        f4 xb[2][FT][2];
+        if (MODE != LAST) {
+#pragma unroll
+            for (int f = 0; f < FT; f++)
+#pragma unroll
+                for (int pc = 0; pc < 2; pc++) xb[0][f][pc] = XF[((f * NS + 0) * 2 + pc) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
+            if (i < NOT) {
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    acc[i][f] = mfma_h(ring[i % R][1], sh[f], acc[i][f]);
+                    acc[i][f] = mfma_h(ring[i % R][0], sl[f], acc[i][f]);
+                    acc[i][f] = mfma_h(ring[i % R][0], sh[f], acc[i][f]);
+                }
+            } else if (i - NOT < 2 * NS) {
+                const int q = i - NOT, s = q >> 1, t = q & 1;
+                if (t == 0 && s + 1 < NS) {
+#pragma unroll
+                    for (int f = 0; f < FT; f++)
+#pragma unroll
+                        for (int pc = 0; pc < 2; pc++) xb[(s + 1) & 1][f][pc] = XF[((f * NS + s + 1) * 2 + pc) * 64 + lane];
+                }
+#pragma unroll
+                for (int f = 0; f < FT; f++) {
+                    nxt[t * FT + f] = mfma_h(ring[i % R][1], xb[s & 1][f][0], nxt[t * FT + f]);
+                    nxt[t * FT + f] = mfma_h(ring[i % R][0], xb[s & 1][f][1], nxt[t * FT + f]);
+                    nxt[t * FT + f] = mfma_h(ring[i % R][0], xb[s & 1][f][0], nxt[t * FT + f]);
+                }
+            }
+            const int e = (i + R) % FP, dp = (i + R) / FP;
+            if (MODE != LAST || (dp == 0 && e < NOT)) request(i % R, e, P + dp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE != LAST) {
+#pragma unroll
+            for (int q = 0; q < 2 * FT; q++) pre[q] = nxt[q];
+        }
+        LCRC_FENCE();
+    }
+
+    f4 bias0[2];
+    __device__ __forceinline__ void begin(int p0)
+    {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 2; t++) bias0[t] = *reinterpret_cast<const f4 *>(b1 + 32 * min(p0, plast) + 16 * t + 4 * g);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int e = NOT + k;
+            request(e % R, e % FP, p0 - 1 + e / FP);
+        }
+        LCRC_FENCE();
+    }
+    __device__ __forceinline__ void finish(f4 (&acc)[NOT][FT], int p0, int p1)
+    {
+        f4 bias[2] = {bias0[0], bias0[1]};
+        f4 pre[2 * FT];
+        pass<PRO>(acc, pre, bias, p0 - 1);
+        for (int pp = p0; pp < p1 - 1; pp++) pass<MID>(acc, pre, bias, pp);
+        if (p0 < p1) pass<LAST>(acc, pre, bias, p1 - 1);
+    }
+    __device__ __forceinline__ void run(f4 (&acc)[NOT][FT], int p0, int p1)
+    {
+        begin(p0);
+        finish(acc, p0, p1);
+    }
+    __device__ __forceinline__ void setup(const NetDev &nd, const f4 *xf_image, int lane_)
+    {
+        w1 = reinterpret_cast<const f4 *>(nd.w1h); w2 = reinterpret_cast<const f4 *>(nd.w2h);
+        b1 = nd.b1; XF = xf_image; lane = lane_;
+        plast = nd.npairs - 1;
+    }
+};
+
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -613,8 +813,8 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 // EARLY: `early` is this wave's loop, set up and begun by the caller (RingLoop::begin) -- its first fragments are already
 // travelling.  hook() runs right after the partial tiles are published, before the softmax (a place to begin() the
 // NEXT net's loop).
-template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, int BKQ = 0, typename Params,
-          typename Epi, typename Hook = NoHook>
+template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, int BKQ = 0, int ARITH = 0,
+          typename Params, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
                                         f4 *__restrict__ slab23, int n_ot_slab, int lane, int wave, Epi epi,
@@ -642,16 +842,22 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         for (int f = 0; f < FT; f++) acc[ot][f] = b;
     }
 
-    const int tpw = (nd.nht + WPG - 1) / WPG;
+    static_assert(ARITH == 0 || (EXACT && !EARLY), "split-f16 arithmetic: compile-time shapes");
+    const int units = ARITH ? nd.npairs : nd.nht;        // what the waves share: hidden tiles, or tile pairs
+    const int tpw = (units + WPG - 1) / WPG;
     const int ht0 = wig * tpw;
-    const int ht1 = min(nd.nht, ht0 + tpw);
+    const int ht1 = min(units, ht0 + tpw);
     // pointers into locals: kernarg fields would be re-read behind every memory fence
     const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
     const f4 *const w2 = reinterpret_cast<const f4 *>(nd.w2p);
     const float *const b1 = nd.b1;
     const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
 
-    if constexpr (EARLY) {
+    if constexpr (ARITH == 1) {
+        HalfLoop<KS, NOT, FT> loop;
+        loop.setup(nd, XF, lane);
+        loop.run(acc, ht0, ht1);
+    } else if constexpr (EARLY) {
         early->finish(acc, ht0, ht1);
     } else {
         RingLoop<KS, NOT, FT, EXACT> loop;
