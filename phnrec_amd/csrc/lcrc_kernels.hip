@@ -331,7 +331,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                             const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
                             float v = val - mk;                              // Normalize nn.cpp:702-716
                             v *= dk;
-                            if constexpr (ARITH == 1) h2_img_store(img, h2_img_ofs(NS1, 16 * f + 4 * g + reg, k), v);
+                            if constexpr (ARITH == 1)
+                                h2_img_store(img, f * (2 * NS1 * 1024) + (4 * g + reg) * 16 + h2_k_ofs(k), NS1 * 1024, v);
                             else img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                         }
                     }
@@ -399,6 +400,9 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             // lane's own constant and only (k >> 2) moves with j
             float *const img = gf + ((i >> 4) * nkqm * 64 + (i & 15) + 16 * (kb & 3)) * 4;
             const int t0 = kb >> 2;
+            // split-f16 image: value j lies (LPF / 8) * 256 bytes behind value j - 1 (LPF = 4: behind value j - 2)
+            const int hf = (i >> 4) * (2 * NSM * 1024) + (i & 15) * 16;
+            const int h0 = hf + h2_k_ofs(kb), h1 = hf + h2_k_ofs(kb + 4);
 #pragma unroll
             for (int j = 0; j < NV; j++) {
                 float v = gl[j] - mk[j];                             // Normalize nn.cpp:702-716
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 const int t = t0 + (LPF / 4) * j;
                 // exact variants: outputs below 16 * (NOT - 1) are valid whatever n_out is -- no compare, no branch
                 if ((EXACT && LPF * j + LPF <= 16 * (NOT - 1)) || part + LPF * j < O) {
-                    if constexpr (ARITH == 1) h2_img_store(gf, h2_img_ofs(NSM, i, kb + LPF * j), v);
+                    if constexpr (ARITH == 1)
+                        h2_img_store(gf, LPF >= 8 ? h0 + j * (LPF / 8) * 256 : ((j & 1) ? h1 : h0) + (j >> 1) * 256, NSM * 1024, v);
                     else img[(t >> 2) * 256 + (t & 3)] = v;
                 }
             }
@@ -724,7 +729,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
 
     // ---- split-f16 arithmetic (lcrc_set_arithmetic): the fused kernel at every launch size ----
     if (p.arith == 1) {
-        const bool probes = p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g || p.stamps;
+        const bool probes = p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g;
         if (!v->h2[0] || !p.net[0].w1h || !p.net[1].w1h || !p.net[2].w1h || probes) return hipErrorInvalidValue;
         const int nk1 = 2 * ((4 * v->ks1 + 31) / 32), nkm = 2 * ((4 * v->ksm + 31) / 32);
         int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);

@@ -489,33 +489,29 @@ __device__ __forceinline__ f4 mfma_h(const f4 &a, const f4 &b, f4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
-// Operand image of a net's input: [frame tile f][k-step s][piece][lane] 16-byte fragments; element j of lane l's
-// fragment is X[frame 16f + (l&15)][k = 32s + 8(l>>4) + j], piece 0 = high part, 1 = low part.
-// Byte offset of the high part of (frame i, input k) in an image of `ns` k-steps; the low part lies 1024 bytes on.
-__device__ __forceinline__ int h2_img_ofs(int ns, int i, int k)
-{
-    return ((((i >> 4) * ns + (k >> 5)) * 2) * 64 + 16 * ((k >> 3) & 3) + (i & 15)) * 16 + 2 * (k & 7);
-}
-__device__ __forceinline__ void h2_img_store(void *img, int ofs, float v)
+// Operand image of a net's input: [frame tile f][piece][k-step s][lane] 16-byte fragments; element j of lane l's
+// fragment is X[frame 16f + (l&15)][k = 32s + 8(l>>4) + j], piece 0 = high part, 1 = low part.  The byte offset of
+// (frame i, input k) is linear in k >> 3:  (i>>4) * 2*ns*1024 + (i&15) * 16  +  h2_k_ofs(k);  the low part lies
+// ns * 1024 bytes further on.
+__device__ __forceinline__ int h2_k_ofs(int k) { return ((k >> 3) << 8) + ((k & 7) << 1); }
+__device__ __forceinline__ void h2_img_store(void *img, int ofs, int lo_ofs, float v)
 {
     v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs) = hi;
-    *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs + 1024) = lo;
+    *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs + lo_ofs) = lo;
 }
 
-constexpr int h2_ring_size(int f, int ft)
+// Ring depth: the split-f16 loops are bound by the L2's bandwidth, not by its latency -- 8, 11/12 and 16 entries run alike
+// (A/B run 17), so the shallowest ring (fewest registers) it is.
+constexpr int h2_ring_size()
 {
-    // entries hold a fragment pair (high, low: 8 registers) and feed 3 * FT MFMAs of 16 cycles: the ring has to be deeper
-    // the fewer frames a workgroup has
-    const int lo = ft >= 2 ? 8 : 14, hi = ft >= 2 ? 12 : 20;
-    int best = lo, pad = 1 << 30;
-    for (int r = hi; r >= lo; r--) {
-        const int p = (f + r - 1) / r * r - f;
-        if (p < pad) { pad = p; best = r; }
-    }
-    return best;
+#ifdef LCRC_H2_RING      // A/B switch (tools/build_ab_lib.sh)
+    return LCRC_H2_RING;
+#else
+    return 8;
+#endif
 }
 
 // Hidden loop on tile PAIRS (32 hidden units): the layer-1 results of two 16-row tiles are, lane for lane, the B
@@ -527,7 +523,7 @@ template <int KS, int NOT, int FT>
 struct HalfLoop {
     static constexpr int NS = (4 * KS + 31) / 32;
     static constexpr int F = NOT + 2 * NS;
-    static constexpr int R = h2_ring_size(F, FT);
+    static constexpr int R = h2_ring_size();
     static constexpr int FP = (F + R - 1) / R * R;
     enum { PRO = 0, MID = 1, LAST = 2 };
 
@@ -592,7 +588,7 @@ struct HalfLoop {
 #pragma unroll
             for (int f = 0; f < FT; f++)
 #pragma unroll
-                for (int pc = 0; pc < 2; pc++) xb[0][f][pc] = XF[((f * NS + 0) * 2 + pc) * 64 + lane];
+                for (int pc = 0; pc < 2; pc++) xb[0][f][pc] = XF[((f * 2 + pc) * NS + 0) * 64 + lane];
         }
 #pragma unroll
         for (int i = (MODE == PRO ? NOT : 0); i < (MODE == LAST ? NOT : FP); i++) {
@@ -609,7 +605,7 @@ struct HalfLoop {
 #pragma unroll
                     for (int f = 0; f < FT; f++)
 #pragma unroll
-                        for (int pc = 0; pc < 2; pc++) xb[(s + 1) & 1][f][pc] = XF[((f * NS + s + 1) * 2 + pc) * 64 + lane];
+                        for (int pc = 0; pc < 2; pc++) xb[(s + 1) & 1][f][pc] = XF[((f * 2 + pc) * NS + s + 1) * 64 + lane];
                 }
 #pragma unroll
                 for (int f = 0; f < FT; f++) {

@@ -660,3 +660,118 @@ def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
         with pytest.raises(capi.LcrcError):
             ctx.configure_decoder(nout, 3, 40, 0.0)
         ctx.close()
+
+
+# ---- split-f16 arithmetic (lcrc_set_arithmetic): f32 products as three exact f16 MFMA products ----------------------
+
+@pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
+def test_split_f16_real_system_vs_reference_golden(capi, oracle_mod, system):
+    """bundled test.raw in the split-f16 arithmetic: same bar against the reference CLI's own -t post dump, and as
+    close to it as the f32 kernels are (the split drops less than f32's own rounding of the sums)"""
+    spec = modelgen.SYSTEMS[system]
+    mel = _norm_mel(oracle_mod, system)
+    lop = read_htk(os.path.join(GOLD, system, "test.lop"))
+    g = capi.Lcrc(model_dir(system), spec["nbanks"])
+    f32 = g.posteriors(mel)
+    g.set_arithmetic(capi.ARITH_SPLIT_F16)
+    post = g.posteriors(mel)
+    assert np.abs(post - lop).max() < TOL
+    assert np.abs(post - lop).max() < 2 * np.abs(f32 - lop).max() + 2e-6
+    assert np.abs(post - f32).max() < 2e-5
+    assert np.abs(post.sum(axis=1) - 1).max() < 1e-5
+    assert (post.argmax(axis=1) != lop.argmax(axis=1)).mean() < 0.005
+    g.set_arithmetic(capi.ARITH_F32)
+    assert np.array_equal(g.posteriors(mel), f32)
+
+
+@pytest.mark.parametrize("shape", [(15, 100, 138), (15, 1500, 137), (15, 1390, 159), (15, 48, 186), (23, 500, 120), (23, 17, 119)])
+def test_split_f16_vs_oracle_shapes_and_sizes(capi, oracle_mod, tmp_path, shape):
+    """seeded models of the shipped shape classes (odd and even numbers of hidden tiles, fewer outputs than the class
+    holds), utterances from 1 frame to several 32-frame tiles, as one utterance and as a batch"""
+    nb, hid, no = shape
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, nb, hid, no, seed=hid)
+    o = oracle_mod.Oracle(d, nb)
+    g = capi.Lcrc(d, nb)
+    assert not g.kernel_name.startswith("generic")
+    g.set_arithmetic(capi.ARITH_SPLIT_F16)
+    lens = [1, 2, 15, 16, 17, 31, 33, 64, 131]
+    mel = modelgen.synth_mel(sum(lens), nb, seed=3)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want = o.posteriors_batch(mel, off)
+    got = g.posteriors_batch(mel, off)
+    assert np.abs(got - want).max() < 2e-5
+    for u in (0, 3, 8):                                  # an utterance alone = the same bits as inside the batch
+        a, b = off[u], off[u + 1]
+        assert np.array_equal(g.posteriors(mel[a:b]), got[a:b])
+    for frames in (16, 32):
+        g.set_tile_frames(frames)
+        assert np.array_equal(g.posteriors_batch(mel, off), got)
+
+
+def test_split_f16_streaming_rows_and_large_launch(capi, oracle_mod):
+    """push, row ranges and a BASELINE-size launch in the split-f16 arithmetic: every form runs the fused kernel, so
+    a frame's bits do not depend on how it is batched"""
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    g = capi.Lcrc(model_dir(system), 15)
+    g.set_arithmetic(capi.ARITH_SPLIT_F16)
+    mel = modelgen.synth_mel(8192, 15, seed=5)
+    whole = g.posteriors(mel)
+    assert np.abs(whole.sum(axis=1) - 1).max() < 1e-5
+    o = oracle_mod.Oracle(model_dir(system), 15)
+    want = o.posteriors(mel[:600], threads=8)
+    assert np.abs(whole[:585] - want[:585]).max() < 2e-5          # (rows whose right context lies inside the cut)
+    assert np.array_equal(g.posteriors_rows(mel, 4000, 100), whole[4000:4100])
+    # the ProcessOffline sequence (srec.cpp:1035-1059) through the streaming entry points, in bunches of 5
+    n = 300
+    short = g.posteriors(mel[:n])
+    g.reset()
+    assert g.push(mel[:15], needed=False) is None
+    out = [g.push(mel[i:i + 5]) for i in range(15, n, 5)]
+    out.append(g.push(np.repeat(mel[n - 1:n], 15, axis=0)))
+    assert np.array_equal(np.concatenate(out), short)
+
+
+def test_split_f16_refused_where_it_does_not_exist(capi, tmp_path):
+    """run-time-shape models and weights beyond f16's range have no split-f16 form: LCRC_E_UNSUPPORTED, the context
+    stays on the f32 kernels; normalised inputs beyond f16's range are clamped"""
+    d = str(tmp_path / "gen")
+    modelgen.write_model_dir(d, 13, 64, 40, seed=2)
+    g = capi.Lcrc(d, 13)
+    assert g.kernel_name.startswith("generic")
+    mel = modelgen.synth_mel(50, 13, seed=1)
+    before = g.posteriors(mel)
+    with pytest.raises(capi.LcrcError) as e:
+        g.set_arithmetic(capi.ARITH_SPLIT_F16)
+    assert e.value.code == capi.LCRC_E_UNSUPPORTED
+    assert np.array_equal(g.posteriors(mel), before)
+    with pytest.raises(capi.LcrcError):
+        g.set_arithmetic(7)
+    # a shipped shape with one weight of 1e5
+    d2 = str(tmp_path / "big")
+    modelgen.write_model_dir(d2, 15, 64, 138, seed=3)
+    from oracle import binding as ob
+    net = ob.Net(nbin=os.path.join(d2, "weights", "band0.nbin"))
+    w = np.ctypeslib.as_array(net.n.W1, shape=(net.n.nHid16, net.n.nInp16))
+    w[3, 5] = 1.0e5
+    net.save_nbin(os.path.join(d2, "weights", "band0.nbin"))
+    g2 = capi.Lcrc(d2, 15)
+    with pytest.raises(capi.LcrcError) as e:
+        g2.set_arithmetic(capi.ARITH_SPLIT_F16)
+    assert e.value.code == capi.LCRC_E_UNSUPPORTED
+    # large inputs inside f16's range: FEXP's tails as in the f32 kernels; beyond it (no audio gets there) the normalised
+    # input is clamped at +-65504 -- finite, normalised posteriors, a documented deviation
+    d3 = str(tmp_path / "ok")
+    modelgen.write_model_dir(d3, 15, 64, 138, seed=3)
+    o3 = ob.Oracle(d3, 15)
+    g3 = capi.Lcrc(d3, 15)
+    g3.set_arithmetic(capi.ARITH_SPLIT_F16)
+    mel = modelgen.synth_mel(64, 15, seed=9) * np.float32(25.0)
+    mel[10] = 300.0
+    mel[11] = -300.0
+    assert np.abs(g3.posteriors(mel) - o3.posteriors(mel)).max() < TOL
+    mel[7] = 3.0e6
+    mel[9] = -3.0e6
+    got = g3.posteriors(mel)
+    assert np.isfinite(got).all() and np.abs(got.sum(axis=1) - 1).max() < 1e-5
+    assert np.abs(got[40:] - o3.posteriors(mel)[40:]).max() < TOL          # rows whose context holds no such frame

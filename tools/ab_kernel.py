@@ -3,6 +3,7 @@
 a few percent, so numbers from separate runs cannot be compared at that level).
 
 usage: ab_kernel.py LIB_A LIB_B [frames]      (paths relative to the repo root; needs a GPU)
+LCRC_ARITH=1 in the environment: both sides on the split-f16 kernels.
 Each library is loaded under its own handle; per system the two are timed alternately (order swapped every
 round), 9 rounds of 100 launches, first round dropped, medians reported.
 """
@@ -31,6 +32,9 @@ class Ctx:
         lib.lcrc_set_timing.argtypes = [vp, C.c_int]
         assert lib.lcrc_create(C.byref(self.h), mdir.encode(), nbanks, 31, 1, 0) == 0
         lib.lcrc_set_timing(self.h, 0)
+        if os.environ.get("LCRC_ARITH", "0") != "0":          # split-f16 arithmetic on both sides
+            lib.lcrc_set_arithmetic.argtypes = [vp, C.c_int]
+            assert lib.lcrc_set_arithmetic(self.h, int(os.environ["LCRC_ARITH"])) == 0
         self.n_out = lib.lcrc_num_outputs(self.h)
 
     def run(self, mel, post, n, stream):

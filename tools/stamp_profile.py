@@ -43,6 +43,11 @@ def main():
     post = torch.empty((n, ctx.n_out), device="cuda")
     bm = int(os.environ.get("LCRC_BM", "32"))                 # frames per workgroup (forced below)
     ctx.set_tile_frames(bm)
+    arith = int(os.environ.get("LCRC_ARITH", "0"))            # 1 = split-f16 arithmetic
+    if arith:
+        ctx.L.lcrc_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+        ctx.set_arithmetic(arith)
+        print("split-f16 arithmetic")
     grid = (n + bm - 1) // bm
     stamps = torch.zeros((grid, 8, 16), dtype=torch.int64, device="cuda")
     s = torch.cuda.current_stream()
