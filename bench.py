@@ -98,8 +98,9 @@ def reference_scaling(mdir, nbanks, seconds):
     return res
 
 
-def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
-    """The reference CPU path on this host, bounded to ~budget_s seconds per variant."""
+def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s, gpu_post_split=None):
+    """The reference CPU path on this host, bounded to ~budget_s seconds per variant.  gpu_post_split: the same batch
+    from the split-f16 kernels, compared with the same reference rows."""
     os.environ.setdefault("MKL_NUM_THREADS", "1")
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import binding as ob
@@ -112,7 +113,7 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
             t = ob.RefTraps(mdir, nbanks, bunch=5, blas=blas)
         except OSError:
             continue
-        done, work, t0, worst = 0, 0, time.perf_counter(), 0.0
+        done, work, t0, worst, worst_split = 0, 0, time.perf_counter(), 0.0, 0.0
         while time.perf_counter() - t0 < budget_s:
             # chunk with a 15-frame halo on each side == rows of the whole utterance;
             # wraps around the batch until the time budget is used
@@ -120,6 +121,8 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
             a, b = max(0, pos - 15), min(mel.shape[0], pos + chunk + 15)
             post = t.process_offline(mel[a:b])[pos - a:pos - a + chunk]
             worst = max(worst, float(np.abs(post - gpu_post[pos:pos + chunk]).max()))
+            if gpu_post_split is not None:
+                worst_split = max(worst_split, float(np.abs(post - gpu_post_split[pos:pos + chunk]).max()))
             done += chunk
             work += b - a          # halo frames are real work for the CPU too
         dt = time.perf_counter() - t0
@@ -128,6 +131,8 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
                            else "naive loop (no BLAS), bunch_size=5"),
                "sample": "%d frames of the bench batch (512-frame chunks + 15-frame halos), %.1f s" % (work, dt),
                "parity_max_abs_vs_gpu": worst}
+        if gpu_post_split is not None:
+            out["parity_max_abs_vs_gpu_split_f16"] = worst_split
         if blas:
             out.update(reference_scaling(mdir, nbanks, min(budget_s, 4.0)))
         break
@@ -146,6 +151,8 @@ def cpu_baseline(mdir, nbanks, mel, gpu_post, budget_s):
     port = {"value": round(n1 / dt1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "first %d frames, %.1f s" % (n1, dt1),
             "parity_max_abs_vs_gpu": float(np.abs(p1 - gpu_post[:n1]).max()),
+            **({"parity_max_abs_vs_gpu_split_f16": float(np.abs(p1 - gpu_post_split[:n1]).max())}
+               if gpu_post_split is not None else {}),
             "all_cores": {"value": round(nall / dta, 1), "cores": cores, "cores_visible": os.cpu_count(),
                           "sample": "%d frames, %.1f s" % (nall, dta)}}
     host = {"cpu_model": cpu_model(), "cores_visible": os.cpu_count(), "cores_usable": cores}
@@ -167,6 +174,38 @@ def time_launches(ctx, stream, d_mel, d_post, n, reps):
     e1.record(stream)
     stream.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+PEAK_F16_MFMA_TFLOPS = 2516.6      # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF)
+
+
+def split_f16_leg(capi, ctx, stream, d_mel, d_post, n, flops_frame, f32_post, f32_ms):
+    """The same workload on the split-f16 kernels (lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16), opt-in): every f32
+    product as three exact f16 x f16 MFMA products accumulated in f32.  `value` of the line stays the f32-MFMA
+    kernel named by north_star; this leg says what the other arithmetic buys on the same inputs and how far its
+    posteriors are from the f32 kernels' (both are compared with the reference in cpu_baseline)."""
+    import torch
+    ctx.set_arithmetic(capi.ARITH_SPLIT_F16)
+    try:
+        time_launches(ctx, stream, d_mel, d_post, n, 150)          # its own pre-heat (another clock point)
+        ms = time_launches(ctx, stream, d_mel, d_post, n, 200)
+        post = d_post.clone()
+    finally:
+        ctx.set_arithmetic(capi.ARITH_F32)
+    alg = n * flops_frame / (ms * 1e-3) / 1e12
+    leg = {"value": round(n / ms * 1e3, 1), "unit": "frames/s", "kernel_ms": round(ms, 4),
+           "speedup_vs_f32_kernel": round(f32_ms / ms, 3),
+           "algorithmic_tflops": round(alg, 1),
+           "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 3),
+           # three f16 products per f32 product: the MFMA work actually executed against the dense f16 peak
+           "frac_of_f16_mfma_peak_3_products": round(3 * alg / PEAK_F16_MFMA_TFLOPS, 3),
+           "bound": "the CU's vector-memory path (64 B/clk): 32 frames per workgroup stream 6.5 MB of weight fragments "
+                    "through every CU per launch (DESIGN.md)",
+           "max_abs_vs_f32_kernels": float((post - f32_post).abs().max().item()),
+           "rows_sum_to_one": bool((post.sum(dim=1) - 1).abs().max().item() < 1e-5),
+           "what": "lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16): f32 operands as (high, low) f16 pairs, products as "
+                   "v_mfma_f32_16x16x32_f16 x 3, f32 accumulation; same launches, inputs and outputs as `value`"}
+    return leg, post
 
 
 def small_launch_legs(capi, modelgen, dev, stream):
@@ -562,9 +601,17 @@ def main():
                     for k in ("push_bunch5", "push_bunch512"):
                         if k in line["small_launches"]:
                             line[k] = line["small_launches"].pop(k)
+            split_post = None
+            gpu_post = d_post.cpu().numpy() if ranks.world == 1 else None
+            if ranks.world == 1 and not args.no_extras:
+                try:
+                    line["split_f16"], sp = split_f16_leg(capi, ctx, stream, d_mel, d_post, args.batch, flops_frame,
+                                                          torch.from_numpy(gpu_post).to(dev), kernel_ms)
+                    split_post = sp.cpu().numpy()
+                except Exception as e:
+                    line["split_f16"] = {"error": repr(e)}
             if ranks.world == 1 and not args.no_cpu:
-                gpu_post = d_post.cpu().numpy()
-                line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds)
+                line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds, split_post)
         ctx.close()
     ranks.finish()
     if line is not None:

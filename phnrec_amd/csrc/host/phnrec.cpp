@@ -31,7 +31,9 @@ static void Help()
     puts(" -b num [32768]     frames per GPU launch when batching a file list (131072 with -D)");
     puts(" -j num [all]       host threads for the front-end and the decoder");
     puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
-    puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)\n");
+    puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)");
+    puts(" -H                 split-f16 arithmetic: f32 products as three exact f16 MFMA products (2x the kernel rate,\n"
+         "                    same distance to the reference; shipped LCRC systems)\n");
 }
 
 struct Opt {
@@ -72,7 +74,7 @@ int main(int argc, char **argv)
 {
     const char *config_dir = nullptr, *file_list = nullptr, *input_file = nullptr, *output_file = nullptr;
     const char *output_mlf = nullptr, *wpenalty = nullptr;
-    bool live = false, verbose = false, gpu_fe = false, gpu_dec = false;
+    bool live = false, verbose = false, gpu_fe = false, gpu_dec = false, split_f16 = false;
     int gpus = 1, batch = 0, threads = 0;
     DataFormat iformat = dfWaveform, oformat = dfStrings;
     WaveFormat wformat = WF_UNKNOWN;
@@ -81,7 +83,7 @@ int main(int argc, char **argv)
     int ind = 0;
     for (;;) {
         const char *arg = nullptr;
-        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:FD", ind, arg);
+        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:FDH", ind, arg);
         if (c == -1) break;
         switch (c) {
         case 'c': config_dir = arg; break;
@@ -113,6 +115,7 @@ int main(int argc, char **argv)
         case 'j': threads = atoi(arg); break;
         case 'F': gpu_fe = true; break;
         case 'D': gpu_dec = true; break;
+        case 'H': split_f16 = true; break;
         case '?': Die("Error during command line parsing\n");
         default: break;                       // bare words are skipped, as in the reference
         }
@@ -127,6 +130,7 @@ int main(int argc, char **argv)
     if (threads > 0) SR.SetHostThreads(threads);
     SR.SetGpuFrontend(gpu_fe);
     SR.SetGpuDecoder(gpu_dec);
+    SR.SetSplitF16(split_f16);
     if (!SR.Init(std::string(config_dir) + "/config")) Die(SR.LastError());
 
     if (wpenalty) {

@@ -319,6 +319,7 @@ bool SpeechRec::EnsureGpus()
         // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
         t->SetHiddenSplit(1);
         if (!t->Init(config_dir_.c_str())) return Fail(t->LastError() + "\n");
+        if (split_f16_ && !t->SetArithmetic(LCRC_ARITH_SPLIT_F16)) return Fail(t->LastError() + "\n");
         if (gpu_frontend_) {
             if (wave_.noise_level != 0.0f) return Fail("source/noise_level needs the host front-end (libc rand()); drop -F\n");
             lcrc_frontend fe;

@@ -68,6 +68,7 @@ public:
     void SetBatchFrames(int n) { batch_frames_ = n; }
     void SetHostThreads(int n) { host_threads_ = n; }
     void SetGpuDecoder(bool v) { gpu_decoder_ = v; }     // -D: PhnDec on the GPU, posteriors never leave it
+    void SetSplitF16(bool v) { split_f16_ = v; }         // -H: lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16)
     void SetGpuFrontend(bool v) { gpu_frontend_ = v; }   // -F: waveform -> posteriors without the host front-end
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
@@ -101,7 +102,7 @@ private:
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
 
     std::string config_dir_, err_;
-    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false;
+    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false, split_f16_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     float wpenalty_ = -2.0f;

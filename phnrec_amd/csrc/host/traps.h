@@ -55,6 +55,13 @@ public:
     // lcrc_set_hidden_split: 0 = small launches spread a tile's hidden units over several workgroups (default),
     // 1 = fused kernel only (a frame's output never depends on what else shares its launch)
     void SetHiddenSplit(int v) { hidden_split_ = v; if (ctx_) lcrc_set_hidden_split(ctx_, v); }
+    // lcrc_set_arithmetic: false when the model has no split-f16 form (LastError() says why)
+    bool SetArithmetic(int a)
+    {
+        if (lcrc_set_arithmetic(ctx_, a) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     bool CalcUtterance(const float *mel, int n, float *post)
     {
         if (lcrc_posteriors(ctx_, mel, n, post) == LCRC_OK) return true;

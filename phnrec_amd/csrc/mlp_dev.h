@@ -503,8 +503,11 @@ __device__ __forceinline__ void h2_img_store(void *img, int ofs, int lo_ofs, flo
     *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs + lo_ofs) = lo;
 }
 
-// Ring depth: the split-f16 loops are bound by the L2's bandwidth, not by its latency -- 8, 11/12 and 16 entries run alike
-// (A/B run 17), so the shallowest ring (fewest registers) it is.
+// Ring depth: what bounds the split-f16 loops at 32 frames per workgroup is the CU's vector-memory path (64 B/clk: every
+// wave streams 42-54 KB of fragments per tile pair, 83 B/clk would be needed to keep up with the MFMAs), not the latency
+// of the loads -- 8, 11/12 and 16 entries run alike (A/B run 17), so the shallowest ring (fewest registers) it is.
+// For the same reason the sigmoid stays one block in front of a pass's MFMAs as in the f32 loop: dealt out over the
+// layer-1 MFMAs' issue gaps (which the f16 MFMA, unlike the f32 one, leaves to the VALU) it gained nothing (A/B run 18).
 constexpr int h2_ring_size()
 {
 #ifdef LCRC_H2_RING      // A/B switch (tools/build_ab_lib.sh)
@@ -555,8 +558,10 @@ struct HalfLoop {
         if (MODE != PRO) {
             SigTile<2 * FT> sg;
             sg.begin(pre);
+            if (!(LCRC_DBG & 2)) {
 #pragma unroll
-            for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k);
+                for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k);
+            }
             f4 s[2 * FT];
             sg.finish(s);
 #pragma unroll
@@ -615,7 +620,7 @@ struct HalfLoop {
                 }
             }
             const int e = (i + R) % FP, dp = (i + R) / FP;
-            if (MODE != LAST || (dp == 0 && e < NOT)) request(i % R, e, P + dp);
+            if ((MODE != LAST || (dp == 0 && e < NOT)) && !(LCRC_DBG & 4)) request(i % R, e, P + dp);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE != LAST) {
@@ -655,7 +660,7 @@ struct HalfLoop {
     {
         w1 = reinterpret_cast<const f4 *>(nd.w1h); w2 = reinterpret_cast<const f4 *>(nd.w2h);
         b1 = nd.b1; XF = xf_image; lane = lane_;
-        plast = nd.npairs - 1;
+        plast = (LCRC_DBG & 1) ? 0 : nd.npairs - 1;
     }
 };
 

@@ -43,6 +43,22 @@ def test_bundled_utterance_end_to_end(system, tmp_path):
     assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
+def test_split_f16_flag(system, tmp_path):
+    """-H (lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16)): the shipped label file and the reference's posterior dump at
+    the same bar as without the flag; combined with the GPU front-end and decoder"""
+    out = tmp_path / "t.rec"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-o", out, "-H")
+    _labels_match(out, os.path.join(GOLD, "rec", system + ".rec"))
+    lop = tmp_path / "t.lop"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-t", "post", "-o", lop, "-H")
+    got, want = read_htk(str(lop)), read_htk(os.path.join(GOLD, system, "test.lop"))
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+    out2 = tmp_path / "t2.rec"
+    run("-c", model_dir(system), "-i", os.path.join(GOLD, "test.raw"), "-o", out2, "-H", "-F", "-D")
+    _labels_match(out2, os.path.join(GOLD, "rec", system + ".rec"))
+
+
 @pytest.mark.parametrize("system", [CZ, EN])
 def test_params_in_posteriors_out(system, tmp_path):
     """-s par: the hot path in its most direct CLI form (srec.cpp:1136-1145: the input is the reference's own
@@ -313,6 +329,9 @@ def test_bench_line_carries_every_leg():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] == 1
     assert c["parity_max_abs_vs_gpu"] < 1e-4
+    assert c["parity_max_abs_vs_gpu_split_f16"] < 1e-4
+    sf = d["split_f16"]              # the opt-in arithmetic beside the headline, never as it
+    assert sf["value"] > d["value"] and sf["max_abs_vs_f32_kernels"] < 2e-5 and sf["rows_sum_to_one"] is True
     assert d["push_bunch5"]["value"] > 50000, "the 50 k frames/s floor at the shipped bunch of 5"
     assert d["push_bunch512"]["value"] > d["push_bunch5"]["value"]
     assert set(d["small_launches"]) >= {"cz_2048", "cz_4096", "en_4096"}
