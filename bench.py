@@ -208,6 +208,9 @@ def split_f16_leg(capi, ctx, stream, d_mel, d_post, n, flops_frame, f32_post, f3
     return leg, post
 
 
+SMALL_PREHEAT = 600     # launches in front of each timed small-launch leg (stated in the line)
+
+
 def small_launch_legs(capi, modelgen, dev, stream):
     """The small-launch regime, beside the headline: roofline fraction of 2048- and 4096-frame launches (the
     launcher picks 16-frame workgroups and, below half of the CUs, the split-hidden kernels), for CZ and for EN
@@ -229,10 +232,13 @@ def small_launch_legs(capi, modelgen, dev, stream):
         d_post = torch.empty((4096, ctx.n_out), dtype=torch.float32, device=dev)
         tag = system.split("_")[1].lower()
         for n in (2048, 4096):
-            time_launches(ctx, stream, d_mel, d_post, n, 30)
+            # its own disclosed pre-heat: the legs before this one leave the device idle between calls, and 30 launches
+            # of 0.05-0.1 ms do not bring the clock back up (it takes ~25 ms of load, see --preheat)
+            time_launches(ctx, stream, d_mel, d_post, n, SMALL_PREHEAT)
             ms = time_launches(ctx, stream, d_mel, d_post, n, 200)
             out["%s_%d" % (tag, n)] = {"kernel_ms": round(ms, 4), "frames_per_s": round(n / ms * 1e3, 1),
-                                       "frac": round(n * fpf / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                                       "frac": round(n * fpf / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "preheat_launches": SMALL_PREHEAT}
         if tag == "cz":
             # streaming: raw ctypes calls on preallocated buffers (what a C caller pays), wall clock
             L, h = ctx.L, ctx.h

@@ -292,66 +292,78 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                     roff[n][f][s4] = (srow - tbase) * nb;
                 }
             }
-        // One loop per half context (n = 0: left, 1: right), bands dealt to the waves.  The operand values and the
-        // normalisation constants of band b + NW are requested (independent LDS reads) before the MFMAs of band b:
+        // Bands are dealt to the waves; an item is one band's LEFT and RIGHT half context together (2 * FT independent
+        // MFMA chains: with 16-frame workgroups one half alone is a single dependent chain of four).  The operand values and
+        // the normalisation constants of band b + NW are requested (independent LDS reads) before the MFMAs of band b:
         // the compiler cannot move LDS reads above the previous item's operand-image stores by itself.
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const float *mean = nrm_band + n * 32 * nkq1, *dev = mean + 16 * nkq1;
-            float *img = xf + (size_t)n * (FT * nkq1 * 256);
-            float *dbg = PROBES ? (n == 0 ? dbg_in0 : dbg_in1) : nullptr;
-            auto gather = [&](int b, float (&x)[FT][4], float &mk, float &dk) {
+        {
+            const float *mean0 = nrm_band, *dev0 = mean0 + 16 * nkq1, *mean1 = nrm_band + 32 * nkq1, *dev1 = mean1 + 16 * nkq1;
+            auto gather = [&](int b, float (&x)[2][FT][4], float (&mk)[2], float (&dk)[2]) {
                 const int bc = min(b, nb - 1);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++)
+                for (int n = 0; n < 2; n++)
 #pragma unroll
-                    for (int f = 0; f < FT; f++) x[f][s4] = melT[roff[n][f][s4] + bc] * wv[n][s4];
-                mk = mean[bc * kNCoef + cc];
-                dk = dev[bc * kNCoef + cc];
+                    for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                        for (int f = 0; f < FT; f++) x[n][f][s4] = melT[roff[n][f][s4] + bc] * wv[n][s4];
+                mk[0] = mean0[bc * kNCoef + cc]; dk[0] = dev0[bc * kNCoef + cc];
+                mk[1] = mean1[bc * kNCoef + cc]; dk[1] = dev1[bc * kNCoef + cc];
             };
-            float xw[FT][4], xn[FT][4], mk, dk, mkn, dkn;
+            float xw[2][FT][4], xn[2][FT][4], mk[2], dk[2], mkn[2], dkn[2];
             gather(wave, xw, mk, dk);
             for (int b = wave; b < nb; b += NW) {
                 gather(b + NW, xn, mkn, dkn);
                 const int k = b * kNCoef + cc;
-                f4 acc[FT];
+                f4 acc[2][FT];
 #pragma unroll
-                for (int f = 0; f < FT; f++) acc[f] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < 2; n++)
+#pragma unroll
+                    for (int f = 0; f < FT; f++) acc[n][f] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                    for (int f = 0; f < FT; f++) acc[f] = mfma16x16x4(xw[f][s4], basis[s4], acc[f]);
+                    for (int n = 0; n < 2; n++)
+#pragma unroll
+                        for (int f = 0; f < FT; f++) acc[n][f] = mfma16x16x4(xw[n][f][s4], basis[s4], acc[n][f]);
                 if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
                     // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
                     const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
 #pragma unroll
-                    for (int f = 0; f < FT; f++) {
+                    for (int n = 0; n < 2; n++) {
+                        float *img = xf + (size_t)n * (FT * nkq1 * 256);
 #pragma unroll
-                        for (int reg = 0; reg < 4; reg++) {
-                            const float val = acc[f][reg] * normc;           // CalcC0 / sDCT scaling
-                            float v = val - mk;                              // Normalize nn.cpp:702-716
-                            v *= dk;
-                            if constexpr (ARITH == 1)
-                                h2_img_store(img, f * (2 * NS1 * 1024) + (4 * g + reg) * 16 + h2_k_ofs(k), NS1 * 1024, v);
-                            else img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
-                        }
-                    }
-                    if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
-#pragma unroll
-                        for (int f = 0; f < FT; f++)
+                        for (int f = 0; f < FT; f++) {
 #pragma unroll
                             for (int reg = 0; reg < 4; reg++) {
-                                const int fr = 16 * f + 4 * g + reg;
-                                if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[f][reg] * normc;
+                                const float val = acc[n][f][reg] * normc;        // CalcC0 / sDCT scaling
+                                float v = val - mk[n];                           // Normalize nn.cpp:702-716
+                                v *= dk[n];
+                                if constexpr (ARITH == 1)
+                                    h2_img_store(img, f * (2 * NS1 * 1024) + (4 * g + reg) * 16 + h2_k_ofs(k), NS1 * 1024, v);
+                                else img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
                             }
+                        }
+                        float *dbg = PROBES ? (n == 0 ? dbg_in0 : dbg_in1) : nullptr;
+                        if (PROBES && dbg) {             // stage probe (diagnostic instantiation only)
+#pragma unroll
+                            for (int f = 0; f < FT; f++)
+#pragma unroll
+                                for (int reg = 0; reg < 4; reg++) {
+                                    const int fr = 16 * f + 4 * g + reg;
+                                    if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[n][f][reg] * normc;
+                                }
+                        }
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < FT; f++)
+                for (int n = 0; n < 2; n++) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) xw[f][s4] = xn[f][s4];
-                mk = mkn;
-                dk = dkn;
+                    for (int f = 0; f < FT; f++)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) xw[n][f][s4] = xn[n][f][s4];
+                    mk[n] = mkn[n];
+                    dk[n] = dkn[n];
+                }
             }
         }
     }
