@@ -300,10 +300,16 @@ def wave_path_leg(capi, mdir, nb, gpu):
     ctx = capi.Lcrc(mdir, nb, device=gpu)
     ctx.configure_frontend(wave_format="alaw", sent_mean_norm=True)
     frames = ctx.frontend_frames(len(raw))
-    post, _ = ctx.wave_to_posteriors([raw])
+    # the C entry point on the caller's own, reused buffers (what a C caller pays)
+    rawb = np.frombuffer(raw + b"\0", dtype=np.uint8).copy()
+    off = np.array([0, len(raw)], np.int64)
+    post = np.empty((frames, ctx.n_out), np.float32)
+    foff = np.zeros(2, np.int32)
+    for _ in range(3):
+        ctx._check(ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff))
     reps, t0 = 20, time.perf_counter()
     for _ in range(reps):
-        ctx.wave_to_posteriors([raw])
+        ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff)
     dt = (time.perf_counter() - t0) / reps
     ok = bool(np.abs(post.sum(axis=1) - 1).max() < 1e-5)
     ctx.close()
@@ -311,7 +317,7 @@ def wave_path_leg(capi, mdir, nb, gpu):
             "bytes_in": len(raw), "rows_sum_to_one": ok,
             "what": "configs[2] input per SURVEY 8(d) cfg3 (A-law, 5 sines + noise, seed 1235): "
                     "lcrc_wave_to_posteriors(): A-law decode + mel bank + sentence mean norm + posteriors on the GPU, "
-                    "host bytes in, host posteriors out, synchronous"}
+                    "host bytes in, host posteriors out (reused buffers), synchronous"}
 
 
 def cli_e2e_leg(mdir, n_files, gpu):
@@ -583,15 +589,37 @@ def main():
             if ranks.world == 1:
                 # the host-pointer entry point (pageable buffers in, pageable out): PCIe-inclusive,
                 # reported beside `value`, never as it
+                # (the C entry point on the caller's own, reused buffers: a fresh numpy array per call would add
+                #  its page faults -- 0.3 ms for 4.5 MB of posteriors -- to every call)
                 reps = 20
-                ctx.posteriors(mel)
+                h_post = np.empty((args.batch, ctx.n_out), np.float32)
+                for _ in range(3):
+                    ctx._check(ctx.L.lcrc_posteriors(ctx.h, mel, args.batch, h_post))
                 t0 = time.perf_counter()
                 for _ in range(reps):
-                    ctx.posteriors(mel)
+                    ctx.L.lcrc_posteriors(ctx.h, mel, args.batch, h_post)
                 dt = (time.perf_counter() - t0) / reps
                 line["host_path"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
                                      "ms_per_call": round(dt * 1e3, 4),
-                                     "what": "lcrc_posteriors(): memcpy to pinned + H2D + kernel + D2H + memcpy, synchronous"}
+                                     "what": "lcrc_posteriors() on reused pageable buffers: memcpy to pinned + H2D + kernel + "
+                                             "D2H + memcpy, synchronous"}
+                # the zero-copy form (lcrc_stage_buffers / lcrc_stage_run): the caller fills and reads the context's
+                # pinned buffers, so what is left is H2D + kernel + D2H -- the PCIe-inclusive floor of this launch size
+                import ctypes as C
+                pm, pp = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+                ctx._check(ctx.L.lcrc_stage_buffers(ctx.h, args.batch, C.byref(pm), C.byref(pp)))
+                C.memmove(pm, mel.ctypes.data, mel.nbytes)
+                one = np.array([0, args.batch], np.int32)
+                for _ in range(3):
+                    ctx._check(ctx.L.lcrc_stage_run(ctx.h, one, 1))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    ctx.L.lcrc_stage_run(ctx.h, one, 1)
+                dt = (time.perf_counter() - t0) / reps
+                line["host_path_zero_copy"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
+                                               "ms_per_call": round(dt * 1e3, 4),
+                                               "what": "lcrc_stage_run() on the context's pinned buffers: H2D + kernel + D2H, "
+                                                       "synchronous"}
             if ranks.world == 1 and not args.no_extras:
                 for key, leg in (("small_launches", lambda: small_launch_legs(capi, modelgen, dev, stream)),
                                  ("wave_path", lambda: wave_path_leg(capi, mdir, nb, gpu)),
