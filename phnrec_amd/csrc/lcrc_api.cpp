@@ -184,7 +184,7 @@ int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
 // Out-of-range rows/columns are zeros, which is what makes padded hidden units and
 // padded k-steps contribute nothing (the reference zero-fills its x4 pads the same
 // way, nn.cpp:239-243,276-280).
-int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
+int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d, bool split_f16_form = false)
 {
     d.n_inp = h.n_inp; d.n_hid = h.n_hid; d.n_out = h.n_out;
     d.ksteps = (h.n_inp + 3) / 4;
@@ -226,7 +226,8 @@ int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
     HIP_TRY(c, dev_upload(c, b2, &d.b2));
     HIP_TRY(c, dev_upload(c, mean, &d.mean));
     HIP_TRY(c, dev_upload(c, dev, &d.dev));
-    return pack_net_h2(c, h, d, ns);
+    d.w1h = d.w2h = nullptr;
+    return split_f16_form ? pack_net_h2(c, h, d, ns) : LCRC_OK;       // (the LCRC kernels only)
 }
 
 // Test hook (lcrc_debug_fail_alloc): the n-th buffer allocation from now on fails with out-of-memory.
@@ -621,7 +622,7 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
     auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
     for (int i = 0; i < 3; i++) {
         c->host[i] = nets[i];
-        int rc = pack_net(c, nets[i], c->nets[i]);
+        int rc = pack_net(c, nets[i], c->nets[i], true);
         if (rc) return bail(rc);
     }
     // DCT basis exactly as sDCT evaluates it (dspc.h:206-221), in f32 with libm cosf
