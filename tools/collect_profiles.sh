@@ -1,0 +1,43 @@
+#!/bin/bash
+# Copies the summaries of a tools/refresh_profiles.sh run (gpurun_out/refresh_<tag>/) into profiles/ under the round's names.
+#   tools/collect_profiles.sh r02
+set -e
+TAG=${1:-r02}
+R=gpurun_out/refresh_$TAG
+P=profiles
+clean() { grep -v amdgpu.ids "$1" > "$2"; }
+cp $R/bench.json $P/${TAG}_bench.json
+cp $R/bench_driver_form.json $P/${TAG}_bench_driver_form.json
+cp $R/stats/*/*kernel_stats.csv $P/${TAG}_kernel_stats.csv
+cp $R/kernel_trace_head.csv $P/${TAG}_kernel_trace_head.csv
+python3 tools/pmc_summary.py $TAG $R > /dev/null
+clean $R/phase_stamps.txt $P/${TAG}_phase_stamps.txt
+clean $R/system_sweep.txt $P/${TAG}_system_sweep.txt
+clean $R/small_launch_sweep.txt $P/${TAG}_small_launch_sweep.txt
+clean $R/traps_bench.txt $P/${TAG}_traps_bench.txt
+cp $R/traps_stats/*/*kernel_stats.csv $P/${TAG}_traps_kernel_stats.csv
+cp $R/wave_stats/*/*kernel_stats.csv $P/${TAG}_waveform_entry_kernel_stats.csv
+clean $R/cli_throughput.txt $P/${TAG}_cli_throughput.txt
+clean $R/ubench.txt $P/${TAG}_ubench.txt
+clean $R/split_f16_bench.txt $P/${TAG}_split_f16_bench.txt
+clean $R/split_phase_stamps.txt $P/${TAG}_split_f16_phase_stamps.txt
+cp $R/split_stats/*/*kernel_stats.csv $P/${TAG}_split_f16_kernel_stats.csv
+cp $R/split_ubench.txt $P/${TAG}_split_f16_ubench.txt
+python3 - "$R" "$P/${TAG}_split_f16_pmc.json" <<'PY'
+import collections, csv, glob, json, sys
+agg = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/split_pmc/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "lcrc_fused_kernel<42, 69, 9, 4, true, 2, false, false, 1>" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {"mean": sum(v) / len(v), "launches": len(v)} for k, v in sorted(agg.items())}
+d = {}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_INSTS_MFMA" in out:
+    d["mfma_cycles_per_instruction"] = out["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / out["SQ_INSTS_MFMA"]["mean"]
+    d["mfma_busy_cycles_per_simd"] = out["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0
+if "SQ_INSTS_VMEM_RD" in out:
+    d["vmem_read_instructions_per_wave"] = out["SQ_INSTS_VMEM_RD"]["mean"] / 1024.0
+json.dump({"kernel": "lcrc_fused_kernel<..., ARITH = 1> (CZ, 8192 frames, split-f16)", "counters": out, "derived": d},
+          open(sys.argv[2], "w"), indent=1)
+print(json.dumps(d))
+PY

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run (dev tool, GPU): 60 random LCRC model shapes (1-23 banks, hidden 1-399, 2-208 outputs,
 independent merger hidden size) on ragged batches, 16- and 32-frame workgroups and forced hidden splits, each against the oracle at the
-1e-4 bar.  usage: fuzz_parity.py [seed]"""
+1e-4 bar; then 24 models of the shipped shape classes (random hidden sizes, weight scales and input scales) in the split-f16
+arithmetic, against the oracle and against the f32 kernels.  usage: fuzz_parity.py [seed]"""
 import os, sys, tempfile, numpy as np
 sys.path.insert(0, os.getcwd())
 from phnrec_amd import capi, modelgen
@@ -35,3 +36,27 @@ for it in range(60):
             assert err < 1e-4, (nb, hid, nout, hm, fr, split, err)
         ctx.close()
 print("fuzz ok, worst max-abs", worst)
+worst_s, worst_d = 0.0, 0.0
+for it in range(24):
+    nb, nout = [(15, 138), (15, 137), (15, 186), (15, 185), (15, 159), (15, 160), (23, 120), (23, 119)][it % 8]
+    hid, hm = int(rng.integers(1, 700)), int(rng.integers(1, 700))
+    with tempfile.TemporaryDirectory() as d:
+        modelgen.write_model_dir(d, nb, hid, nout, seed=int(rng.integers(1 << 30)), hidden_merger=hm)
+        ctx = capi.Lcrc(d, nb)
+        assert not ctx.kernel_name.startswith("generic"), ctx.kernel_name
+        o = ob.Oracle(d, nb)
+        lens = [int(v) for v in rng.integers(0, 150, size=int(rng.integers(1, 7)))]
+        if sum(lens) == 0: lens.append(5)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mel = modelgen.synth_mel(int(off[-1]), nb, seed=it, mean_norm=bool(it & 1)) * np.float32(rng.choice([0.2, 1.0, 4.0]))
+        want = o.posteriors_batch(mel, off)
+        f32 = ctx.posteriors_batch(mel, off)
+        ctx.set_arithmetic(capi.ARITH_SPLIT_F16)
+        for fr in (16, 32):
+            ctx.set_tile_frames(fr)
+            got = ctx.posteriors_batch(mel, off)
+            err, dif = float(np.abs(got - want).max()), float(np.abs(got - f32).max())
+            worst_s, worst_d = max(worst_s, err), max(worst_d, dif)
+            assert err < 1e-4 and dif < 5e-5, (nb, hid, nout, hm, fr, err, dif)
+        ctx.close()
+print("split-f16 fuzz ok, worst max-abs vs oracle", worst_s, "vs the f32 kernels", worst_d)
