@@ -283,10 +283,8 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
 #define LCRC_DBG 0
 #endif
 
-// ---- hidden loop, ring form (shipped shapes, 8 waves per workgroup) -----------------------
-// Two waves share a SIMD (512 threads, <= 256 registers per lane): while one issues loads,
-// LDS reads or VALU work, or waits, the other keeps the MFMA pipe busy
-// (tools/ubench/cross_wave.hip).  To fit the register budget the weight fragments stream
+// ---- hidden loop, ring form ----------------------------------------------------------------
+// One wave per SIMD (a second one does not pay: DESIGN.md 3, "What bounds it").  The weight fragments stream
 // through a RING of R registers-quads instead of one buffer per layer.  Per hidden tile t the
 // fragments are consumed in the fixed order
 //     entry e <  NOT         W2(t)[e]         layer 2 of tile t      (8 MFMAs)
