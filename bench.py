@@ -193,7 +193,18 @@ def split_f16_leg(capi, ctx, stream, d_mel, d_post, n, flops_frame, f32_post, f3
     finally:
         ctx.set_arithmetic(capi.ARITH_F32)
     alg = n * flops_frame / (ms * 1e-3) / 1e12
-    leg = {"value": round(n / ms * 1e3, 1), "unit": "frames/s", "kernel_ms": round(ms, 4),
+    # its own bound: every workgroup (32 frames) streams the whole fragment set through its CU's vector-memory path
+    frag = 0
+    for i in range(3):
+        k, h, o = ctx.net_dims(i)
+        pairs, ns, n_ot = (h + 31) // 32, (k + 31) // 32, (o + 15) // 16
+        frag += pairs * (2 * ns + n_ot) * 2048
+    wgs = (n + 31) // 32
+    vmem_peak = 64 * 256 * 2.4e9                     # 64 B/clk per CU, 256 CUs, nominal clock
+    leg = {
+           "vmem_path": {"bound": "vector-memory path of the CUs (L1/TA, 64 B/clk each)", "bytes_per_workgroup": frag,
+                         "achieved": round(frag * wgs / (ms * 1e-3) / 1e12, 2), "peak": round(vmem_peak / 1e12, 1),
+                         "unit": "TB/s", "frac": round(frag * wgs / (ms * 1e-3) / vmem_peak, 3)},"value": round(n / ms * 1e3, 1), "unit": "frames/s", "kernel_ms": round(ms, 4),
            "speedup_vs_f32_kernel": round(f32_ms / ms, 3),
            "algorithmic_tflops": round(alg, 1),
            "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 3),
