@@ -361,7 +361,7 @@ def cli_e2e_leg(mdir, n_files, gpu):
             f.write("".join(n + "\n" for n in names))
         out["frames"] = frames
         env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=str(gpu))
-        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"])):
+        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"]), ("gpu_frontend_F_split_f16_H", ["-F", "-H"])):
             try:
                 t0 = time.perf_counter()
                 pr = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "out.mlf")] + extra, env=env,

@@ -62,6 +62,8 @@ def main():
             return
         for extra, label in ((["-t", "post"], "wf->post (HTK dumps)"), (["-m", os.path.join(td, "out.mlf")], "wf->str (MLF)"), (["-F", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end (-F)"),
                              (["-F", "-D", "-m", os.path.join(td, "out.mlf")], "wf->str, GPU front-end + decoder (-F -D)"),
+                             (["-F", "-H", "-m", os.path.join(td, "out.mlf")], "wf->str, -F, split-f16 arithmetic (-H)"),
+                             (["-F", "-D", "-H", "-m", os.path.join(td, "out.mlf")], "wf->str, -F -D -H"),
                              (["-F", "-D", "-b", "131072", "-m", os.path.join(td, "out.mlf")], "wf->str, -F -D, 131072 frames per launch"),
                              (["-F", "-b", "131072", "-m", os.path.join(td, "out.mlf")], "wf->str, -F, 131072 frames per launch"),
                              (["-m", os.path.join(td, "out.mlf"), "-j", "8"], "wf->str, 8 host threads")):
