@@ -6,22 +6,23 @@ TAG=${1:-r02}
 R=gpurun_out/refresh_$TAG
 P=profiles
 clean() { grep -v amdgpu.ids "$1" > "$2"; }
+first() { ls $1 | head -1; }     # (a traced run may leave one file per process)
 cp $R/bench.json $P/${TAG}_bench.json
 cp $R/bench_driver_form.json $P/${TAG}_bench_driver_form.json
-cp $R/stats/*/*kernel_stats.csv $P/${TAG}_kernel_stats.csv
+cp $(first "$R/stats/*/*kernel_stats.csv") $P/${TAG}_kernel_stats.csv
 cp $R/kernel_trace_head.csv $P/${TAG}_kernel_trace_head.csv
 python3 tools/pmc_summary.py $TAG $R > /dev/null
 clean $R/phase_stamps.txt $P/${TAG}_phase_stamps.txt
 clean $R/system_sweep.txt $P/${TAG}_system_sweep.txt
 clean $R/small_launch_sweep.txt $P/${TAG}_small_launch_sweep.txt
 clean $R/traps_bench.txt $P/${TAG}_traps_bench.txt
-cp $R/traps_stats/*/*kernel_stats.csv $P/${TAG}_traps_kernel_stats.csv
-cp $R/wave_stats/*/*kernel_stats.csv $P/${TAG}_waveform_entry_kernel_stats.csv
+cp $(first "$R/traps_stats/*/*kernel_stats.csv") $P/${TAG}_traps_kernel_stats.csv
+cp $(first "$R/wave_stats/*/*kernel_stats.csv") $P/${TAG}_waveform_entry_kernel_stats.csv
 clean $R/cli_throughput.txt $P/${TAG}_cli_throughput.txt
 clean $R/ubench.txt $P/${TAG}_ubench.txt
 clean $R/split_f16_bench.txt $P/${TAG}_split_f16_bench.txt
 clean $R/split_phase_stamps.txt $P/${TAG}_split_f16_phase_stamps.txt
-cp $R/split_stats/*/*kernel_stats.csv $P/${TAG}_split_f16_kernel_stats.csv
+cp $(first "$R/split_stats/*/*kernel_stats.csv") $P/${TAG}_split_f16_kernel_stats.csv
 cp $R/split_ubench.txt $P/${TAG}_split_f16_ubench.txt
 python3 - "$R" "$P/${TAG}_split_f16_pmc.json" <<'PY'
 import collections, csv, glob, json, sys
