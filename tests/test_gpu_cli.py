@@ -235,7 +235,7 @@ def _make_list(tmp_path, name, n_files, seed, fmt="lin16", rate=8000):
     return lst
 
 
-@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D")])
+@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D"), ("-H",), ("-H", "-F", "-D")])
 def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
     """`-g 2` (four contexts pulling launches from one queue; both logical GPUs mapped onto this box's GPU
     with PHNREC_DEVICE_MAP) writes byte for byte the MLF of `-g 1`: utterances never interact, outputs are
