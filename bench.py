@@ -576,6 +576,8 @@ def main():
                                        "log-mel frames resident in HBM, posteriors left in HBM"
                                        % (SYSTEM, args.batch),
                            "weights": weights_desc, "kernel": ctx.kernel_name,
+                           "arithmetic": "f32 operands on v_mfma_f32_16x16x4_f32, f32 accumulation (LCRC_ARITH_F32, the default; "
+                                         "the opt-in split-f16 arithmetic is the separate leg `split_f16`)",
                            "sharding": "one replica per GPU, utterances never exchanged (no collective)"},
                 # what actually ran: ranks as the process group counted them, how they were started, where
                 "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
