@@ -273,7 +273,7 @@ int lcrc_set_arithmetic(lcrc_ctx *ctx, int arithmetic);
  * device / pinned memory were exhausted; -1 switches the injection off.  The failing call returns
  * LCRC_E_NOMEM, leaves no half-allocated buffer group behind, and the context stays usable. */
 int lcrc_debug_fail_alloc(int nth);
-/* Name of the kernel variant selected for this model ("cz_11_18_9", "generic", ...) */
+/* Name of the kernel variant selected for this model ("cz_42_69_9", "generic_64_104_13", ...; the same in both arithmetics) */
 const char *lcrc_kernel_name(const lcrc_ctx *ctx);
 
 #ifdef __cplusplus
