@@ -34,6 +34,9 @@ void Traps::Init(char *dir)
         fprintf(stderr, "%s\n", lcrc_last_error(0));          // the text of traps.cpp:143
         exit(1);
     }
+    // opt-in: the split-f16 arithmetic (include/lcrc.h); a model without that form stays on the f32 kernels
+    if (getenv("PHNREC_SPLIT_F16") && lcrc_set_arithmetic(handle_, LCRC_ARITH_SPLIT_F16) != LCRC_OK)
+        fprintf(stderr, "WARNING: %s\n", lcrc_last_error(handle_));
 }
 
 void Traps::Reset() { lcrc_reset(handle_); }

@@ -60,12 +60,16 @@ def test_binding_demo_reproduces_the_reference(system, bunch, tmp_path, oracle_m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split_f16", [False, True])
 @pytest.mark.parametrize("system", [CZ, EN])
-def test_reference_cli_over_the_library(system, tmp_path):
+def test_reference_cli_over_the_library(system, split_f16, tmp_path, monkeypatch):
     """the reference's own phnrec.cpp / srec.cpp / melbanks.cpp / phndec.cpp with the MI355X library behind
-    Traps: its smoke test (test.sh) gives the shipped label file, -t post its own posterior dump"""
+    Traps: its smoke test (test.sh) gives the shipped label file, -t post its own posterior dump; also with the
+    binding's PHNREC_SPLIT_F16 switch (lcrc_set_arithmetic)"""
     if not os.path.exists(REFCLI):
         pytest.skip("tests/integration/_build/phnrec_ref_lcrc is built where /root/reference exists")
+    if split_f16:
+        monkeypatch.setenv("PHNREC_SPLIT_F16", "1")
     raw = os.path.join(GOLD, "test.raw")
     rec = tmp_path / "t.rec"
     p = subprocess.run([REFCLI, "-c", model_dir(system), "-i", raw, "-o", str(rec)], capture_output=True, text=True)
