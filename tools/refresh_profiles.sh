@@ -39,6 +39,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/traps_stats -- pyth
 python3 tools/split_f16_bench.py > $OUT/split_f16_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/split_stats -- python3 tools/split_f16_bench.py 8192 > $OUT/split_prof.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/split_pmc -- python3 tools/split_f16_bench.py 8192 > $OUT/split_pmc.log 2>&1
+rocprofv3 --pmc TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $OUT/split_ta_pmc -- python3 tools/split_f16_bench.py 8192 > $OUT/split_ta_pmc.log 2>&1
 LCRC_ARITH=1 python3 tools/stamp_profile.py > $OUT/split_phase_stamps.txt 2>&1
 LCRC_ARITH=1 LCRC_BM=16 python3 tools/stamp_profile.py PHN_EN_TIMIT_LCRC_N500 4096 >> $OUT/split_phase_stamps.txt 2>&1
 ./tools/ubench/split_f16 > $OUT/split_ubench.txt 2>&1
