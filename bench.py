@@ -207,7 +207,7 @@ def split_f16_leg(capi, ctx, stream, d_mel, d_post, n, flops_frame, f32_post, f3
                          "unit": "TB/s", "frac": round(frag * wgs / (ms * 1e-3) / vmem_peak, 3)},"value": round(n / ms * 1e3, 1), "unit": "frames/s", "kernel_ms": round(ms, 4),
            "speedup_vs_f32_kernel": round(f32_ms / ms, 3),
            "algorithmic_tflops": round(alg, 1),
-           "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 3),
+           "speed_vs_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 3),   # a ratio of rates, not a roofline fraction
            # three f16 products per f32 product: the MFMA work actually executed against the dense f16 peak
            "frac_of_f16_mfma_peak_3_products": round(3 * alg / PEAK_F16_MFMA_TFLOPS, 3),
            "bound": "the CU's vector-memory path (64 B/clk): 32 frames per workgroup stream 6.5 MB of weight fragments "
@@ -305,30 +305,228 @@ def config2_alaw_signal(frames=BATCH):
     return alaw_encode(np.clip(sig, -32768, 32767).astype(np.float32)).tobytes()
 
 
-def wave_path_leg(capi, mdir, nb, gpu):
+def config1_lin16_signal(frames=4096):
+    """BASELINE configs[1]'s input as SURVEY.md 8(d) cfg2 defines it: 16 kHz lin16 mono, (frames-1)*160+400 samples,
+    0.3 full-scale mix of 5 sines (200-3400 Hz) + Gaussian noise sigma 1000, clipped to int16, seed 1234"""
+    n = (frames - 1) * 160 + 400
+    rng = np.random.default_rng(1234)
+    t = np.arange(n) / 16000.0
+    sig = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n)
+    return np.clip(sig, -32768, 32767).astype("<i2").tobytes()
+
+
+def wave_path_leg(capi, mdir, nb, gpu, raw=None, wave_format="alaw", sent_mean_norm=True, what=None):
     """bytes in -> posteriors out through the GPU front-end (lcrc_wave_to_posteriors), PCIe-inclusive"""
-    raw = config2_alaw_signal()
+    raw = config2_alaw_signal() if raw is None else raw
     ctx = capi.Lcrc(mdir, nb, device=gpu)
-    ctx.configure_frontend(wave_format="alaw", sent_mean_norm=True)
+    spec = {}
+    if wave_format == "lin16" and nb == 23:       # the EN system's front-end (PHN_EN_TIMIT_LCRC_N500/config)
+        spec = dict(sample_freq=16000, vector_size=400, vector_step=160, lower_freq=0.0, higher_freq=8000.0)
+    ctx.configure_frontend(wave_format=wave_format, sent_mean_norm=sent_mean_norm, **spec)
     frames = ctx.frontend_frames(len(raw))
     # the C entry point on the caller's own, reused buffers (what a C caller pays)
     rawb = np.frombuffer(raw + b"\0", dtype=np.uint8).copy()
     off = np.array([0, len(raw)], np.int64)
     post = np.empty((frames, ctx.n_out), np.float32)
     foff = np.zeros(2, np.int32)
-    for _ in range(3):
-        ctx._check(ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff))
-    reps, t0 = 20, time.perf_counter()
-    for _ in range(reps):
-        ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff)
-    dt = (time.perf_counter() - t0) / reps
+    out = {}
+    # sentence mean in the reference's sequential order (the library's default) and as the opt-in tree
+    for key, order in (("value", 1), ("tree_mean_value", 0)) if sent_mean_norm else (("value", 1),):
+        ctx._check(ctx.L.lcrc_set_mean_order(ctx.h, order))
+        for _ in range(3):
+            ctx._check(ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff))
+        reps, t0 = 20, time.perf_counter()
+        for _ in range(reps):
+            ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff)
+        dt = (time.perf_counter() - t0) / reps
+        out[key] = round(frames / dt, 1)
+        out["ms_per_call" if key == "value" else "tree_mean_ms_per_call"] = round(dt * 1e3, 4)
     ok = bool(np.abs(post.sum(axis=1) - 1).max() < 1e-5)
     ctx.close()
-    return {"value": round(frames / dt, 1), "unit": "frames/s", "ms_per_call": round(dt * 1e3, 4), "frames": frames,
-            "bytes_in": len(raw), "rows_sum_to_one": ok,
-            "what": "configs[2] input per SURVEY 8(d) cfg3 (A-law, 5 sines + noise, seed 1235): "
-                    "lcrc_wave_to_posteriors(): A-law decode + mel bank + sentence mean norm + posteriors on the GPU, "
-                    "host bytes in, host posteriors out (reused buffers), synchronous"}
+    out.update({"unit": "frames/s", "frames": frames, "bytes_in": len(raw), "rows_sum_to_one": ok,
+                "what": what or "configs[2] input per SURVEY 8(d) cfg3 (A-law, 5 sines + noise, seed 1235): "
+                                "lcrc_wave_to_posteriors(): A-law decode + mel bank + sentence mean norm (reference order; "
+                                "tree_mean_*: lcrc_set_mean_order(0)) + posteriors on the GPU, host bytes in, host posteriors "
+                                "out (reused buffers), synchronous"})
+    return out
+
+
+def synthetic_list(td, n_files, seed=1236, rate=8000):
+    """SURVEY 8(d) cfg4's list: raw lin16 files of 3-15 s (slices of one synthetic signal); returns names, frames"""
+    rng = np.random.default_rng(seed)
+    n_base = 16 * rate
+    t = np.arange(n_base) / float(rate)
+    base = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n_base)
+    base = np.clip(base, -32768, 32767).astype("<i2")
+    names, frames = [], 0
+    vs, step = rate // 40, rate // 100
+    for i in range(n_files):
+        n = int(rng.uniform(3.0, 15.0) * rate)
+        o = int(rng.integers(0, n_base - n))
+        p = os.path.join(td, "f%05d.raw" % i)
+        base[o:o + n].tofile(p)
+        names.append(p)
+        frames += (n - vs) // step + 1
+    lst = os.path.join(td, "list.scp")
+    with open(lst, "w") as f:
+        f.write("".join(n + "\n" for n in names))
+    return lst, names, frames
+
+
+def run_cli(exe, args, env, timeout=600):
+    """one CLI run: wall clock of the process and the figures of its PHNREC_STATS line"""
+    import subprocess
+    t0 = time.perf_counter()
+    pr = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    wall = time.perf_counter() - t0
+    stats = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")]
+    if pr.returncode != 0 or not stats:
+        return {"error": "rc=%d %s" % (pr.returncode, pr.stderr.strip()[-300:])}, pr
+    kv = dict(tok.split("=", 1) for tok in stats[-1].replace("(", "").replace(")", "").split() if "=" in tok)
+    return {"value": float(kv["frames_per_s"]), "unit": "frames/s", "list_wall_s": float(kv["wall_s"]),
+            "process_wall_s": round(wall, 3), "xrt": float(kv["xRT"]), "gpu_kernel_ms": float(kv["gpu_kernel_ms"]),
+            "setup_s": float(kv["setup_s"]), "create_s": float(kv.get("create_s", 0)),
+            "first_launch_s": float(kv.get("first_launch_s", 0)), "main_s": float(kv.get("main_s", 0)),
+            "host_cpu_s": float(kv.get("host_cpu_s", 0)), "host_threads": int(kv.get("host_threads", 0)),
+            "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write") if k in kv}}, pr
+
+
+def single_file_leg(mdir, gpu):
+    """The reference's own smoke test (test.sh): `phnrec -c DIR -i test.raw -o test.rec` (and -t post) as a PROCESS,
+    wall clock from exec to exit, beside the reference's MKL build on the same file in the same run.  For one 7.5 s
+    file the GPU's start-up (HIP runtime, code objects, weight upload) is the whole cost; the break-down says where."""
+    import subprocess
+    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+    raw = os.path.join(ROOT, "tests", "golden", "test.raw")
+    if not os.path.exists(exe) or not os.path.exists(raw):
+        return None
+    env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=str(gpu))
+    out = {"file": "tests/golden/test.raw (7.5 s, 747 frames)",
+           "what": "process wall clock, median / min of 5 runs after one discarded run; break-down from PHNREC_STATS and "
+                   "LCRC_TRACE_STARTUP of the median run"}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for key, extra in (("str", ["-o", os.path.join(td, "x.rec")]), ("post", ["-t", "post", "-o", os.path.join(td, "x.lop")])):
+            runs = []
+            for i in range(6):
+                r, pr = run_cli(exe, ["-c", mdir, "-i", raw] + extra, dict(env, LCRC_TRACE_STARTUP="1"), timeout=120)
+                if "error" in r:
+                    out[key] = r
+                    break
+                r["trace"] = {ln.split(":", 1)[1].rsplit(None, 2)[0].strip(): float(ln.split()[-2])
+                              for ln in pr.stderr.splitlines() if ln.startswith("lcrc startup:")}
+                if i > 0:
+                    runs.append(r)
+            else:
+                runs.sort(key=lambda r: r["process_wall_s"])
+                med = runs[len(runs) // 2]
+                out[key] = {"process_wall_s": med["process_wall_s"], "min_process_wall_s": runs[0]["process_wall_s"],
+                            "main_s": med["main_s"], "gpu_create_s": med["create_s"], "first_launch_s": med["first_launch_s"],
+                            "list_wall_s": med["list_wall_s"], "kernel_ms": med["gpu_kernel_ms"], "create_trace_ms": med["trace"]}
+        from oracle import binding as ob
+        for key, blas in (("reference_cpu_mkl", True), ("reference_cpu_naive", False)):
+            ref = ob.ref_cli_path(blas)
+            if ref is None:
+                continue
+            renv = dict(os.environ, MKL_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL")
+            walls = []
+            try:
+                for i in range(6):
+                    t0 = time.perf_counter()
+                    subprocess.run([ref, "-c", mdir, "-i", raw, "-o", os.path.join(td, "r.rec")], env=renv, check=True,
+                                   capture_output=True, timeout=120)
+                    if i > 0:
+                        walls.append(time.perf_counter() - t0)
+                walls.sort()
+                out[key] = {"process_wall_s": round(walls[len(walls) // 2], 3), "min_process_wall_s": round(walls[0], 3),
+                            "kind": "reference", "cores": 1}
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+    return out
+
+
+HU = "PHN_HU_SPDAT_LCRC_N1500"
+
+
+def sharded_list_leg(n_gpus, dmap, n_files):
+    """BASELINE configs[3]: the HU system on a 10 000-file synthetic list (seed 1236), `phnrec -g N`
+    over the ranks' GPUs -> posteriors + host Viterbi -> MLF.  The CLI shards by pulling launches of consecutive files
+    from one queue (no collective).  host_ceiling: what this host's cores can do on the same list with the GPUs idle --
+    reading the files, and the host Viterbi on posterior dumps -- so that a flat curve over N can be read for what it is."""
+    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+    mdir = os.path.join(ROOT, "tests", "golden", "models", HU)
+    if not os.path.exists(exe) or not os.path.isdir(mdir):
+        return {"error": "CLI or %s model directory missing" % HU}
+    cores = usable_cpus()
+    out = {"system": HU, "files": n_files, "gpus": n_gpus, "device_map": dmap, "cores_usable": cores,
+           "what": "phnrec -c HU -l list -m out.mlf -g N (PHNREC_DEVICE_MAP = the ranks' GPUs): raw lin16 8 kHz files of "
+                   "3-15 s -> MLF on disk; frames/s of the list loop as the CLI reports it (process start-up and model load "
+                   "excluded; process_wall_s includes them)"}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        lst, names, frames = synthetic_list(td, n_files)
+        out["frames"] = frames
+        env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=",".join(str(d) for d in dmap))
+        mlfs = {}
+        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"]), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+            mlf = os.path.join(td, key + ".mlf")
+            try:
+                best = None
+                for _ in range(2):                    # the better of two runs (the first also warms the page cache)
+                    r, _pr = run_cli(exe, ["-c", mdir, "-l", lst, "-m", mlf, "-g", str(n_gpus)] + extra, env)
+                    if "error" in r or best is None or r["value"] > best["value"]:
+                        best = r
+                    if "error" in r:
+                        break
+                out[key] = best
+                mlfs[key] = mlf
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+        if isinstance(out.get("gpu_frontend_F"), dict) and "value" in out["gpu_frontend_F"]:
+            out["frames_per_s"] = out["gpu_frontend_F"]["value"]
+        try:
+            a, b = open(mlfs["gpu_frontend_F"]).read(), open(mlfs["gpu_frontend_decoder_F_D"]).read()
+            out["mlf_F_equals_F_D"] = a == b
+            out["mlf_entries"] = a.count('"\n') if a else 0
+        except Exception:
+            pass
+        # ---- what the host alone can do on this list ----
+        # The CLI times its host stages (CPU seconds summed over its threads: stat / read of the files into pinned
+        # memory, gather, Viterbi + label formatting + MLF): with the GPUs infinitely fast the list would still need
+        # that much CPU.  ceiling = frames x usable cores / host CPU seconds of the SAME run.
+        ceil = {"what": "frames x cores_usable / host_cpu_s of the run above (PHNREC_STATS: CPU seconds of the host stages -- "
+                        "file reads into pinned memory, gather, host Viterbi, label / MLF formatting -- summed over the "
+                        "pool's threads); the rate the host side of `phnrec -g N` cannot exceed on this box however many "
+                        "GPUs serve it"}
+        for key in ("host_frontend", "gpu_frontend_F", "gpu_frontend_decoder_F_D"):
+            r = out.get(key)
+            if isinstance(r, dict) and r.get("host_cpu_s", 0) > 0:
+                ceil[key] = {"frames_per_s": round(frames * cores / r["host_cpu_s"], 1), "host_cpu_s": r["host_cpu_s"],
+                             "cpu_s_by_stage": r.get("cpu_s_by_stage")}
+        if "gpu_frontend_F" in ceil:
+            ceil["frames_per_s"] = ceil["gpu_frontend_F"]["frames_per_s"]
+        try:
+            # the decoder leg alone, GPU idle: posterior dumps of the first files through `phnrec -s post -l ... -m`
+            sub = min(n_files, 1000)
+            sub_lst = os.path.join(td, "sub.scp")
+            with open(sub_lst, "w") as f:
+                for i in range(sub):
+                    f.write("%s %s\n" % (names[i], os.path.join(td, "p%05d.lop" % i)))
+            r, _pr = run_cli(exe, ["-c", mdir, "-l", sub_lst, "-t", "post", "-F", "-g", str(n_gpus)], env)
+            if "error" not in r:
+                lop_lst = os.path.join(td, "lop.scp")
+                with open(lop_lst, "w") as f:
+                    f.write("".join("%s\n" % os.path.join(td, "p%05d.lop" % i) for i in range(sub)))
+                best = None
+                for _ in range(2):
+                    v, _pr = run_cli(exe, ["-c", mdir, "-s", "post", "-l", lop_lst, "-m", os.path.join(td, "v.mlf")], env)
+                    if "error" not in v and (best is None or v["value"] > best["value"]):
+                        best = v
+                if best:
+                    ceil["decoder_only_frames_per_s"] = best["value"]
+                    ceil["decoder_only_sample"] = "%d posterior dumps: `phnrec -s post` (HTK read + Viterbi + MLF), no GPU" % sub
+        except Exception as e:
+            ceil["decoder_only_error"] = repr(e)
+        out["host_ceiling"] = ceil
+    return out
 
 
 def cli_e2e_leg(mdir, n_files, gpu):
@@ -458,6 +656,8 @@ def main():
     # ("roofline.cold"), so a short --warmup neither hides nor includes the ramp silently.  0 switches it off.
     ap.add_argument("--preheat", type=int, default=300)
     ap.add_argument("--cli-files", type=int, default=2000, help="files of the cli_e2e leg (0 = skip)")
+    ap.add_argument("--list-files", type=int, default=10000,
+                    help="files of the sharded_list leg (BASELINE configs[3]: 10 000; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-launch / push / wave / CLI legs")
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -634,8 +834,15 @@ def main():
                                                "what": "lcrc_stage_run() on the context's pinned buffers: H2D + kernel + D2H, "
                                                        "synchronous"}
             if ranks.world == 1 and not args.no_extras:
+                en_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_EN_TIMIT_LCRC_N500")
                 for key, leg in (("small_launches", lambda: small_launch_legs(capi, modelgen, dev, stream)),
                                  ("wave_path", lambda: wave_path_leg(capi, mdir, nb, gpu)),
+                                 ("wave_path_en", lambda: wave_path_leg(
+                                     capi, en_dir, 23, gpu, raw=config1_lin16_signal(), wave_format="lin16", sent_mean_norm=False,
+                                     what="configs[1] input per SURVEY 8(d) cfg2 (EN, 16 kHz lin16, 5 sines + noise, seed 1234, "
+                                          "4096 frames, posterior-only): lcrc_wave_to_posteriors(), host bytes in, host posteriors out "
+                                          "(reused buffers), synchronous") if os.path.isdir(en_dir) else None),
+                                 ("single_file", lambda: single_file_leg(mdir, gpu)),
                                  ("cli_e2e", lambda: cli_e2e_leg(mdir, args.cli_files, gpu) if args.cli_files > 0 else None),
                                  ("dropin_reference_cli", lambda: reference_cli_leg(mdir, gpu))):
                     try:
@@ -648,6 +855,13 @@ def main():
                     for k in ("push_bunch5", "push_bunch512"):
                         if k in line["small_launches"]:
                             line[k] = line["small_launches"].pop(k)
+            if args.list_files > 0:
+                # the thing north_star asks to scale: the sharded file list through the CLI, -g N over the ranks' GPUs
+                # (the other ranks idle at the barrier below; their contexts hold no work)
+                try:
+                    line["sharded_list"] = sharded_list_leg(ranks.world, dmap, args.list_files)
+                except Exception as e:
+                    line["sharded_list"] = {"error": repr(e)}
             split_post = None
             gpu_post = d_post.cpu().numpy() if ranks.world == 1 else None
             if ranks.world == 1 and not args.no_extras:
@@ -660,6 +874,7 @@ def main():
             if ranks.world == 1 and not args.no_cpu:
                 line["cpu_baseline"] = cpu_baseline(mdir, nb, mel, gpu_post, args.cpu_seconds, split_post)
         ctx.close()
+    ranks.host_barrier()     # rank 0's side legs are over (a CPU-side wait: the other ranks' GPUs stay idle meanwhile)
     ranks.finish()
     if line is not None:
         print(json.dumps(line), flush=True)

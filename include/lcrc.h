@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define LCRC_ABI_VERSION 1
+/* 2: lcrc_clone; sentence mean in the reference's order by default; split-f16 operand images built on request and
+ *    scaled (any finite weights); lcrc_debug_fail_alloc needs LCRC_FAULT_INJECTION=1 in the environment */
+#define LCRC_ABI_VERSION 2
 
 enum {
     LCRC_OK        = 0,
@@ -57,6 +59,18 @@ typedef struct lcrc_ctx lcrc_ctx;
  * error instead of exit(1). */
 int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
                 int add_c0, int device_id);
+/* Optional: starts the HIP runtime and GPU `device_id`'s context (~0.2 s in a fresh process, by far the largest part of
+ * a first lcrc_create) and returns when they are up.  Thread-safe; meant to be called from a helper thread at program
+ * start so that the caller's own initialisation -- configuration, the model files and their re-packing inside
+ * lcrc_create, the first file's front-end -- overlaps with it (the CLI does).  No reference counterpart: the reference
+ * has no device to bring up. */
+int lcrc_device_warmup(int device_id);
+/* A further context for the same model on the same GPU (the reference would construct a second Traps and load the
+ * files again, traps.cpp:88-171): own stream, staging buffers, streaming state and settings (all at their defaults),
+ * but the read-only device buffers -- packed weights, biases, norms, tables -- are SHARED with `src` and freed with the
+ * last context that uses them.  No file is read, nothing is packed or uploaded.  This is how the CLI gets its second
+ * context per GPU (one stages / decodes while the other's launch runs). */
+int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src);
 
 /* The other values of posteriors/system ("next" row f4): "1BT_DCT" (the schema default, srec.cpp:69: C0 / DCT
  * of every band's 31-point trajectory into one net), "1BT" (one 31-input net per band, -ln of their outputs
@@ -161,11 +175,12 @@ typedef struct lcrc_frontend {
 
 int lcrc_frontend_configure(lcrc_ctx *ctx, const lcrc_frontend *cfg);
 /* Order of the column sums of the sentence mean normalisation (srec.cpp:1500-1511, matrix.h:2101-2116).
- * 0 (default): a fixed-shape tree per utterance (256-row blocks from the utterance's first row, strided lane
- * sums folded by halves, block sums added in order) -- deterministic, independent of what else is in the call,
- * a few microseconds for any length; the mean differs from the reference's by ~1e-7 relative.
- * 1: the reference's sequential f32 sums in frame order, bit for bit (a dependent add chain: ~13 ns per frame
- * of the longest utterance). */
+ * 1 (default): the reference's sequential f32 sums in frame order, bit for bit (a dependent add chain per
+ * utterance and bank: ~13 ns per frame of the longest utterance of the call; utterances run side by side).
+ * 0 (opt-in, for very long single utterances): a fixed-shape tree per utterance (256-row blocks from the
+ * utterance's first row, strided lane sums folded by halves, block sums added in order) -- deterministic,
+ * independent of what else is in the call, a few microseconds for any length; the mean differs from the
+ * reference's by ~1e-7 relative. */
 int lcrc_set_mean_order(lcrc_ctx *ctx, int sequential);
 /* frames a file of n_bytes yields: len > vs ? (len - vs)/step + 1 : 1   (srec.cpp:945) */
 int lcrc_frontend_frames(const lcrc_ctx *ctx, long long n_bytes);
@@ -251,7 +266,10 @@ int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
 /* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
  * (tuning and test hook; results are bit-identical either way) */
 int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
-/* Small launches (streaming bunches, short utterances: fewer 16-frame tiles than half of the CUs) run
+/* NOTE on batch invariance: with the default (0) a frame's last bits depend on the size of the launch it is part
+ * of, for every caller of this library (as the reference's do on bunch_size through BLAS's sgemv / sgemm kernels);
+ * callers that need bit-identical posteriors however frames are batched set 1, as this repository's CLI does.
+ * Small launches (streaming bunches, short utterances: fewer 16-frame tiles than half of the CUs) run
  * on the split-hidden kernels: every frame tile's hidden dimension is spread over several workgroups,
  * whose partial output tiles the last arriver adds in a fixed order.  The result of a frame then depends
  * on the number of workgroups per tile (last bits; each setting is deterministic and within the parity
@@ -262,16 +280,22 @@ int lcrc_set_hidden_split(lcrc_ctx *ctx, int workgroups_per_tile);
 /* Arithmetic of the LCRC kernels.  LCRC_ARITH_F32 (default): v_mfma_f32_16x16x4_f32, the reference's f32 products
  * one by one.  LCRC_ARITH_SPLIT_F16: every f32 operand as a (high, low) pair of f16 values and every product as three
  * exact f16 x f16 MFMA products accumulated in f32 (what is dropped is below 2^-22 of a product -- the size of f32's
- * own rounding of the sums; measured distance to the reference: the same few 1e-6 as LCRC_ARITH_F32).  The f16 MFMA
- * runs 16x the f32 MFMA's rate, so the kernel is 2-3x faster; it exists for the shipped LCRC shapes and models whose
- * weights lie within +-65504 (else LCRC_E_UNSUPPORTED and the setting is unchanged); normalised inputs beyond that
- * range are clamped to it.  Every launch uses the fused kernel in this mode (as with lcrc_set_hidden_split(h, 1)). */
+ * own rounding of the sums; measured distance to the reference: the same few 1e-6 as LCRC_ARITH_F32).  So that the low
+ * halves keep their 11 bits (an f16 below 2^-14 is subnormal) every operand is scaled by a power of two before it is
+ * split -- each weight matrix so that its largest entry lies in (2^13, 2^14], net inputs by 2^6, hidden activations by
+ * 2^14 -- and the accumulators are scaled back exactly; a model with tiny (or huge) weights loses nothing.  The f16
+ * MFMA runs 16x the f32 MFMA's rate, so the kernel is 2-3x faster; it exists for the shipped LCRC shapes (else
+ * LCRC_E_UNSUPPORTED and the setting is unchanged; also for non-finite weights); normalised net inputs beyond +-1023
+ * are clamped there (documented deviation: a feature 1000 standard deviations out saturates every sigmoid anyway).  The
+ * operand images are built and uploaded by the first call that asks for them.  Every launch uses the fused kernel in
+ * this mode (as with lcrc_set_hidden_split(h, 1)). */
 #define LCRC_ARITH_F32 0
 #define LCRC_ARITH_SPLIT_F16 1
 int lcrc_set_arithmetic(lcrc_ctx *ctx, int arithmetic);
-/* Test hook: the nth (0 = next) staging-buffer allocation of this process from now on fails as if the
- * device / pinned memory were exhausted; -1 switches the injection off.  The failing call returns
- * LCRC_E_NOMEM, leaves no half-allocated buffer group behind, and the context stays usable. */
+/* Test hook, inert unless the process environment holds LCRC_FAULT_INJECTION=1 (else LCRC_E_UNSUPPORTED): the nth
+ * (0 = next) staging-buffer allocation of this process from now on fails as if the device / pinned memory were
+ * exhausted; -1 switches the injection off.  The failing call returns LCRC_E_NOMEM, leaves no half-allocated
+ * buffer group behind, and the context stays usable. */
 int lcrc_debug_fail_alloc(int nth);
 /* Name of the kernel variant selected for this model ("cz_42_69_9", "generic_64_104_13", ...; the same in both arithmetics) */
 const char *lcrc_kernel_name(const lcrc_ctx *ctx);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 
 # every symbol include/lcrc.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "lcrc_create", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
+    "lcrc_create", "lcrc_clone", "lcrc_device_warmup", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
@@ -106,6 +106,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lcrc_clone.argtypes = [C.POINTER(vp), vp]
+    L.lcrc_device_warmup.argtypes = [C.c_int]
     L.lcrc_model_outputs.argtypes = [C.c_char_p, C.c_char_p]
     L.lcrc_create_system.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcrc_destroy.argtypes = [vp]
@@ -169,10 +171,12 @@ def model_info(model_dir, nbanks):
 class Lcrc:
     """One estimator context on one GPU (mirrors class Traps' public surface)."""
 
-    def __init__(self, model_dir, nbanks, device=0, trap_len=31, add_c0=True, system="LCRC", hamming=False):
+    def __init__(self, model_dir, nbanks, device=0, trap_len=31, add_c0=True, system="LCRC", hamming=False, clone_of=None):
         self.L = load()
         self.h = C.c_void_p()
-        if system == "LCRC" and not hamming:
+        if clone_of is not None:         # lcrc_clone: a second context that shares clone_of's weights on the device
+            rc = self.L.lcrc_clone(C.byref(self.h), clone_of.h)
+        elif system == "LCRC" and not hamming:
             rc = self.L.lcrc_create(C.byref(self.h), os.fsencode(model_dir), nbanks, trap_len,
                                     int(add_c0), device)
         else:
@@ -183,6 +187,9 @@ class Lcrc:
             raise LcrcError(rc, self.L.lcrc_last_error(None).decode())
         self.nbanks = nbanks
         self.n_out = self.L.lcrc_num_outputs(self.h)
+
+    def clone(self):
+        return Lcrc(None, self.nbanks, clone_of=self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -278,7 +285,7 @@ class Lcrc:
         self._check(self.L.lcrc_frontend_configure(self.h, C.byref(fe)))
 
     def set_mean_order(self, sequential):
-        """False (default): fixed-shape tree sums; True: the reference's sequential column sums"""
+        """True (default): the reference's sequential column sums; False: fixed-shape tree sums (opt-in)"""
         self._check(self.L.lcrc_set_mean_order(self.h, int(sequential)))
 
     def frontend_frames(self, n_bytes):

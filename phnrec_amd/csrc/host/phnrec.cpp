@@ -3,6 +3,7 @@
 // (getopt.cpp:22-41: "-xVALUE" or "-x VALUE", bare words skipped) is restated below.
 // Additions (letters the reference does not use): -g, -b, -j, -F.
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,15 +64,19 @@ static int NextOpt(int argc, char **argv, const char *options, int &ind, const c
     return 1;
 }
 
+static SpeechRec *g_sr = nullptr;
+
 static void Die(const std::string &msg)
 {
     fprintf(stderr, "ERROR: %s", msg.c_str());
     if (msg.empty() || msg.back() != '\n') fputc('\n', stderr);
+    if (g_sr) g_sr->JoinWarmUp();         // never exit() under a thread that is still inside the HIP runtime
     exit(1);
 }
 
 int main(int argc, char **argv)
 {
+    const auto t_main = std::chrono::steady_clock::now();
     const char *config_dir = nullptr, *file_list = nullptr, *input_file = nullptr, *output_file = nullptr;
     const char *output_mlf = nullptr, *wpenalty = nullptr;
     bool live = false, verbose = false, gpu_fe = false, gpu_dec = false, split_f16 = false;
@@ -122,8 +127,12 @@ int main(int argc, char **argv)
     }
 
     SpeechRec SR;
+    g_sr = &SR;
     SR.SetVerbose(verbose);
     if (!config_dir) Die("Configuration directory is not set (-c)\n");
+    // a conversion through the posterior estimator will need the GPU: bring the HIP runtime up NOW, on a helper thread,
+    // while the configuration, the model files and the weights' re-packing are dealt with on this one
+    if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
     else if (gpu_dec) SR.SetBatchFrames(131072);     // the decoder is sequential per utterance: more of them per launch
@@ -132,6 +141,7 @@ int main(int argc, char **argv)
     SR.SetGpuDecoder(gpu_dec);
     SR.SetSplitF16(split_f16);
     if (!SR.Init(std::string(config_dir) + "/config")) Die(SR.LastError());
+    const double config_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count();
 
     if (wpenalty) {
         float v;
@@ -154,10 +164,22 @@ int main(int argc, char **argv)
 
     if (getenv("PHNREC_STATS")) {
         const RunStats &s = SR.Stats();
+        // setup_s: pool + GPU contexts (create_s of it: HIP start-up, model load, pack, upload); first_launch_s: the first
+        // launch call of the run (code-object load, cold clock) -- part of wall_s; main_s: since main() was entered
         fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f "
-                        "(front_end_s=%.3f setup_s=%.3f)\n",
+                        "(front_end_s=%.3f setup_s=%.3f create_s=%.3f first_launch_s=%.3f config_s=%.3f main_s=%.3f) "
+                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f) host_threads=%d\n",
                 s.files, s.frames, s.seconds, s.seconds > 0 ? s.frames / s.seconds : 0.0,
-                s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds);
+                s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds,
+                s.create_seconds, s.first_launch_seconds, config_s,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
+                s.cpu_stage1 + s.cpu_read + s.cpu_gather + s.cpu_stage3, s.cpu_stage1, s.cpu_read, s.cpu_gather, s.cpu_stage3,
+                s.host_threads);
     }
-    return 0;
+    // Every output file is closed by now.  Leave without tearing the HIP runtime down piece by piece (contexts, streams,
+    // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.
+    SR.JoinWarmUp();
+    fflush(stdout);
+    fflush(stderr);
+    _Exit(0);
 }

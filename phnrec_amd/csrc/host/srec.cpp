@@ -105,18 +105,36 @@ ThreadPool::~ThreadPool()
 void ThreadPool::Run()
 {
     for (;;) {
-        Task t;
+        Task t{nullptr, 0, 0, nullptr};
+        std::function<void()> bg;
         {
             std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [this] { return stop_ || !queue_.empty(); });
-            if (queue_.empty()) return;
-            t = queue_.front();
-            queue_.pop_front();
+            cv_.wait(l, [this] { return stop_ || !queue_.empty() || !background_.empty(); });
+            if (!queue_.empty()) {                        // a blocked caller's chunks come first
+                t = queue_.front();
+                queue_.pop_front();
+            } else if (!background_.empty()) {
+                bg = std::move(background_.front());
+                background_.pop_front();
+            } else {
+                return;
+            }
         }
+        if (bg) { bg(); continue; }
         for (int i = t.begin; i < t.end; i++) (*t.fn)(i);
         std::lock_guard<std::mutex> l(t.group->mu);
         if (--t.group->pending == 0) t.group->cv.notify_all();
     }
+}
+
+void ThreadPool::Submit(std::function<void()> fn)
+{
+    if (threads_.empty()) { fn(); return; }
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        background_.push_back(std::move(fn));
+    }
+    cv_.notify_one();
 }
 
 void ThreadPool::ParallelFor(int n, const std::function<void(int)> &fn)
@@ -283,64 +301,112 @@ bool SpeechRec::Init(const std::string &config_file)
     return true;
 }
 
-bool SpeechRec::EnsureGpus()
+static int FirstDevice()
 {
-    if (!gpus_.empty()) return true;
-    int n = n_gpus_;
-    if (n <= 0) n = 1;
-    // several contexts per GPU: while one's launch is in flight the others stage / decode / write
-    // (PHNREC_CTX_PER_GPU overrides the default for experiments)
-    int per_gpu = 2;
-    if (const char *e = getenv("PHNREC_CTX_PER_GPU")) per_gpu = std::max(1, std::min(8, atoi(e)));
-    // PHNREC_DEVICE_MAP="0,0": the physical device of each of the -g N logical GPUs (default: 0..N-1).  Lets a
-    // 1-GPU box run the -g 2 arrangement (4 contexts, one launch queue); on an 8-GPU node it picks the GPUs.
-    std::vector<int> dmap;
     if (const char *e = getenv("PHNREC_DEVICE_MAP")) {
-        for (const char *q = e; *q;) {
-            char *end = nullptr;
-            const long v = strtol(q, &end, 10);
-            if (end == q || v < 0) return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
-            dmap.push_back((int)v);
-            q = *end == ',' ? end + 1 : end;
-            if (*end && *end != ',') return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
-        }
-        if ((int)dmap.size() < n) return Fail("PHNREC_DEVICE_MAP names fewer devices than -g asks for\n");
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        if (end != e && v >= 0) return (int)v;
     }
-    for (int k = 0; k < per_gpu * n; k++) {
-        const int d = dmap.empty() ? k / per_gpu : dmap[k / per_gpu];
-        std::unique_ptr<Traps> t(new Traps);
-        t->SetSystem(C.GetString("posteriors", "system").c_str());
-        t->SetTrapLen(C.GetInt("posteriors", "length"));
-        t->SetHamming(C.GetBool("posteriors", "hamming"));
-        t->SetNBanks(nbanks_);
-        t->SetAddC0(C.GetBool("posteriors", "add_c0"));
-        t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
-        t->SetDevice(d);
-        // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
-        t->SetHiddenSplit(1);
-        if (!t->Init(config_dir_.c_str())) return Fail(t->LastError() + "\n");
-        if (split_f16_ && !t->SetArithmetic(LCRC_ARITH_SPLIT_F16)) return Fail(t->LastError() + "\n");
-        if (gpu_frontend_) {
-            if (wave_.noise_level != 0.0f) return Fail("source/noise_level needs the host front-end (libc rand()); drop -F\n");
-            lcrc_frontend fe;
-            fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
-            fe.sample_freq = C.GetInt("source", "sample_freq");
-            fe.vector_size = C.GetInt("melbanks", "vector_size");
-            fe.vector_step = C.GetInt("melbanks", "vector_step");
-            fe.nbanks_full = C.GetInt("melbanks", "nbanks_full");
-            fe.lower_freq = C.GetFloat("melbanks", "lower_freq");
-            fe.higher_freq = C.GetFloat("melbanks", "higher_freq");
-            fe.preem_coef = C.GetFloat("melbanks", "preem_coef");
-            fe.scale = wave_.scale;
-            fe.dc_shift = wave_.dc_shift;
-            fe.z_mean_source = C.GetBool("melbanks", "z_mean_source") ? 1 : 0;
-            fe.sent_mean_norm = sent_mean_norm_ ? 1 : 0;
-            if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
-                return Fail("framenorm/* needs the host front-end; drop -F\n");
-            if (!t->ConfigureFrontend(fe)) return Fail(t->LastError() + "\n");
-        }
-        gpus_.push_back(std::move(t));
+    return 0;
+}
+
+void SpeechRec::WarmUpGpuAsync()
+{
+    if (warmup_.joinable()) return;
+    const int dev = FirstDevice();
+    warmup_ = std::thread([dev] { (void)lcrc_device_warmup(dev); });    // failures surface in lcrc_create
+}
+
+SpeechRec::~SpeechRec()
+{
+    if (warmup_.joinable()) warmup_.join();
+}
+
+// One-off set-up of a context behind Init / InitClone: arithmetic, GPU front-end.  Returns "" or the error text
+// (called from one thread per GPU, so it does not touch err_).
+std::string SpeechRec::SetUpContext(Traps &t)
+{
+    if (split_f16_ && !t.SetArithmetic(LCRC_ARITH_SPLIT_F16)) return t.LastError() + "\n";
+    if (gpu_frontend_) {
+        if (wave_.noise_level != 0.0f) return "source/noise_level needs the host front-end (libc rand()); drop -F\n";
+        lcrc_frontend fe;
+        fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
+        fe.sample_freq = C.GetInt("source", "sample_freq");
+        fe.vector_size = C.GetInt("melbanks", "vector_size");
+        fe.vector_step = C.GetInt("melbanks", "vector_step");
+        fe.nbanks_full = C.GetInt("melbanks", "nbanks_full");
+        fe.lower_freq = C.GetFloat("melbanks", "lower_freq");
+        fe.higher_freq = C.GetFloat("melbanks", "higher_freq");
+        fe.preem_coef = C.GetFloat("melbanks", "preem_coef");
+        fe.scale = wave_.scale;
+        fe.dc_shift = wave_.dc_shift;
+        fe.z_mean_source = C.GetBool("melbanks", "z_mean_source") ? 1 : 0;
+        fe.sent_mean_norm = sent_mean_norm_ ? 1 : 0;
+        if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
+            return "framenorm/* needs the host front-end; drop -F\n";
+        if (!t.ConfigureFrontend(fe)) return t.LastError() + "\n";
     }
+    return std::string();
+}
+
+// Contexts: `per_gpu` on each of the -g N GPUs.  A list wants two per GPU (while one's launch is in flight the
+// other stages / decodes / writes); one file wants one.  The first context of a GPU loads the model (GPUs in
+// parallel: one thread each), further ones share its weights on the device (lcrc_clone: no file reads, no
+// packing, no upload).
+bool SpeechRec::EnsureGpus(int per_gpu)
+{
+    const int n = std::max(1, n_gpus_);
+    // (PHNREC_CTX_PER_GPU overrides the default for experiments)
+    if (const char *e = getenv("PHNREC_CTX_PER_GPU")) per_gpu = std::max(1, std::min(8, atoi(e)));
+    if (gpu_devices_.empty()) {
+        // PHNREC_DEVICE_MAP="0,0": the physical device of each of the -g N logical GPUs (default: 0..N-1).  Lets a
+        // 1-GPU box run the -g 2 arrangement (4 contexts, one launch queue); on an 8-GPU node it picks the GPUs.
+        std::vector<int> dmap;
+        if (const char *e = getenv("PHNREC_DEVICE_MAP")) {
+            for (const char *q = e; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q || v < 0 || (*end && *end != ','))
+                    return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
+                dmap.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+            }
+            if ((int)dmap.size() < n) return Fail("PHNREC_DEVICE_MAP names fewer devices than -g asks for\n");
+        }
+        for (int g = 0; g < n; g++) gpu_devices_.push_back(dmap.empty() ? g : dmap[g]);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = (int)gpus_.size() / n; k < per_gpu; k++) {
+        if (k > 0 && warmup_.joinable()) warmup_.join();
+        std::vector<std::unique_ptr<Traps>> made(n);
+        std::vector<std::string> errs(n);
+        auto make = [&](int g) {
+            std::unique_ptr<Traps> t(new Traps);
+            t->SetSystem(C.GetString("posteriors", "system").c_str());
+            t->SetTrapLen(C.GetInt("posteriors", "length"));
+            t->SetHamming(C.GetBool("posteriors", "hamming"));
+            t->SetNBanks(nbanks_);
+            t->SetAddC0(C.GetBool("posteriors", "add_c0"));
+            t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
+            t->SetDevice(gpu_devices_[g]);
+            // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
+            t->SetHiddenSplit(1);
+            if (!(k == 0 ? t->Init(config_dir_.c_str()) : t->InitClone(*gpus_[g]))) { errs[g] = t->LastError() + "\n"; return; }
+            errs[g] = SetUpContext(*t);
+            if (errs[g].empty()) made[g] = std::move(t);
+        };
+        if (n == 1) {
+            make(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int g = 0; g < n; g++) th.emplace_back(make, g);
+            for (auto &t : th) t.join();
+        }
+        for (int g = 0; g < n; g++) if (!made[g]) return Fail(errs[g]);
+        for (int g = 0; g < n; g++) gpus_.push_back(std::move(made[g]));
+    }
+    stats_.create_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
 }
 
@@ -513,13 +579,32 @@ bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job
     return true;
 }
 
-// File lists run as a two-stage pipeline over chunks of kChunkFiles files: while the GPU contexts and
-// the decoder / writers work on chunk c, the pool already reads (and, without -F, front-ends) the
-// files of chunk c + 1.  Outputs appear in list order; a failing file stops the run like the
-// reference's sequential loop does (files before it have been written).
-bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf)
+// A file list (or the one file of -i) runs as ONE pipeline from its first line to its last:
+//   feeder (the calling thread)  parses lines and queues stage 1 of each job on the pool: file read [+ host
+//                                front-end + sentence norm]; with -F only a stat() -- the files are then read
+//                                straight into the launching context's pinned byte buffer
+//   GPU workers (one thread per context, two contexts per GPU) each take the next launch -- the longest run of
+//                                consecutive staged jobs within batch_frames_ --, gather, run the kernel(s), and
+//                                decode / dump the launch's utterances on the pool (chunks of a blocked worker run
+//                                ahead of queued stage-1 tasks)
+//   writer (whoever finishes a job) MLF entries leave in list order.
+// Nothing joins the contexts before the end of the list; the window of jobs in flight is bounded by frames
+// (a few launches per context) and bytes, not by a file count.  Launch boundaries depend on timing only at the
+// very end of a list; results do not depend on them (the CLI pins the fused kernel: batch-invariant bits).
+// Errors keep the reference's sequential meaning (srec.cpp:1246-1290): a file that cannot be read or a bad list
+// line stops the run THERE -- everything before it is computed and written, then the error is reported.
+namespace {
+
+struct Slot {
+    int state = 0;          // 0: stage 1 pending, 1: staged (waits for a launch), 2: in a launch, 3: done
+};
+
+}  // namespace
+
+bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<int(Job &)> &next, FILE *mlf, bool single_file)
 {
-    const auto t0 = std::chrono::steady_clock::now();
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
     if (!pool_) {
         const int threads = host_threads_ > 0 ? host_threads_ : UsableCpus();
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
@@ -527,57 +612,17 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
-        if (!EnsureGpus()) return false;
+        if (!EnsureGpus(single_file ? 1 : 2)) return false;
     }
-    const auto t1 = std::chrono::steady_clock::now();
-    stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
-    const int n = (int)jobs.size();
-    for (const Job &j : jobs) Log(j.tgt.empty() ? j.src + "\n" : j.src + " -> " + j.tgt + "\n");
-
-    constexpr int kChunkFiles = 512;
-    std::atomic<long long> stage1_us(0);
-    auto stage1 = [&](int lo, int hi) {
-        const auto s0 = std::chrono::steady_clock::now();
-        pool_->ParallelFor(hi - lo, [&](int i) { Stage1(in, out, jobs[lo + i]); });
-        stage1_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - s0).count();
-    };
-    auto first_error = [&](int lo, int hi) -> const Job * {
-        for (int i = lo; i < hi; i++) if (!jobs[i].ok) return &jobs[i];
-        return nullptr;
-    };
-    auto stage23 = [&](int lo, int hi) -> bool {
-        if (!need_gpu) {
-            pool_->ParallelFor(hi - lo, [&](int i) {
-                Job &j = jobs[lo + i];
-                Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
-            });
-            return true;
-        }
-        // Consecutive utterances are packed into launches of <= batch_frames_ frames.  The GPU
-        // contexts pull launches from one queue (no exchange between GPUs: every context holds all
-        // weights).  Per launch: features are gathered straight into the context's pinned staging
-        // buffer, and the decoder / HTK writer read the posteriors straight out of it.
-        std::vector<std::pair<int, int>> batches;      // [first, last) job index
-        for (int i = lo; i < hi;) {
-            int j = i, frames = 0;
-            while (j < hi && (j == i || frames + jobs[j].frames <= batch_frames_)) frames += jobs[j++].frames;
-            batches.emplace_back(i, j);
-            i = j;
-        }
-        std::atomic<int> next(0);
-        std::atomic<bool> failed(false);
-        std::vector<std::string> errs(gpus_.size());
-        std::vector<double> kms(gpus_.size(), 0.0);
-        // posterior writer path: both softening functions and the dump's byte order run in the
-        // posterior kernel's epilogue; the host only decodes or writes
-        {
-            lcrc_softening st[2] = {DeviceSoftening(post_soft_, post_soft_arg_), DeviceSoftening(dec_soft_, dec_soft_arg_)};
-            for (auto &g : gpus_)
-                if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
-        }
+    const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
+    std::vector<std::string> phn_names;
+    if (need_gpu) {
+        // posterior writer path: both softening functions and the dump's byte order run in the posterior
+        // kernel's epilogue; the host only decodes or writes
+        lcrc_softening st[2] = {DeviceSoftening(post_soft_, post_soft_arg_), DeviceSoftening(dec_soft_, dec_soft_arg_)};
+        for (auto &g : gpus_)
+            if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
         // -D: the decoder runs behind the posterior kernel and only labels cross PCIe
-        const bool dev_dec = gpu_decoder_ && out == dfStrings;
-        std::vector<std::string> phn_names;
         if (dev_dec) {
             PhnDec names;
             if (!names.LoadPhnList(phoneme_list_)) return Fail("Can not open the phoneme list: " + phoneme_list_ + "\n");
@@ -586,136 +631,283 @@ bool SpeechRec::RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, F
         for (auto &g : gpus_)
             if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
                 return Fail(g->LastError() + "\n");
-        auto device_labels = [&](Traps &tr, int first, int cnt) -> bool {
+    }
+    const auto t1 = clock::now();
+    stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
+
+    struct Item { Job job; Slot slot; };
+    std::mutex mu;
+    std::condition_variable cv_feed, cv_work, cv_idle;
+    std::deque<std::unique_ptr<Item>> win;     // jobs in flight, list order; win.front() has sequence number `base`
+    long long base = 0, next_launch = 0;       // next_launch: first job no launch has taken yet
+    int pending1 = 0;                          // stage-1 tasks queued or running
+    long long staged_frames = 0, staged_bytes = 0;   // staged, not yet taken by a launch
+    bool eof = false, feeder_blocked = false;
+    long long stop_seq = -1;                   // first job whose stage 1 failed: nothing at or behind it is launched
+    std::string fatal;                         // GPU / output error: the run ends
+    long long files_done = 0, frames_done = 0;
+    // CPU time the host stages take, summed over the threads that run them (what the cores must deliver however
+    // fast the GPUs are: PHNREC_STATS prints it, bench.py derives the host ceiling of a list from it)
+    std::atomic<long long> stage1_us(0), read_us(0), gather_us(0), stage3_us(0);
+    struct CpuTimer {
+        std::atomic<long long> &acc;
+        clock::time_point t0;
+        explicit CpuTimer(std::atomic<long long> &a) : acc(a), t0(clock::now()) {}
+        ~CpuTimer() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count(); }
+    };
+    std::atomic<bool> first_launch(true);
+    const int n_ctx = need_gpu ? (int)gpus_.size() : 0;
+    const int max_pending = std::max(8, 4 * std::max(1, pool_->Size()));
+    const long long max_staged_frames = (long long)batch_frames_ * (n_ctx + 2);
+    const long long max_staged_bytes = 2LL << 30;
+    const size_t max_window = 1 << 16;
+
+    // in-order output; call with `mu` held
+    auto drain = [&]() {
+        while (!win.empty() && win.front()->slot.state == 3 && fatal.empty()) {
+            Job &j = win.front()->job;
+            if (!j.ok) { fatal = j.err; break; }
+            if (mlf) fputs(j.labels.c_str(), mlf);
+            files_done++;
+            frames_done += j.frames;
+            win.pop_front();
+            base++;
+        }
+        cv_feed.notify_all();
+        cv_idle.notify_all();
+    };
+
+    auto job_bytes = [](const Job &j) { return (long long)((j.mel.size() + j.post.size()) * sizeof(float)); };
+    auto stage1_task = [&](Item *it) {
+        {
+            CpuTimer tm(stage1_us);
+            Stage1(in, out, it->job);
+        }
+        std::lock_guard<std::mutex> l(mu);
+        pending1--;
+        it->slot.state = 1;
+        staged_frames += it->job.frames;
+        staged_bytes += job_bytes(it->job);
+        cv_work.notify_all();
+        cv_feed.notify_all();
+        cv_idle.notify_all();
+    };
+
+    // The next launch: the longest run of consecutive staged jobs from next_launch within batch_frames_ (at least
+    // one job).  Blocks until that run is closed -- full, at the end of the list, or in front of a failed job.
+    // false: there will be no more launches.
+    auto take_launch = [&](std::vector<Item *> &items) -> bool {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            if (!fatal.empty()) return false;
+            items.clear();
+            long long frames = 0, bytes = 0;
+            bool closed = false, final = false;     // final: no job will ever follow this run
+            for (long long q = next_launch;; q++) {
+                if (stop_seq >= 0 && q >= stop_seq) { closed = final = true; break; }
+                // (a feeder that waits for room while nothing is being staged will not extend this run)
+                if (q - base >= (long long)win.size()) { final = eof; closed = eof || feeder_blocked; break; }
+                Item *it = win[(size_t)(q - base)].get();
+                if (it->slot.state == 0) break;
+                if (!it->job.ok) { stop_seq = q; closed = final = true; cv_feed.notify_all(); break; }
+                if (!items.empty() && frames + it->job.frames > batch_frames_) { closed = true; break; }
+                items.push_back(it);
+                frames += it->job.frames;
+                bytes += job_bytes(it->job);
+                if (frames >= batch_frames_ || bytes >= max_staged_bytes) { closed = true; break; }
+            }
+            if (items.empty() && final) return false;
+            if (closed && !items.empty()) {
+                for (Item *it : items) {
+                    it->slot.state = 2;
+                    staged_frames -= it->job.frames;
+                    staged_bytes -= job_bytes(it->job);
+                }
+                next_launch += (long long)items.size();
+                cv_feed.notify_all();
+                return true;
+            }
+            cv_work.wait(l);
+        }
+    };
+
+    std::vector<double> kms((size_t)n_ctx, 0.0);
+    // conversions that do not touch the GPU (-t par, -s post) take the same road -- runs of consecutive staged jobs --
+    // so that nothing BEHIND a file that cannot be read is ever written
+    auto host_worker = [&]() {
+        std::vector<Item *> items;
+        while (take_launch(items)) {
+            pool_->ParallelFor((int)items.size(), [&](int k) {
+                CpuTimer tm(stage3_us);
+                Job &j = items[k]->job;
+                Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
+                std::vector<float>().swap(j.mel);
+                std::vector<float>().swap(j.post);
+            });
+            std::lock_guard<std::mutex> l(mu);
+            for (Item *it : items) it->slot.state = 3;
+            drain();
+        }
+    };
+    auto worker = [&](int g) {
+        Traps &tr = *gpus_[g];
+        std::vector<Item *> items;
+        std::vector<int> off;
+        auto abort_run = [&](const std::string &msg) {
+            std::lock_guard<std::mutex> l(mu);
+            if (fatal.empty()) fatal = msg + "\n";
+            cv_work.notify_all(); cv_feed.notify_all(); cv_idle.notify_all();
+        };
+        auto device_labels = [&](int cnt) -> bool {
             const lcrc_label *lab; const int *lfirst, *lcount; int nu = 0;
             if (!tr.LastLabels(&lab, &lfirst, &lcount, &nu) || nu != cnt) return false;
             pool_->ParallelFor(cnt, [&](int k) {
-                Job &j = jobs[first + k];
+                CpuTimer tm(stage3_us);
                 std::vector<Label> v((size_t)lcount[k]);
                 for (int i = 0; i < lcount[k]; i++) {
-                    const lcrc_label &l = lab[lfirst[k] + i];
-                    v[i] = Label{l.start, l.end, phn_names[l.phn], l.score};
+                    const lcrc_label &lb = lab[lfirst[k] + i];
+                    v[i] = Label{lb.start, lb.end, phn_names[lb.phn], lb.score};
                 }
-                EmitLabels(j, mlf != nullptr, v);
+                EmitLabels(items[k]->job, mlf != nullptr, v);
             });
             return true;
         };
-        auto worker = [&](int g) {
-            Traps &tr = *gpus_[g];
-            std::vector<int> off;
-            for (int b; (b = next.fetch_add(1)) < (int)batches.size() && !failed;) {
-                const int first = batches[b].first, cnt = batches[b].second - first;
-                off.assign(1, 0);
-                for (int k = 0; k < cnt; k++) off.push_back(off.back() + jobs[first + k].frames);
-                if (gpu_frontend_ && in == dfWaveform) {
-                    // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the
-                    // three nets all run on the device
-                    // the files go straight into the context's pinned byte buffer (copied in parallel)
-                    std::vector<long long> bstart(cnt), blen(cnt);
-                    long long pos = 0;
-                    for (int k = 0; k < cnt; k++) {
-                        bstart[k] = pos;
-                        blen[k] = jobs[first + k].file_bytes;
-                        pos += blen[k] + (blen[k] & 1);
-                    }
-                    unsigned char *pinned = nullptr;
-                    if (!tr.WaveStageBuffer(pos, &pinned)) { errs[g] = tr.LastError(); failed = true; return; }
-                    std::atomic<int> bad(-1);
-                    pool_->ParallelFor(cnt, [&](int k) {          // files -> pinned memory, in parallel
-                        Job &j = jobs[first + k];
-                        FILE *f = fopen(j.src.c_str(), "rb");
-                        const bool ok = f && (blen[k] == 0 || fread(pinned + bstart[k], 1, (size_t)blen[k], f) == (size_t)blen[k]);
-                        if (f) fclose(f);
-                        if (!ok) { int e = -1; bad.compare_exchange_strong(e, k); }
-                    });
-                    if (bad >= 0) {
-                        errs[g] = "Can not open waveform file: " + jobs[first + bad].src; failed = true; return;
-                    }
-                    std::vector<int> foff(cnt + 1);      // posteriors stay in the context's pinned output buffer
-                    if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) {
-                        errs[g] = tr.LastError(); failed = true; return;
-                    }
-                    if (off.back() > 0) kms[g] += tr.LastKernelMs();
-                    if (dev_dec) {
-                        if (off.back() > 0 && !device_labels(tr, first, cnt)) { errs[g] = "device decoder returned no labels"; failed = true; return; }
-                        if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(jobs[first + k], mlf != nullptr, {}); });
-                        continue;
-                    }
-                    float *hp = const_cast<float *>(tr.StagedPosteriors());
-                    pool_->ParallelFor(cnt, [&](int k) {
-                        Job &j = jobs[first + k];
-                        float *pp = hp + (size_t)foff[k] * n_out_;
-                        j.cols = n_out_;
-                        Stage3(out, j, mlf != nullptr, pp, n_out_, true);
-                    });
-                    continue;
+        while (take_launch(items)) {
+            const int cnt = (int)items.size();
+            off.assign(1, 0);
+            for (int k = 0; k < cnt; k++) off.push_back(off.back() + items[k]->job.frames);
+            const auto l0 = clock::now();
+            const float *h_post = nullptr;
+            std::vector<int> foff;
+            if (gpu_frontend_ && in == dfWaveform) {
+                // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the three nets all run
+                // on the device; the files go straight into the context's pinned byte buffer (read in parallel)
+                std::vector<long long> bstart(cnt), blen(cnt);
+                long long pos = 0;
+                for (int k = 0; k < cnt; k++) {
+                    bstart[k] = pos;
+                    blen[k] = items[k]->job.file_bytes;
+                    pos += blen[k] + (blen[k] & 1);
                 }
-                float *h_mel = nullptr, *h_post = nullptr;
-                if (!tr.StageBuffers(off.back(), &h_mel, &h_post)) { errs[g] = tr.LastError(); failed = true; return; }
+                unsigned char *pinned = nullptr;
+                if (!tr.WaveStageBuffer(pos, &pinned)) { abort_run(tr.LastError()); return; }
+                std::atomic<int> bad(-1);
                 pool_->ParallelFor(cnt, [&](int k) {
-                    Job &j = jobs[first + k];
+                    CpuTimer tm(read_us);
+                    FILE *f = fopen(items[k]->job.src.c_str(), "rb");
+                    const bool ok = f && (blen[k] == 0 || fread(pinned + bstart[k], 1, (size_t)blen[k], f) == (size_t)blen[k]);
+                    if (f) fclose(f);
+                    if (!ok) { int e = -1; bad.compare_exchange_strong(e, k); }
+                });
+                if (bad >= 0) { abort_run("Can not open waveform file: " + items[bad]->job.src); return; }
+                foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
+                if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                h_post = tr.StagedPosteriors();
+            } else {
+                float *h_mel = nullptr, *hp = nullptr;
+                if (!tr.StageBuffers(off.back(), &h_mel, &hp)) { abort_run(tr.LastError()); return; }
+                pool_->ParallelFor(cnt, [&](int k) {
+                    CpuTimer tm(gather_us);
+                    Job &j = items[k]->job;
                     memcpy(h_mel + (size_t)off[k] * nbanks_, j.mel.data(), j.mel.size() * sizeof(float));
                     std::vector<float>().swap(j.mel);
                 });
-                if (!tr.StageRun(off.data(), cnt)) { errs[g] = tr.LastError(); failed = true; return; }
-                if (off.back() > 0) kms[g] += tr.LastKernelMs();
-                if (dev_dec) {
-                    if (off.back() > 0 && !device_labels(tr, first, cnt)) { errs[g] = "device decoder returned no labels"; failed = true; return; }
-                    if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(jobs[first + k], mlf != nullptr, {}); });
-                    continue;
-                }
+                if (!tr.StageRun(off.data(), cnt)) { abort_run(tr.LastError()); return; }
+                foff = off;
+                h_post = hp;
+            }
+            if (first_launch.exchange(false))
+                stats_.first_launch_seconds = std::chrono::duration<double>(clock::now() - l0).count();
+            if (off.back() > 0) kms[g] += tr.LastKernelMs();
+            if (dev_dec) {
+                if (off.back() > 0 && !device_labels(cnt)) { abort_run("device decoder returned no labels"); return; }
+                if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(items[k]->job, mlf != nullptr, {}); });
+            } else {
                 pool_->ParallelFor(cnt, [&](int k) {
-                    Job &j = jobs[first + k];
-                    float *post = h_post + (size_t)off[k] * n_out_;
+                    CpuTimer tm(stage3_us);
+                    Job &j = items[k]->job;
                     j.cols = n_out_;
-                    Stage3(out, j, mlf != nullptr, post, n_out_, true);
+                    Stage3(out, j, mlf != nullptr, const_cast<float *>(h_post) + (size_t)foff[k] * n_out_, n_out_, true);
                 });
             }
-        };
-        std::vector<std::thread> gt;
-        for (size_t g = 0; g < gpus_.size(); g++) gt.emplace_back(worker, (int)g);
-        for (auto &t : gt) t.join();
-        for (size_t g = 0; g < gpus_.size(); g++) {
-            if (!errs[g].empty()) return Fail(errs[g] + "\n");
-            stats_.gpu_kernel_ms += kms[g];
+            std::lock_guard<std::mutex> l(mu);
+            for (Item *it : items) it->slot.state = 3;
+            drain();
         }
-        for (int i = lo; i < hi; i++) stats_.frames += jobs[i].frames;
-        return true;
     };
 
-    bool ok = true;
-    stage1(0, std::min(n, kChunkFiles));
-    for (int lo = 0; lo < n && ok; lo += kChunkFiles) {
-        const int hi = std::min(n, lo + kChunkFiles), nhi = std::min(n, hi + kChunkFiles);
-        // A file that cannot be read stops the run where the reference's sequential loop stops
-        // (srec.cpp:1280-1284): everything BEFORE it is still computed and written, then the error is reported.
-        const Job *bad = first_error(lo, hi);
-        const int stop = bad ? (int)(bad - jobs.data()) : hi;
-        std::thread ahead;
-        if (!bad && hi < n) ahead = std::thread([&, hi, nhi] { stage1(hi, nhi); });
-        if (stop > lo) ok = stage23(lo, stop);
-        if (ahead.joinable()) ahead.join();
-        if (!ok) break;
-        for (int i = lo; i < stop; i++) {
-            Job &j = jobs[i];
-            if (!j.ok) { ok = Fail(j.err); break; }
-            if (mlf) fputs(j.labels.c_str(), mlf);
-            j = Job();                               // results are out: release the buffers
+    std::vector<std::thread> workers;
+    for (int g = 0; g < n_ctx; g++) workers.emplace_back(worker, g);
+    if (!need_gpu) for (int k = 0; k < 2; k++) workers.emplace_back(host_worker);
+
+    // ---- feeder ----
+    std::string parse_err;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> l(mu);
+            for (;;) {
+                if (!fatal.empty() || stop_seq >= 0) break;
+                const bool room = win.size() < max_window && staged_frames < max_staged_frames && staged_bytes < max_staged_bytes;
+                if (room && pending1 < max_pending) break;
+                if (!room && pending1 == 0 && !feeder_blocked) {      // what is staged now is all a launch can get
+                    feeder_blocked = true;
+                    cv_work.notify_all();
+                }
+                cv_feed.wait(l);
+            }
+            feeder_blocked = false;
+            if (!fatal.empty() || stop_seq >= 0) break;
         }
-        if (ok && bad) ok = Fail(bad->err);
+        std::unique_ptr<Item> it(new Item);
+        const int r = next(it->job);
+        if (r < 0) parse_err = err_;
+        if (r <= 0) break;
+        Log(it->job.tgt.empty() ? it->job.src + "\n" : it->job.src + " -> " + it->job.tgt + "\n");
+        Item *raw = it.get();
+        {
+            std::lock_guard<std::mutex> l(mu);
+            win.push_back(std::move(it));
+            pending1++;
+        }
+        pool_->Submit([&stage1_task, raw] { stage1_task(raw); });
     }
-    stats_.stage1_seconds += stage1_us.load() * 1e-6;
-    if (!ok) return false;
-    stats_.files += n;
-    stats_.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    {
+        std::unique_lock<std::mutex> l(mu);
+        eof = true;
+        cv_work.notify_all();
+    }
+    for (auto &t : workers) t.join();
+    {
+        // every queued stage-1 task must have ended before the window goes out of scope
+        std::unique_lock<std::mutex> l(mu);
+        cv_idle.wait(l, [&] { return pending1 == 0; });
+    }
+    stats_.stage1_seconds += stage1_us.load() * 1e-9 / std::max(1, pool_->Size());
+    stats_.cpu_stage1 += stage1_us.load() * 1e-9;
+    stats_.cpu_read += read_us.load() * 1e-9;
+    stats_.cpu_gather += gather_us.load() * 1e-9;
+    stats_.cpu_stage3 += stage3_us.load() * 1e-9;
+    stats_.host_threads = std::max(1, pool_->Size());
+    for (double k : kms) stats_.gpu_kernel_ms += k;
+    stats_.files += files_done;
+    stats_.frames += frames_done;
+    stats_.seconds += std::chrono::duration<double>(clock::now() - t1).count();
+    if (!fatal.empty()) return Fail(fatal);
+    // a job whose stage 1 failed: everything before it has been written
+    for (auto &it : win)
+        if (!it->job.ok) return Fail(it->job.err);
+    if (!parse_err.empty()) return Fail(parse_err);
     return true;
 }
 
 bool SpeechRec::ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line)
 {
-    std::vector<Job> jobs(1);
-    if (!ParseLine(line, out, false, jobs[0])) return false;
-    return RunJobs(in, out, jobs, nullptr);
+    bool given = false;
+    return RunPipeline(in, out, [&](Job &j) -> int {
+        if (given) return 0;
+        given = true;
+        return ParseLine(line, out, false, j) ? 1 : -1;
+    }, nullptr, true);
 }
 
 bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf_path)
@@ -728,23 +920,12 @@ bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string
         if (!mlf) { fclose(fl); return Fail("Can not create the MLF: " + mlf_path + "\n"); }
         fprintf(mlf, "#!MLF!#\n");
     }
-    const size_t kChunk = 1024;                       // utterances in flight (bounds host memory)
     char buf[1024];
-    bool ok = true, eof = false;
-    std::string parse_err;
-    while (ok && !eof && parse_err.empty()) {
-        std::vector<Job> jobs;
-        while (jobs.size() < kChunk) {
-            if (!fgets(buf, 1023, fl)) { eof = true; break; }
-            Job j;
-            // an invalid line stops the list there; the lines before it are processed first (srec.cpp:1246-1290
-            // works line by line)
-            if (!ParseLine(buf, out, mlf != nullptr, j)) { parse_err = LastError(); break; }
-            jobs.push_back(std::move(j));
-        }
-        if (!jobs.empty()) ok = RunJobs(in, out, jobs, mlf);
-    }
-    if (ok && !parse_err.empty()) ok = Fail(parse_err);
+    // an invalid line stops the list there; the lines before it are processed first (srec.cpp:1246-1290 works line by line)
+    const bool ok = RunPipeline(in, out, [&](Job &j) -> int {
+        if (!fgets(buf, 1023, fl)) return 0;
+        return ParseLine(buf, out, mlf != nullptr, j) ? 1 : -1;
+    }, mlf, false);
     if (mlf) fclose(mlf);
     fclose(fl);
     return ok;

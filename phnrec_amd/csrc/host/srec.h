@@ -4,10 +4,11 @@
 // The par -> post step is the GPU path (class Traps over include/lcrc.h); everything else
 // here is host plumbing kept byte-compatible with the reference's files and messages.
 //
-// What is different by design: utterances are independent, so a file list is processed in
-// chunks -- front-end and Viterbi on a host thread pool, posteriors in multi-utterance
-// launches spread over all selected GPUs (no exchange between GPUs; outputs are written in
-// list order).  Live audio (-a) and the STK decoder are outside this path's scope.
+// What is different by design: utterances are independent, so a file list runs as ONE pipeline
+// from its first line to its last -- read-ahead / front-end on a host thread pool, posteriors in
+// multi-utterance launches that all GPU contexts pull from one queue (no exchange between GPUs),
+// Viterbi / dump writing behind each launch, outputs in list order.  Nothing joins the GPUs
+// before the end of the list.  Live audio (-a) and the STK decoder are outside this path's scope.
 #ifndef PHNREC_HOST_SREC_H
 #define PHNREC_HOST_SREC_H
 
@@ -35,10 +36,18 @@ struct RunStats {
     long long frames = 0, files = 0;
     double seconds = 0, gpu_kernel_ms = 0;      // seconds: processing without one-off GPU/pool set-up
     double init_seconds = 0, stage1_seconds = 0;
+    double create_seconds = 0;                  // of init_seconds: creating the GPU contexts (HIP start-up, model load, upload)
+    double first_launch_seconds = 0;            // wall time of the run's first launch call (code-object load, cold clock)
+    // CPU seconds of the host stages, summed over threads: stage 1 (file read [+ front-end]; stat() with -F), file reads
+    // into pinned memory (-F), gather into pinned memory, stage 3 (Viterbi / label formatting / dump writing)
+    double cpu_stage1 = 0, cpu_read = 0, cpu_gather = 0, cpu_stage3 = 0;
+    int host_threads = 1;
 };
 
-// Persistent worker pool; ParallelFor may be called from several threads at once (each GPU
-// worker farms its gather / decode loops out to the same pool).
+// Persistent worker pool.  ParallelFor (blocking, data-parallel) may be called from several threads at
+// once: each GPU worker farms its gather / decode loops out to the same pool, and those chunks run
+// BEFORE anything queued with Submit (asynchronous read-ahead tasks), so a launch that is ready never
+// waits behind the front-end of files that are not needed yet.
 int UsableCpus();   // affinity mask capped by the cgroup CPU quota
 
 class ThreadPool {
@@ -46,13 +55,15 @@ public:
     explicit ThreadPool(int n);
     ~ThreadPool();
     void ParallelFor(int n, const std::function<void(int)> &fn);
+    void Submit(std::function<void()> fn);                  // runs inline when the pool has no threads
     int Size() const { return (int)threads_.size(); }
 
 private:
     struct Task { const std::function<void(int)> *fn; int begin, end; struct Group *group; };
     void Run();
     std::vector<std::thread> threads_;
-    std::deque<Task> queue_;
+    std::deque<Task> queue_;                       // ParallelFor chunks: served first
+    std::deque<std::function<void()>> background_;  // Submit tasks
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false;
@@ -70,6 +81,11 @@ public:
     void SetGpuDecoder(bool v) { gpu_decoder_ = v; }     // -D: PhnDec on the GPU, posteriors never leave it
     void SetSplitF16(bool v) { split_f16_ = v; }         // -H: lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16)
     void SetGpuFrontend(bool v) { gpu_frontend_ = v; }   // -F: waveform -> posteriors without the host front-end
+    // Starts the HIP runtime and the first GPU's context on a helper thread (lcrc_device_warmup): ~0.2 s that then overlap
+    // with Init(), the model files and their re-packing.  Call it as early as the conversion is known to need the GPU.
+    void WarmUpGpuAsync();
+    void JoinWarmUp() { if (warmup_.joinable()) warmup_.join(); }
+    ~SpeechRec();
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
     bool ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf);
@@ -90,13 +106,15 @@ private:
         std::string err;
     };
     bool ParseLine(const std::string &line, DataFormat out, bool mlf, Job &job);
-    bool RunJobs(DataFormat in, DataFormat out, std::vector<Job> &jobs, FILE *mlf);
+    // next(job): 1 = a job, 0 = end of the list, -1 = invalid line (LastError() says which)
+    bool RunPipeline(DataFormat in, DataFormat out, const std::function<int(Job &)> &next, FILE *mlf, bool single_file);
     void Stage1(DataFormat in, DataFormat out, Job &job);              // load [+ front-end] [+ sentence norm]
     // soft funcs, decode / dump; `post` = job.frames x cols posteriors (writable)
     // device_done: softening (and, for dumps, the big-endian byte order) already applied by the GPU
     void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done = false);
     void EmitLabels(Job &job, bool mlf, const std::vector<Label> &labels);
-    bool EnsureGpus();
+    bool EnsureGpus(int contexts_per_gpu);
+    std::string SetUpContext(Traps &t);
     void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
     bool Fail(const std::string &msg) { err_ = msg; return false; }
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
@@ -112,8 +130,10 @@ private:
     float post_soft_arg_[3] = {0, 0, 0}, dec_soft_arg_[3] = {0, 0, 0};
     std::vector<std::string> phonemes_path_;
     std::string phoneme_list_;
-    std::vector<std::unique_ptr<Traps>> gpus_;        // two contexts per GPU (alternating launches)
+    std::vector<std::unique_ptr<Traps>> gpus_;        // [context k of GPU g] at k * n_gpus + g
+    std::vector<int> gpu_devices_;                    // physical device of each logical GPU (PHNREC_DEVICE_MAP)
     std::unique_ptr<ThreadPool> pool_;
+    std::thread warmup_;
     RunStats stats_;
     MelBanks mb_proto_;
 };

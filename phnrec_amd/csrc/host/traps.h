@@ -37,6 +37,14 @@ public:
         lcrc_set_hidden_split(ctx_, hidden_split_);
         return true;
     }
+    // a second context over `src`'s model on the same GPU (lcrc_clone): shares its weights on the device
+    bool InitClone(const Traps &src)
+    {
+        if (ctx_) { lcrc_destroy(ctx_); ctx_ = nullptr; }
+        if (lcrc_clone(&ctx_, src.ctx_) != LCRC_OK) { err_ = lcrc_last_error(nullptr); ctx_ = nullptr; return false; }
+        lcrc_set_hidden_split(ctx_, hidden_split_);
+        return true;
+    }
     void Reset() { lcrc_reset(ctx_); }
     void CalcFeaturesBunched(float *band_energies, float *features, int n = 1, bool neededFea = true)
     {

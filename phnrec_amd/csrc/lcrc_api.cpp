@@ -12,11 +12,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "frontend_dev.h"
@@ -28,13 +32,38 @@ using namespace phnrec;
 
 enum { SYS_LCRC = 0, SYS_1BT_DCT = 1, SYS_1BT = 2, SYS_3BT = 3 };
 
+// split-f16 operand images of one net (pack_net_h2)
+struct H2Images {
+    const float4 *w1h = nullptr, *w2h = nullptr;
+    const float *b1h = nullptr, *b2h = nullptr;
+    float sig_descale = 1.f, out_descale = 1.f;
+};
+
+// What the contexts of one model on one GPU share (lcrc_clone): the read-only device buffers -- packed weights,
+// biases, normalisation vectors, tables -- and the host copy of the nets the split-f16 operand images are packed
+// from on first request.  Freed with the last context.
+struct SharedModel {
+    int device = 0;
+    std::vector<void *> allocs;
+    HostNet host[3];
+    std::mutex mu;                       // guards the lazily built split-f16 images
+    int h2_state = 0;                    // 0: not built, 1: built, -1: the model has no such form
+    H2Images h2[3];
+    ~SharedModel()
+    {
+        if (allocs.empty()) return;
+        (void)hipSetDevice(device);
+        for (void *p : allocs) (void)hipFree(p);
+    }
+};
+
 struct lcrc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int nbanks = 0;
-    HostNet host[3];
+    std::shared_ptr<SharedModel> model;
     NetDev nets[3];
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;          // this context's own device buffers (split scratch)
     float *d_win = nullptr, *d_costab = nullptr;
     float normc = 0.f;
     // the other posteriors/system variants ("next" row f4): nets[2] is the merger in every system
@@ -71,7 +100,7 @@ struct lcrc_ctx {
     float *d_means = nullptr, *d_mean_part = nullptr;
     size_t cap_bytes = 0, cap_fe_utts = 0, cap_mean_blocks = 0;
     int mean_blocks = 0;                 // blocks of the last staged batch (tree mean)
-    bool mean_sequential = false;        // lcrc_set_mean_order
+    bool mean_sequential = true;         // lcrc_set_mean_order: the reference's order unless the caller opts out
     // streaming state (lcrc_push): the pushed frames live in a pinned, device-mapped strip whose last 30 rows
     // are the history (Traps::be_mat minus its newest slot); the kernel reads the strip and writes the
     // posteriors of a push in place (zero-copy), so a push costs no allocation and no copy command
@@ -84,6 +113,7 @@ struct lcrc_ctx {
     float4 *d_part = nullptr, *d_gimg = nullptr;
     unsigned *d_cnt = nullptr;
     int split_hint = 0;
+    bool split_scratch_failed = false;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = true, timed = false;
@@ -111,6 +141,20 @@ namespace {
 
 thread_local std::string g_create_err = "";
 
+// LCRC_TRACE_STARTUP=1: where a context's creation spends its time, one line per phase on stderr (diagnostic)
+struct StartupTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    StartupTrace() : on(getenv("LCRC_TRACE_STARTUP") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "lcrc startup: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 int fail(lcrc_ctx *c, int code, const std::string &msg)
 {
     if (c) c->err = msg; else g_create_err = msg;
@@ -130,23 +174,41 @@ hipError_t dev_upload(lcrc_ctx *c, const std::vector<T> &h, const T **out)
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, h.size() * sizeof(T));
     if (e != hipSuccess) return e;
-    c->allocs.push_back(d);
+    c->model->allocs.push_back(d);
     e = hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     *out = static_cast<const T *>(d);
     return e;
 }
 
-// Split-f16 form of a net (mlp_dev.h HalfLoop): every weight as a (high, low) f16 pair, high = f16(w), low =
-// f16(w - high), in the A-fragment order of v_mfma_f32_16x16x32_f16 (lane l: row l&15, k-slots 8(l>>4) .. +7):
+// Split-f16 form of a net (mlp_dev.h HalfLoop): every weight as a (high, low) f16 pair, high = f16(w'), low =
+// f16(w' - high), w' = w * 2^e, in the A-fragment order of v_mfma_f32_16x16x32_f16 (lane l: row l&15, k-slots 8(l>>4) .. +7):
 //   w1h[(((P*ns + s)*2 + T)*2 + piece)*64 + l][j] = W1[32P + 16T + (l&15)][32s + 8(l>>4) + j]
 //   w2h[((P*n_ot + ot)*2 + piece)*64 + l][j]      = W2[16ot + (l&15)][32P + (j < 4 ? 4(l>>4) + j : 16 + 4(l>>4) + j - 4)]
-// (layer 2's k-slots follow the accumulator layout of the pair's two layer-1 tiles).  A model with a weight
-// beyond f16's range has no such form: w1h stays NULL and lcrc_set_arithmetic refuses.
-int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
+// (layer 2's k-slots follow the accumulator layout of the pair's two layer-1 tiles).
+// The exponent e of a matrix puts its largest weight in (2^13, 2^14]: the low half of a value below 2^-3 would be an
+// f16 subnormal (2^-25 absolute instead of 2^-22 relative -- a model with weights of 1e-3 would lose ten bits), and
+// a weight beyond f16's range comes back into it.  The biases are stored in the accumulators' scale; the kernels undo
+// the scaling exactly (powers of two).  A non-finite weight has no such form.
+int h2_exponent(const std::vector<float> &w, bool *finite)
 {
-    d.w1h = d.w2h = nullptr;
-    for (float w : h.w1) if (!(fabsf(w) <= 65504.0f)) return LCRC_OK;
-    for (float w : h.w2) if (!(fabsf(w) <= 65504.0f)) return LCRC_OK;
+    float m = 0.f;
+    for (float v : w) {
+        if (!std::isfinite(v)) { *finite = false; return 0; }
+        m = std::max(m, fabsf(v));
+    }
+    if (m == 0.f) return 0;
+    int ex = 0;
+    (void)frexpf(m, &ex);                        // m = f * 2^ex, f in [0.5, 1)
+    return std::max(-60, std::min(60, 14 - ex));  // m * 2^e in [2^13, 2^14)
+}
+
+int pack_net_h2(lcrc_ctx *c, const HostNet &h, const NetDev &d, H2Images &out, bool *representable)
+{
+    *representable = true;
+    const int e1 = h2_exponent(h.w1, representable), e2 = h2_exponent(h.w2, representable);
+    if (!*representable) return LCRC_OK;
+    const int ns = (h.n_inp + 31) / 32;
+    const float s1 = ldexpf(1.0f, e1), s2 = ldexpf(1.0f, e2);
     std::vector<_Float16> w1h((size_t)d.npairs * ns * 2 * 2 * 64 * 8, (_Float16)0.0f);
     std::vector<_Float16> w2h((size_t)d.npairs * d.n_ot * 2 * 64 * 8, (_Float16)0.0f);
     auto put = [](std::vector<_Float16> &a, size_t frag, int l, int j, float w) {
@@ -161,7 +223,7 @@ int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
                     for (int j = 0; j < 8; j++) {
                         const int hh = 32 * P + 16 * T + (l & 15), k = 32 * s + 8 * (l >> 4) + j;
                         if (hh < h.n_hid && k < h.n_inp)
-                            put(w1h, (((size_t)P * ns + s) * 2 + T) * 2, l, j, h.w1[(size_t)hh * h.n_inp + k]);
+                            put(w1h, (((size_t)P * ns + s) * 2 + T) * 2, l, j, h.w1[(size_t)hh * h.n_inp + k] * s1);
                     }
     for (int P = 0; P < d.npairs; P++)
         for (int ot = 0; ot < d.n_ot; ot++)
@@ -170,11 +232,47 @@ int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
                     const int g = l >> 4, o = 16 * ot + (l & 15);
                     const int hh = 32 * P + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4);
                     if (o < h.n_out && hh < h.n_hid)
-                        put(w2h, ((size_t)P * d.n_ot + ot) * 2, l, j, h.w2[(size_t)o * h.n_hid + hh]);
+                        put(w2h, ((size_t)P * d.n_ot + ot) * 2, l, j, h.w2[(size_t)o * h.n_hid + hh] * s2);
                 }
+    // biases in the accumulators' scale: inputs carry 2^6 (kH2InScale), activations 2^14 (kH2ActScale)
+    const float a1 = ldexpf(1.0f, e1 + 6), a2 = ldexpf(1.0f, e2 + 14);
+    std::vector<float> b1h((size_t)d.npairs * 32, 0.f), b2h((size_t)d.n_ot * 16, 0.f);
+    for (int i = 0; i < h.n_hid; i++) b1h[i] = h.b1[i] * a1;
+    for (int i = 0; i < h.n_out; i++) b2h[i] = h.b2[i] * a2;
+    for (float v : b1h) if (!std::isfinite(v)) *representable = false;
+    for (float v : b2h) if (!std::isfinite(v)) *representable = false;
+    if (!*representable) return LCRC_OK;
     const _Float16 *p = nullptr;
-    HIP_TRY(c, dev_upload(c, w1h, &p)); d.w1h = reinterpret_cast<const float4 *>(p);
-    HIP_TRY(c, dev_upload(c, w2h, &p)); d.w2h = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, w1h, &p)); out.w1h = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, w2h, &p)); out.w2h = reinterpret_cast<const float4 *>(p);
+    HIP_TRY(c, dev_upload(c, b1h, &out.b1h));
+    HIP_TRY(c, dev_upload(c, b2h, &out.b2h));
+    out.sig_descale = ldexpf(1.0f, -(e1 + 6));
+    out.out_descale = ldexpf(1.0f, -(e2 + 14));
+    return LCRC_OK;
+}
+
+// The split-f16 operand images of a model: built and uploaded on the FIRST lcrc_set_arithmetic(.., LCRC_ARITH_SPLIT_F16)
+// of any of the contexts that share the model (a context that never asks pays nothing), then handed to this context.
+int ensure_split_f16(lcrc_ctx *c)
+{
+    SharedModel &m = *c->model;
+    std::lock_guard<std::mutex> l(m.mu);
+    if (m.h2_state == 0) {
+        m.h2_state = -1;
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; i++) {
+            int rc = pack_net_h2(c, m.host[i], c->nets[i], m.h2[i], &ok);
+            if (rc) return rc;
+        }
+        if (ok) m.h2_state = 1;
+    }
+    if (m.h2_state != 1) return LCRC_E_UNSUPPORTED;
+    for (int i = 0; i < 3; i++) {
+        c->nets[i].w1h = m.h2[i].w1h; c->nets[i].w2h = m.h2[i].w2h;
+        c->nets[i].b1h = m.h2[i].b1h; c->nets[i].b2h = m.h2[i].b2h;
+        c->nets[i].h2_sig_descale = m.h2[i].sig_descale; c->nets[i].h2_out_descale = m.h2[i].out_descale;
+    }
     return LCRC_OK;
 }
 
@@ -184,50 +282,91 @@ int pack_net_h2(lcrc_ctx *c, const HostNet &h, NetDev &d, int ns)
 // Out-of-range rows/columns are zeros, which is what makes padded hidden units and
 // padded k-steps contribute nothing (the reference zero-fills its x4 pads the same
 // way, nn.cpp:239-243,276-280).
-int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d, bool split_f16_form = false)
+// Host half: shape + every array of the net in ONE block of floats (each array at a 64-float boundary), so that
+// packing needs no GPU (it runs while the HIP runtime is still starting up, several nets in parallel) and the upload
+// is one allocation and one copy per net.
+struct PackedNet {
+    NetDev d;                 // shape fields only
+    std::vector<float> blob;
+    size_t w1p, w2p, b1, b2, mean, dev;     // offsets (floats)
+};
+
+void pack_net_host(const HostNet &h, PackedNet &pk)
 {
+    NetDev &d = pk.d;
+    memset(&d, 0, sizeof d);
     d.n_inp = h.n_inp; d.n_hid = h.n_hid; d.n_out = h.n_out;
     d.ksteps = (h.n_inp + 3) / 4;
     d.nkq = (d.ksteps + 3) / 4;
     d.nht = (h.n_hid + 15) / 16;
     d.n_ot = (h.n_out + 15) / 16;
-    // (+ one all-zero fragment behind each array: the run-time-shape kernels run the MFMA groups of their size class
-    //  unconditionally and point the entries past this net's k-groups / output tiles at it)
-    std::vector<float> w1p(((size_t)d.nht * d.nkq + 1) * 256, 0.f), w2p(((size_t)d.nht * d.n_ot + 1) * 256, 0.f);
-    for (int ht = 0; ht < d.nht; ht++)
-        for (int kq = 0; kq < d.nkq; kq++)
-            for (int l = 0; l < 64; l++)
-                for (int j = 0; j < 4; j++) {
-                    const int hh = 16 * ht + (l & 15), k = 16 * kq + 4 * j + (l >> 4);
-                    if (hh < h.n_hid && k < h.n_inp)
-                        w1p[(((size_t)ht * d.nkq + kq) * 64 + l) * 4 + j] = h.w1[(size_t)hh * h.n_inp + k];
-                }
-    for (int ht = 0; ht < d.nht; ht++)
-        for (int ot = 0; ot < d.n_ot; ot++)
-            for (int l = 0; l < 64; l++)
-                for (int r = 0; r < 4; r++) {
-                    const int o = 16 * ot + (l & 15), hh = 16 * ht + 4 * (l >> 4) + r;
-                    if (o < h.n_out && hh < h.n_hid)
-                        w2p[(((size_t)ht * d.n_ot + ot) * 64 + l) * 4 + r] = h.w2[(size_t)o * h.n_hid + hh];
-                }
+    d.npairs = (d.nht + 1) / 2;
+    d.h2_sig_descale = d.h2_out_descale = 1.f;
+    // (+ one all-zero fragment behind each weight array: the run-time-shape kernels run the MFMA groups of their size
+    //  class unconditionally and point the entries past this net's k-groups / output tiles at it)
     // (b1 padded to whole tile pairs, mean / dev to whole 32-deep k-steps: what the split-f16 kernels stage)
     const int ns = (h.n_inp + 31) / 32;
-    d.npairs = (d.nht + 1) / 2;
-    std::vector<float> b1((size_t)d.npairs * 32, 0.f), b2((size_t)d.n_ot * 16, 0.f);
-    std::vector<float> mean((size_t)std::max(d.nkq * 16, ns * 32), 0.f), dev(mean.size(), 1.f);
-    memcpy(b1.data(), h.b1.data(), sizeof(float) * h.n_hid);
-    memcpy(b2.data(), h.b2.data(), sizeof(float) * h.n_out);
-    memcpy(mean.data(), h.mean.data(), sizeof(float) * h.n_inp);
-    memcpy(dev.data(), h.dev.data(), sizeof(float) * h.n_inp);
-    const float *p = nullptr;
-    HIP_TRY(c, dev_upload(c, w1p, &p)); d.w1p = reinterpret_cast<const float4 *>(p);
-    HIP_TRY(c, dev_upload(c, w2p, &p)); d.w2p = reinterpret_cast<const float4 *>(p);
-    HIP_TRY(c, dev_upload(c, b1, &d.b1));
-    HIP_TRY(c, dev_upload(c, b2, &d.b2));
-    HIP_TRY(c, dev_upload(c, mean, &d.mean));
-    HIP_TRY(c, dev_upload(c, dev, &d.dev));
-    d.w1h = d.w2h = nullptr;
-    return split_f16_form ? pack_net_h2(c, h, d, ns) : LCRC_OK;       // (the LCRC kernels only)
+    const size_t n_w1 = ((size_t)d.nht * d.nkq + 1) * 256, n_w2 = ((size_t)d.nht * d.n_ot + 1) * 256;
+    const size_t n_b1 = (size_t)d.npairs * 32, n_b2 = (size_t)d.n_ot * 16, n_nrm = (size_t)std::max(d.nkq * 16, ns * 32);
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    pk.w1p = 0;
+    pk.w2p = pk.w1p + up(n_w1);
+    pk.b1 = pk.w2p + up(n_w2);
+    pk.b2 = pk.b1 + up(n_b1);
+    pk.mean = pk.b2 + up(n_b2);
+    pk.dev = pk.mean + up(n_nrm);
+    pk.blob.assign(pk.dev + up(n_nrm), 0.f);
+    float *w1p = pk.blob.data() + pk.w1p, *w2p = pk.blob.data() + pk.w2p;
+    for (int ht = 0; ht < d.nht; ht++)
+        for (int kq = 0; kq < d.nkq; kq++)
+            for (int l = 0; l < 64; l++) {
+                const int hh = 16 * ht + (l & 15);
+                if (hh >= h.n_hid) continue;
+                const float *row = &h.w1[(size_t)hh * h.n_inp];
+                float *dst = w1p + (((size_t)ht * d.nkq + kq) * 64 + l) * 4;
+                for (int j = 0; j < 4; j++) {
+                    const int k = 16 * kq + 4 * j + (l >> 4);
+                    if (k < h.n_inp) dst[j] = row[k];
+                }
+            }
+    for (int ht = 0; ht < d.nht; ht++)
+        for (int ot = 0; ot < d.n_ot; ot++)
+            for (int l = 0; l < 64; l++) {
+                const int o = 16 * ot + (l & 15);
+                if (o >= h.n_out) continue;
+                const float *row = &h.w2[(size_t)o * h.n_hid];
+                float *dst = w2p + (((size_t)ht * d.n_ot + ot) * 64 + l) * 4;
+                for (int r = 0; r < 4; r++) {
+                    const int hh = 16 * ht + 4 * (l >> 4) + r;
+                    if (hh < h.n_hid) dst[r] = row[hh];
+                }
+            }
+    memcpy(pk.blob.data() + pk.b1, h.b1.data(), sizeof(float) * h.n_hid);
+    memcpy(pk.blob.data() + pk.b2, h.b2.data(), sizeof(float) * h.n_out);
+    memcpy(pk.blob.data() + pk.mean, h.mean.data(), sizeof(float) * h.n_inp);
+    std::fill(pk.blob.begin() + pk.dev, pk.blob.end(), 1.f);
+    memcpy(pk.blob.data() + pk.dev, h.dev.data(), sizeof(float) * h.n_inp);
+}
+
+// Device half: the block to the GPU, pointers into it
+int upload_net(lcrc_ctx *c, const PackedNet &pk, NetDev &d)
+{
+    const float *base = nullptr;
+    HIP_TRY(c, dev_upload(c, pk.blob, &base));
+    d = pk.d;
+    d.w1p = reinterpret_cast<const float4 *>(base + pk.w1p);
+    d.w2p = reinterpret_cast<const float4 *>(base + pk.w2p);
+    d.b1 = base + pk.b1; d.b2 = base + pk.b2; d.mean = base + pk.mean; d.dev = base + pk.dev;
+    d.w1h = d.w2h = nullptr;       // built on request (ensure_split_f16)
+    d.b1h = d.b2h = nullptr;
+    return LCRC_OK;
+}
+
+int pack_net(lcrc_ctx *c, const HostNet &h, NetDev &d)
+{
+    PackedNet pk;
+    pack_net_host(h, pk);
+    return upload_net(c, pk, d);
 }
 
 // Test hook (lcrc_debug_fail_alloc): the n-th buffer allocation from now on fails with out-of-memory.
@@ -372,6 +511,28 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     return LCRC_OK;
 }
 
+// Scratch of the split-hidden path (small launches), allocated when the first launch that could use it arrives: zeroed
+// once, the kernels leave the tickets at zero.  A context that only ever sees large launches (the CLI's batches, the
+// bench) never pays for it.  On failure the context simply keeps to the fused kernel.
+void ensure_split_scratch(lcrc_ctx *c)
+{
+    if (c->d_part || c->split_scratch_failed) return;
+    size_t pb = 0, gb = 0, cb = 0;
+    lcrc_split_scratch(c->nets, kSplitCapWgs, &pb, &gb, &cb);
+    void *part = nullptr, *gimg = nullptr, *cnt = nullptr;
+    if (hipMalloc(&part, pb) != hipSuccess || hipMalloc(&gimg, gb) != hipSuccess || hipMalloc(&cnt, cb) != hipSuccess ||
+        hipMemsetAsync(gimg, 0, gb, c->stream) != hipSuccess || hipMemsetAsync(cnt, 0, cb, c->stream) != hipSuccess) {
+        if (part) (void)hipFree(part);
+        if (gimg) (void)hipFree(gimg);
+        if (cnt) (void)hipFree(cnt);
+        (void)hipGetLastError();
+        c->split_scratch_failed = true;
+        return;
+    }
+    c->allocs.push_back(part); c->allocs.push_back(gimg); c->allocs.push_back(cnt);
+    c->d_part = static_cast<float4 *>(part); c->d_gimg = static_cast<float4 *>(gimg); c->d_cnt = static_cast<unsigned *>(cnt);
+}
+
 // Rows [row_first, row_first + row_count) of the n_rows rows are computed (row_count < 0: all of them);
 // d_post receives row_first's posteriors first.
 int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
@@ -385,6 +546,11 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
         return launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
     }
     if (row_count == 0) return LCRC_OK;
+    // (the scratch's clears run on the context's stream: a launch on another stream waits for them once)
+    if (!c->d_part && c->split_hint != 1 && c->arith == 0 && !dbg && row_count <= kSplitMaxRows) {
+        ensure_split_scratch(c);
+        if (c->d_part && s != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     LcrcParams p;
     memset(&p, 0, sizeof p);
     for (int i = 0; i < 3; i++) p.net[i] = c->nets[i];
@@ -589,6 +755,8 @@ static int open_context(lcrc_ctx **out, int nbanks, int device_id)
     lcrc_ctx *c = new lcrc_ctx;
     c->device = device_id;
     c->nbanks = nbanks;
+    c->model = std::make_shared<SharedModel>();
+    c->model->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         g_create_err = "cannot create HIP stream/events";
@@ -596,6 +764,17 @@ static int open_context(lcrc_ctx **out, int nbanks, int device_id)
         return LCRC_E_DEVICE;
     }
     *out = c;
+    return LCRC_OK;
+}
+
+int lcrc_device_warmup(int device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    HIP_TRY(nullptr, hipFree(nullptr));                 // brings the device's primary context up
     return LCRC_OK;
 }
 
@@ -608,23 +787,37 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
         return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: posteriors/system=LCRC is implemented for length=31, add_c0=true");
 
     // -- files first, so that a bad model directory is reported even without a GPU
+    StartupTrace trace;
     HostNet nets[3];
     std::vector<float> win[2];
     {
         int rc = load_model(model_dir, nbanks, nets, win);
         if (rc) return rc;
     }
+    trace.mark("model files");
+    // fragment order on the host first (no GPU involved: a caller that started lcrc_device_warmup on another thread has
+    // the HIP runtime coming up meanwhile), the three nets side by side
+    PackedNet packed[3];
+    {
+        std::thread t1([&] { pack_net_host(nets[1], packed[1]); }), t2([&] { pack_net_host(nets[2], packed[2]); });
+        pack_net_host(nets[0], packed[0]);
+        t1.join();
+        t2.join();
+    }
+    trace.mark("pack (host)");
     lcrc_ctx *c = nullptr;
     {
         int rc = open_context(&c, nbanks, device_id);
         if (rc) return rc;
     }
+    trace.mark("HIP device, stream, events");
     auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
     for (int i = 0; i < 3; i++) {
-        c->host[i] = nets[i];
-        int rc = pack_net(c, nets[i], c->nets[i], true);
+        int rc = upload_net(c, packed[i], c->nets[i]);
         if (rc) return bail(rc);
+        c->model->host[i] = std::move(nets[i]);
     }
+    trace.mark("upload weights");
     // DCT basis exactly as sDCT evaluates it (dspc.h:206-221), in f32 with libm cosf
     std::vector<float> cosv(10 * 16), winv(32);
     const float pibyn = (float)M_PI / (float)kHalf;
@@ -647,23 +840,6 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
     }
     c->variant = v;
     c->trap_bands = 2;
-    {
-        // scratch of the split-hidden path (small launches): zeroed once, the kernels leave the tickets at zero
-        size_t pb = 0, gb = 0, cb = 0;
-        lcrc_split_scratch(c->nets, kSplitCapWgs, &pb, &gb, &cb);
-        void *part = nullptr, *gimg = nullptr, *cnt = nullptr;
-        if (hipMalloc(&part, pb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
-        c->allocs.push_back(part);
-        if (hipMalloc(&gimg, gb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
-        c->allocs.push_back(gimg);
-        if (hipMalloc(&cnt, cb) != hipSuccess) { c->err = "cannot allocate split scratch"; return bail(LCRC_E_NOMEM); }
-        c->allocs.push_back(cnt);
-        if (hipMemset(gimg, 0, gb) != hipSuccess || hipMemset(cnt, 0, cb) != hipSuccess) {
-            c->err = "cannot clear split scratch";
-            return bail(LCRC_E_DEVICE);
-        }
-        c->d_part = static_cast<float4 *>(part); c->d_gimg = static_cast<float4 *>(gimg); c->d_cnt = static_cast<unsigned *>(cnt);
-    }
     *out = c;
     return LCRC_OK;
 }
@@ -756,7 +932,7 @@ int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system
             return bail(LCRC_E_DEVICE);
         }
     }
-    c->host[2] = merger;
+    c->model->host[2] = merger;
     {
         int rc = pack_net(c, merger, c->nets[2]);
         if (rc) return bail(rc);
@@ -778,6 +954,33 @@ int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system
     if (dev_upload(c, cosv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
     c->d_costab31 = const_cast<float *>(p);
     c->variant = sys == SYS_1BT_DCT ? "traps_1bt_dct" : sys == SYS_1BT ? "traps_1bt" : "traps_3bt";
+    *out = c;
+    return LCRC_OK;
+}
+
+int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src)
+{
+    if (!out || !src) return fail(nullptr, LCRC_E_ARG, "lcrc_clone: NULL argument");
+    *out = nullptr;
+    lcrc_ctx *c = nullptr;
+    {
+        int rc = open_context(&c, src->nbanks, src->device);
+        if (rc) return rc;
+    }
+    c->model = src->model;                 // the read-only device buffers and the host nets are shared
+    for (int i = 0; i < 3; i++) {
+        c->nets[i] = src->nets[i];
+        c->nets[i].w1h = c->nets[i].w2h = nullptr;      // (handed out by lcrc_set_arithmetic)
+        c->nets[i].b1h = c->nets[i].b2h = nullptr;
+    }
+    c->d_win = src->d_win; c->d_costab = src->d_costab; c->normc = src->normc;
+    c->system = src->system; c->trap_bands = src->trap_bands; c->shift = src->shift;
+    c->use_hamming = src->use_hamming; c->add_c0 = src->add_c0;
+    c->band_nets = src->band_nets; c->d_band_nets = src->d_band_nets; c->d_band_col = src->d_band_col;
+    c->band_max = src->band_max;
+    c->d_hamm31 = src->d_hamm31; c->d_costab31 = src->d_costab31; c->normc31 = src->normc31;
+    c->traps_unfused = src->traps_unfused;
+    c->variant = src->variant; c->lds_bytes = src->lds_bytes;
     *out = c;
     return LCRC_OK;
 }
@@ -1274,6 +1477,28 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
     if (!c->hist_init) c->ring_rows = 0;
+    // Large pushes (the offline main call of srec.cpp:1048 hands over a whole utterance) go through the device staging
+    // buffers -- [history | frames] copied at PCIe rate, the kernel on HBM -- instead of the kernel reading the frames from
+    // and writing the posteriors to mapped host memory row by row; the strip then only keeps the new history.
+    constexpr int kPushStagedMin = 256;
+    if (needed && c->system == SYS_LCRC && n >= kPushStagedMin && c->hist_init) {
+        int rc = ensure_staging(c, H + (size_t)n, 1);
+        if (rc) return rc;
+        memcpy(c->h_mel, c->h_ring + (c->ring_rows - H) * nb, H * nb * sizeof(float));
+        memcpy(c->h_mel + H * nb, mel, (size_t)n * nb * sizeof(float));
+        HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (H + (size_t)n) * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        rc = launch(c, c->d_mel, nullptr, 1, (int)(H + n), c->d_post, c->stream, nullptr, kShift, n, false);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        // the new history while the copies and the kernel run: the last 30 pushed frames
+        memcpy(c->h_ring, mel + ((size_t)n - H) * nb, H * nb * sizeof(float));
+        c->ring_rows = H;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
+        c->delay += n;
+        if (c->delay > 9999) c->delay = 9999;
+        return LCRC_OK;
+    }
     int rc = ensure_ring(c, (c->hist_init ? 0 : H) + (size_t)n);
     if (rc) return rc;
     if (!c->hist_init) {                     // first frame floods the history (traps.cpp:184-200)
@@ -1328,6 +1553,8 @@ int lcrc_posteriors_rows(lcrc_ctx *c, const float *mel, int n_rows, int row_firs
 
 int lcrc_debug_fail_alloc(int nth)
 {
+    const char *e = getenv("LCRC_FAULT_INJECTION");
+    if (!e || strcmp(e, "1") != 0) return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_debug_fail_alloc: set LCRC_FAULT_INJECTION=1");
     g_fail_alloc = nth;
     return LCRC_OK;
 }
@@ -1354,8 +1581,12 @@ int lcrc_set_arithmetic(lcrc_ctx *c, int arithmetic)
         return fail(c, LCRC_E_ARG, "lcrc_set_arithmetic: LCRC_ARITH_F32 or LCRC_ARITH_SPLIT_F16");
     if (arithmetic == LCRC_ARITH_SPLIT_F16) {
         if (c->system != SYS_LCRC || !lcrc_has_split_f16(c->nets))
-            return fail(c, LCRC_E_UNSUPPORTED, "lcrc_set_arithmetic: split-f16 kernels exist for the shipped LCRC shapes, "
-                        "weights within +-65504");
+            return fail(c, LCRC_E_UNSUPPORTED, "lcrc_set_arithmetic: split-f16 kernels exist for the shipped LCRC shapes");
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int rc = ensure_split_f16(c);
+        if (rc == LCRC_E_UNSUPPORTED)
+            return fail(c, rc, "lcrc_set_arithmetic: the model has no split-f16 form (non-finite weights or biases)");
+        if (rc) return rc;
     }
     c->arith = arithmetic;
     return LCRC_OK;

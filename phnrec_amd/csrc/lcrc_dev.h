@@ -33,6 +33,12 @@ struct NetDev {
     const float4 *w1h;   // [npairs][ns][2 tiles][2 pieces][64]  A fragments of layer 1 (8 f16 k-values per lane)
     const float4 *w2h;   // [npairs][not][2 pieces][64]          A fragments of layer 2 (8 hidden units of the pair)
     int npairs;          // ceil(nht / 2); b1 is padded to 32 * npairs, mean / dev to 32 * ns
+    // ... whose operands are scaled by powers of two (mlp_dev.h "Operand scaling"): the biases in the accumulators'
+    // scale, and the factors that undo it
+    const float *b1h;    // b1 * 2^(e1 + 6)
+    const float *b2h;    // b2 * 2^(e2 + 14)
+    float h2_sig_descale;   // 2^-(e1 + 6): folded into FEXP's f64 constant
+    float h2_out_descale;   // 2^-(e2 + 14): applied to a wave's partial output tile
 };
 
 struct LcrcParams {
@@ -179,8 +185,9 @@ void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t 
 constexpr int kSplitCapWgs = 512;    // workgroups of a split launch (tiles x split) never exceed this
 // variant that WOULD be selected for these nets (no launch); NULL if unsupported
 const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes);
-// whether the model has split-f16 kernels (a shipped shape, weights within f16's range)
+// whether split-f16 kernels exist for the model's shape (a shipped shape)
 bool lcrc_has_split_f16(const NetDev *nets);
+constexpr int kSplitMaxRows = 4096;  // launches above it never take the split-hidden path
 
 }  // namespace phnrec
 #endif

@@ -4,7 +4,7 @@
 //     post[r] = merger( ln band0(proj_L(ctx_r)) | ln band1(proj_R(ctx_r)) )
 // i.e. everything Traps::CalcFeatures does per frame (traps.cpp:470-516):
 //   AddVectorToBEMatrix           traps.cpp:180-219  -> clamped window gather from an LDS-staged mel tile
-//   CalcInputFeaturesForBandNets  traps.cpp:285-343  -> window * DCT projection on the VALU
+//   CalcInputFeaturesForBandNets  traps.cpp:285-343  -> window * DCT projection as small MFMA products (stage 1)
 //   NeuralNet::Forward x3         nn.cpp:872-899     -> f32 MFMA (v_mfma_f32_16x16x4_f32) with fused
 //                                                       normalise / bias / FEXP sigmoid / FEXP softmax
 //   CalcInputFeaturesForMerger    traps.cpp:435-461  -> ln() + merger normalisation straight into the
@@ -34,8 +34,9 @@
 //
 // Arithmetic contract (tests/: <= 1e-4 max-abs per frame vs the reference):
 //   * exp is the reference's FEXP bit trick, bit-emulated (fexp.h:14-21), incl.
-//     x86's out-of-range cvttsd2si result; sigmoid is evaluated in f64 like the
-//     reference's expression (fexp.h:33-38);
+//     x86's out-of-range cvttsd2si result: FEXP's f64 product and integer part are
+//     exact; the sigmoid's 1/(1+e) is v_rcp_f32 (1 ulp) where the reference divides
+//     in f64 and rounds once (fexp.h:33-38; mlp_dev.h SigTile says why);
 //   * products accumulate from the bias in ascending k (MFMA = f32 fma chain);
 //     layer 2 is split over waves, then folded in a fixed order: deterministic;
 //   * projection and normalisation use unfused f32 mul/add in the reference's
@@ -657,7 +658,7 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
 bool lcrc_has_split_f16(const NetDev *nets)
 {
     const Variant *v = pick(nets);
-    return v && v->h2[0] && nets[0].w1h && nets[1].w1h && nets[2].w1h;
+    return v && v->h2[0];
 }
 
 void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes)

@@ -159,9 +159,11 @@ struct SigTile {
 #pragma unroll
             for (int i = 0; i < 4; i++) x[4 * f + i] = -p[f][i];
     }
-    __device__ __forceinline__ void stage(int k)
+    // `a`: FEXP's constant 2^20 / ln 2 -- times a power of two where the pre-activations arrive scaled (split-f16
+    // arithmetic: exact, so the value is the one the unscaled pre-activation gives)
+    static constexpr double kFexpA = 1048576.0 / 0.69314718055994530942;
+    __device__ __forceinline__ void stage(int k, const double a = kFexpA)
     {
-        const double a = 1048576.0 / 0.69314718055994530942;
 #pragma unroll
         for (int i = 0; i < kN; i++) {
             switch (k) {
@@ -481,6 +483,14 @@ struct RingLoop {
 // with such weights, inputs are clamped there (a normalised feature of that size saturates every sigmoid anyway).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr float kHalfMax = 65504.0f;
+// Operand scaling.  The low half of a value below 2^-3 is an f16 SUBNORMAL (absolute error 2^-25 instead of 2^-22
+// relative), so every operand is moved up by a power of two before it is split -- exact, and undone exactly:
+//   weights      by 2^e per matrix, max|w| * 2^e in (2^13, 2^14]   (host, pack_net_h2; the biases by the same factors)
+//   net inputs   by kH2InScale  (normalised features are O(1..10); they clamp at +-65504 / kH2InScale = +-1023)
+//   activations  by kH2ActScale (sigmoid outputs lie in (0, 1))
+// layer-1 accumulators then hold 2^(e1 + 6) x the pre-activation -- undone inside FEXP's f64 product (NetDev::h2_sig_descale)
+// --, layer-2 accumulators 2^(e2 + 14) x theirs -- undone when a wave publishes its partial tile (NetDev::h2_out_descale).
+constexpr float kH2InScale = 64.0f, kH2ActScale = 16384.0f;
 
 __device__ __forceinline__ f4 mfma_h(const f4 &a, const f4 &b, f4 c)
 {
@@ -494,7 +504,7 @@ __device__ __forceinline__ f4 mfma_h(const f4 &a, const f4 &b, f4 c)
 __device__ __forceinline__ int h2_k_ofs(int k) { return ((k >> 3) << 8) + ((k & 7) << 1); }
 __device__ __forceinline__ void h2_img_store(void *img, int ofs, int lo_ofs, float v)
 {
-    v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+    v = __builtin_amdgcn_fmed3f(v * kH2InScale, -kHalfMax, kHalfMax);
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     *reinterpret_cast<_Float16 *>(static_cast<char *>(img) + ofs) = hi;
@@ -532,6 +542,7 @@ struct HalfLoop {
     const float *b1;
     const f4 *XF;
     int plast, lane;
+    double sig_mul;             // FEXP's constant x 2^-(e1 + 6)
     f4 ring[R][2];
 
     __device__ __forceinline__ void request(int slot, int e, int P)
@@ -558,7 +569,7 @@ struct HalfLoop {
             sg.begin(pre);
             if (!(LCRC_DBG & 2)) {
 #pragma unroll
-                for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k);
+                for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k, sig_mul);
             }
             f4 s[2 * FT];
             sg.finish(s);
@@ -567,7 +578,7 @@ struct HalfLoop {
                 h8 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float v = s[(j >> 2) * FT + f][j & 3];
+                    const float v = s[(j >> 2) * FT + f][j & 3] * kH2ActScale;
                     const _Float16 a = (_Float16)v;
                     hi[j] = a;
                     lo[j] = (_Float16)(v - (float)a);
@@ -657,7 +668,8 @@ struct HalfLoop {
     __device__ __forceinline__ void setup(const NetDev &nd, const f4 *xf_image, int lane_)
     {
         w1 = reinterpret_cast<const f4 *>(nd.w1h); w2 = reinterpret_cast<const f4 *>(nd.w2h);
-        b1 = nd.b1; XF = xf_image; lane = lane_;
+        b1 = nd.b1h; XF = xf_image; lane = lane_;
+        sig_mul = SigTile<1>::kFexpA * (double)nd.h2_sig_descale;
         plast = (LCRC_DBG & 1) ? 0 : nd.npairs - 1;
     }
 };
@@ -836,7 +848,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     for (int ot = 0; ot < NOT; ot++) {
         f4 b = {0.f, 0.f, 0.f, 0.f};
         if (wig == 0 && (EXACT || ot < n_ot))
-            b = *reinterpret_cast<const f4 *>(nd.b2 + 16 * ot + 4 * g);   // PrepareBiases nn.cpp:857
+            b = *reinterpret_cast<const f4 *>((ARITH ? nd.b2h : nd.b2) + 16 * ot + 4 * g);   // PrepareBiases nn.cpp:857
 #pragma unroll
         for (int f = 0; f < FT; f++) acc[ot][f] = b;
     }
@@ -867,6 +879,13 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     }
 
     LCRC_STAMP(prm, wave, lane, stamp0);       // hidden loop done
+    if constexpr (ARITH == 1) {                // the accumulators hold 2^(e2 + 14) x the sums (exact to undo)
+        const float ds = nd.h2_out_descale;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ot++)
+#pragma unroll
+            for (int f = 0; f < FT; f++) acc[ot][f] *= ds;
+    }
     {
         // No fold round: every wave publishes its partial tile in a slab of its own and the softmax adds
         // them while it reads (two per net when two nets share the waves, four otherwise).  slab23 may lie over

@@ -38,34 +38,73 @@ def free_port():
     return p
 
 
+def _stop_group(p, sig):
+    """signal the child's whole process group (it leads its own session), falling back to the child alone"""
+    try:
+        os.killpg(p.pid, sig)
+    except (ProcessLookupError, PermissionError, OSError):
+        try:
+            p.send_signal(sig)
+        except (ProcessLookupError, OSError):
+            pass
+
+
 def self_launch(script, argv, world, poll_s=0.05):
     """`python bench.py --gpus N` without a launcher: start N fresh single-GPU ranks of `script` (the
     environment torch.distributed.run would give them, rendezvous on 127.0.0.1) and return the worst exit
     code.  The calling process must not have touched the GPU and never does: the ranks are CHILD
     processes, nothing is re-executed.  Rank 0 inherits stdout (its one JSON line is the run's output);
-    the other ranks' stdout goes to stderr.  If a rank fails, the others are terminated (by PID) instead
-    of being left waiting at a barrier."""
+    the other ranks' stdout goes to stderr.  No rank outlives this call: if one fails, or this process is
+    interrupted or told to terminate (harness timeout, SIGTERM, Ctrl-C), every live rank's process group gets
+    SIGTERM, then SIGKILL -- never a rank left holding its GPU at a barrier."""
+    import signal
     port = free_port()
     procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                   LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   PHNREC_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
-                                      stdout=None if rank == 0 else sys.stderr))
+
+    def interrupted(signum, frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+
+    handlers = {}
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            handlers[sig] = signal.signal(sig, interrupted)
+        except ValueError:              # not the main thread: the finally clause still runs on exceptions
+            pass
     worst = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            rc = p.poll()
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0:
-                worst = worst or rc
-                for q in live:          # a rank died: the rest would hang at the next barrier
-                    q.terminate()
-        time.sleep(poll_s)
+    try:
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                       LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       PHNREC_SELF_LAUNCHED="1")
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                          stdout=None if rank == 0 else sys.stderr, start_new_session=True))
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in live:          # a rank died: the rest would hang at the next barrier
+                        _stop_group(q, signal.SIGTERM)
+            time.sleep(poll_s)
+    except KeyboardInterrupt:
+        worst = worst or 130
+    finally:
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            _stop_group(p, signal.SIGTERM)
+        deadline = time.time() + 5.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                _stop_group(p, signal.SIGKILL)
+                p.wait()
+        for sig, h in handlers.items():
+            signal.signal(sig, h)
     return worst
 
 
@@ -82,6 +121,7 @@ class Ranks:
                          "torch.distributed.run" if self.launched else "none")
         self.pg = False
         self.backend = None
+        self.host_group = None
 
     def init(self, backend):
         # also under a launcher with a single rank, so that the rendezvous / RCCL path is the one
@@ -95,7 +135,16 @@ class Ranks:
             self.backend = backend
             # what the process group itself says, not what the environment promised
             self.world = dist.get_world_size()
+            # a host-side group for waits that must not occupy the GPUs (an RCCL barrier is a kernel that spins on
+            # every waiting rank's device)
+            self.host_group = dist.new_group(backend="gloo") if backend != "gloo" else None
         return self
+
+    def host_barrier(self):
+        """all ranks meet on the CPU (gloo); the GPUs stay free for whoever is still working"""
+        if self.pg:
+            import torch.distributed as dist
+            dist.barrier(group=self.host_group) if self.host_group is not None else dist.barrier()
 
     def barrier(self):
         if self.pg:

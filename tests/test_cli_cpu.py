@@ -182,3 +182,30 @@ def test_a_missing_file_in_the_middle_of_a_list(tmp_path):
     p = run("-c", model_dir(CZ), "-s", "post", "-l", lst, ok=False)
     assert p.returncode == 1 and "Invalid line in file list" in p.stderr
     assert (data / "utt_a.rec").exists() and (data / "utt_b.rec").exists() and not (data / "utt_c.rec").exists()
+
+
+@pytest.mark.parametrize("threads,batch", [(1, 100), (4, 300), (8, 100000)])
+def test_long_list_leaves_in_list_order(tmp_path, threads, batch):
+    """The list pipeline (read-ahead on the pool, runs of consecutive staged files, in-order writer) on a list of
+    240 entries with small and large launch sizes and 1 / 4 / 8 host threads: the MLF is the concatenation of the
+    reference CLI's entries in list order (srec.cpp:1246-1290 is a sequential loop), whatever the interleaving."""
+    gold = open(os.path.join(GOLD, "cli", "list.mlf")).read()
+    entries = {}
+    for n in ("utt_a", "utt_b", "utt_c"):
+        i = gold.index('"*/%s.rec"' % n)
+        entries[n] = gold[i:gold.index("\n.\n", i) + 3]
+    rng = np.random.default_rng(threads)
+    order = [("utt_a", "utt_b", "utt_c")[int(k)] for k in rng.integers(0, 3, 240)]
+    data = tmp_path / "d"
+    data.mkdir()
+    lines = []
+    for i, n in enumerate(order):
+        sub = data / ("%03d" % i)
+        sub.mkdir()
+        shutil.copyfile(os.path.join(GOLD, "cli", n + ".lop"), sub / (n + ".lop"))
+        lines.append("%s\n" % (sub / (n + ".lop")))
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(lines))
+    mlf = tmp_path / "out.mlf"
+    run("-c", model_dir(CZ), "-s", "post", "-l", lst, "-m", mlf, "-j", threads, "-b", batch)
+    assert mlf.read_text() == "#!MLF!#\n" + "".join(entries[n] for n in order)

@@ -257,6 +257,40 @@ def test_two_logical_gpus_same_mlf_as_one(flags, tmp_path):
         assert open(f, "rb").read() == blob, f
 
 
+@pytest.mark.parametrize("n_gpus,flags", [(4, ()), (8, ()), (8, ("-F",)), (4, ("-F", "-D"))])
+def test_four_and_eight_logical_gpus_same_mlf_as_one(n_gpus, flags, tmp_path):
+    """`-g 4` / `-g 8` (8 / 16 contexts on ONE launch queue that runs from the first line of the list to the last --
+    nothing joins the contexts in between), every logical GPU mapped onto this box's GPU: byte for byte the MLF
+    of `-g 1`, and the run reports every file (srec.cpp:1246-1290 is a sequential loop; the order of its output is
+    the list's)."""
+    lst = _make_list(tmp_path, "hu", 150, seed=5)
+    one, many = tmp_path / "one.mlf", tmp_path / "many.mlf"
+    run("-c", model_dir(HU), "-l", lst, "-m", one, "-g", 1, "-b", 700, *flags)
+    p = run("-c", model_dir(HU), "-l", lst, "-m", many, "-g", n_gpus, "-b", 700, *flags,
+            env={"PHNREC_DEVICE_MAP": ",".join(["0"] * n_gpus), "PHNREC_STATS": "1"})
+    assert "files=150" in p.stderr
+    a, b = one.read_text(), many.read_text()
+    assert a == b and a.startswith("#!MLF!#\n") and a.count("\n.\n") == 150
+    heads = [l for l in a.splitlines() if l.startswith('"')]
+    assert heads == sorted(heads) and len(heads) == 150
+
+
+def test_unreadable_file_in_a_gpu_list_stops_there(tmp_path):
+    """the reference exit(1)s at the first file it cannot open (srec.cpp:1280-1284): with the GPU pipeline too, every
+    file BEFORE it has its MLF entry, none behind it, whatever -g is"""
+    lst = _make_list(tmp_path, "cz", 40, seed=6)
+    names = lst.read_text().split()
+    os.remove(names[25])
+    for g in (1, 4):
+        mlf = tmp_path / ("g%d.mlf" % g)
+        e = dict(os.environ, PHNREC_DEVICE_MAP=",".join(["0"] * g))
+        p = subprocess.run([BIN, "-c", model_dir(CZ), "-l", str(lst), "-m", str(mlf), "-g", str(g), "-b", "400"],
+                           capture_output=True, text=True, env=e)
+        assert p.returncode == 1 and "Can not open waveform file: %s" % names[25] in p.stderr
+        heads = [l for l in mlf.read_text().splitlines() if l.startswith('"')]
+        assert heads == ['"*/f%03d.rec"' % i for i in range(25)], (g, heads[-3:])
+
+
 def test_configs3_list_at_scale(tmp_path):
     """BASELINE configs[3] at its stated size on the one GPU of this box: the shipped HU weights, 10 000 files of
     3-15 s (slices of one synthetic 8 kHz signal, ~9 M frames), host Viterbi, one MLF -- once with `-g 1`, once as
@@ -312,8 +346,8 @@ def test_bench_line_carries_every_leg():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PHNREC_DEVICE_MAP")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                        "--preheat", "10", "--cpu-seconds", "1", "--cli-files", "60"], capture_output=True, text=True,
-                       env=env, timeout=900)
+                        "--preheat", "10", "--cpu-seconds", "1", "--cli-files", "60", "--list-files", "120"],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
@@ -339,6 +373,17 @@ def test_bench_line_carries_every_leg():
     assert d["cli_e2e"]["host_frontend"]["value"] > 50000 and d["cli_e2e"]["gpu_frontend_F"]["value"] > 50000
     if "dropin_reference_cli" in d:
         assert d["dropin_reference_cli"]["value"] > 50000
+    # configs[1]'s own input (EN, 16 kHz lin16, seed 1234, 4096 frames) through the waveform entry
+    assert d["wave_path_en"]["frames"] == 4096 and d["wave_path_en"]["rows_sum_to_one"] is True
+    # the reference's smoke test as a process, beside the reference's CPU build on the same file
+    sf1 = d["single_file"]
+    assert sf1["str"]["process_wall_s"] > 0 and sf1["post"]["process_wall_s"] > 0 and "create_trace_ms" in sf1["str"]
+    if "reference_cpu_mkl" in sf1:
+        assert sf1["reference_cpu_mkl"]["process_wall_s"] > 0
+    # the sharded list (configs[3]'s system and list recipe), with what the host alone can do beside it
+    sl = d["sharded_list"]
+    assert sl["files"] == 120 and sl["gpus"] == 1 and sl["frames_per_s"] > 50000 and sl["mlf_F_equals_F_D"] is True
+    assert sl["host_ceiling"]["frames_per_s"] > 0 and sl["host_ceiling"]["gpu_frontend_F"]["host_cpu_s"] > 0
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
@@ -350,12 +395,17 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["PHNREC_DEVICE_MAP"] = "0,0"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                        "--preheat", "0", "--no-cpu", "--no-extras"], capture_output=True, text=True, env=env, timeout=600)
+                        "--preheat", "0", "--no-cpu", "--no-extras", "--list-files", "150"],
+                       capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks"]["world"] == 2 and line["ranks"]["oversubscribed"] is True
     assert line["ranks"]["device_map"] == [0, 0] and line["n_gpus"] == 1
     assert line["value"] > 0 and line["steps"] == 5
+    # the N-rank line carries the sharded-list figure: `phnrec -g 2` over the ranks' GPUs, and the host's ceiling
+    sl = line["sharded_list"]
+    assert sl["gpus"] == 2 and sl["device_map"] == [0, 0] and sl["files"] == 150
+    assert sl["frames_per_s"] > 50000 and sl["host_ceiling"]["frames_per_s"] > 0 and sl["cores_usable"] >= 1
 
 
 def test_more_gpus_than_the_box_has_fails_loudly(tmp_path):
@@ -375,16 +425,25 @@ def test_four_systems_at_once(tmp_path):
     args, lists = [], {}
     for k, system in enumerate((CZ, HU, RU, EN)):
         lst = _make_list(tmp_path, system[4:6].lower(), 12, seed=10 + k, rate=16000 if system == EN else 8000)
+        with open(lst, "a") as f:                          # + the reference's bundled utterance as a 13th entry
+            f.write(os.path.join(GOLD, "test.raw") + "\n")
         lists[system] = lst
         args += [model_dir(system), str(lst)]
     e = dict(os.environ, PHNREC_GPU_PAIRS="0,0 0,0 0,0 0,0")
     p = subprocess.run(["bash", script] + args + ["-b", "500"], capture_output=True, text=True, env=e, timeout=600)
     assert p.returncode == 0, p.stderr
-    assert p.stderr.count("phnrec: files=12") == 4
+    assert p.stderr.count("phnrec: files=13") == 4
     for system, lst in lists.items():
         mlf = str(lst)[:-4] + ".mlf"
         four = open(mlf).read()
         ref = tmp_path / (system + ".ref.mlf")
         run("-c", model_dir(system), "-l", lst, "-m", ref)
-        assert four == ref.read_text(), system
-        assert four.count("\n.\n") == 12
+        assert four == ref.read_text(), system          # (parity of each system on its own: the tests above)
+        assert four.count("\n.\n") == 13
+        # ... and against the reference itself: the bundled utterance's entry vs the label file SHIPPED with the reference
+        lines = four.splitlines()
+        k = lines.index('"*/test.rec"')
+        entry = [l.split() for l in lines[k + 1:lines.index(".", k)]]
+        gold = [l.split() for l in open(os.path.join(GOLD, "rec", system + ".rec")) if len(l.split()) == 4]
+        assert [(int(x[0]), int(x[1]), x[2]) for x in entry] == [(int(x[0]), int(x[1]), x[2]) for x in gold], system
+        assert max(abs(float(x[3]) - float(y[3])) for x, y in zip(entry, gold)) < 1e-2

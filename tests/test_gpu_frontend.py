@@ -81,8 +81,8 @@ def test_wave_to_posteriors(capi, system):
 
 
 def test_sentence_mean_orders(capi, oracle_mod):
-    """lcrc_set_mean_order: the default fixed-shape tree sums vs the reference's sequential sums (srec.cpp:1500-1511,
-    matrix.h:2101-2116).  Both stay within the bar of the reference's dumps; the tree is batch-invariant (an
+    """lcrc_set_mean_order: the reference's sequential sums (srec.cpp:1500-1511, matrix.h:2101-2116; the default)
+    vs the opt-in fixed-shape tree sums.  Both stay within the bar of the reference's dumps; the tree is batch-invariant (an
     utterance's posteriors do not depend on what else is in the call); on a long utterance (many 256-row blocks)
     both agree with the oracle fed with numpy's own mean-normalised features"""
     raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
@@ -113,6 +113,42 @@ def test_sentence_mean_orders(capi, oracle_mod):
         p, _ = ctx.wave_to_posteriors([long_raw])
         assert p.shape[0] == mel.shape[0]
         assert np.abs(p[rows] - ref).max() < 1e-4, seq
+
+
+def test_default_mean_order_is_the_references(capi):
+    """a fresh context sums the sentence mean in the reference's sequential order (ABI 2): identical bits to an
+    explicit lcrc_set_mean_order(1), and batch-invariant"""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    a = _ctx(capi, CZ)
+    a.set_hidden_split(1)
+    dflt, _ = a.wave_to_posteriors([raw])
+    a.set_mean_order(True)
+    seq, _ = a.wave_to_posteriors([raw])
+    assert np.array_equal(dflt, seq)
+    post, foff = a.wave_to_posteriors([raw[:30000], raw, raw[:100]])
+    assert np.array_equal(post[foff[1]:foff[2]], dflt)
+    a.close()
+
+
+def test_config1_signal_through_the_waveform_entry(capi, oracle_mod):
+    """BASELINE configs[1]'s input as SURVEY 8(d) cfg2 defines it (EN, 16 kHz lin16, 5 sines + noise, seed 1234,
+    4096 frames, posterior-only) through lcrc_wave_to_posteriors -- bench.py's `wave_path_en` leg: every row against
+    the oracle evaluated on the front-end's own features (which test_mel_matches_reference_dump ties to the
+    reference's `-t par` dumps), and the two waveform entries agree bit for bit"""
+    import bench
+    raw = bench.config1_lin16_signal()
+    assert len(raw) == 2 * 655600
+    ctx = _ctx(capi, EN)
+    mel, foff = ctx.wave_to_mel([raw])
+    assert mel.shape == (4096, 23) and list(foff) == [0, 4096]
+    assert 6.0 < float(mel.mean()) < 30.0 and np.isfinite(mel).all()    # log-mel energies of a 0.3 full-scale signal
+    post, _ = ctx.wave_to_posteriors([raw])
+    want = oracle_mod.Oracle(model_dir(EN), 23).posteriors(mel, threads=bench.usable_cpus())   # EN: no sentence mean norm
+    err = np.abs(post - want).max(axis=1)
+    assert post.shape == (4096, 120) and err.max() < 1e-4, (int(err.argmax()), float(err.max()))
+    staged, _ = ctx.wave_to_posteriors_staged([raw])
+    assert np.array_equal(staged, post)
+    ctx.close()
 
 
 def test_front_end_options_vs_host_front_end(capi, tmp_path):

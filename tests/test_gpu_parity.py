@@ -292,10 +292,12 @@ def test_api_errors(capi, tmp_path):
         ctx.posteriors_batch(np.zeros((4, 15), np.float32), np.array([0, 3, 2, 4], np.int32))
 
 
-def test_allocation_failure_leaves_the_context_usable(capi, tmp_path):
+def test_allocation_failure_leaves_the_context_usable(capi, tmp_path, monkeypatch):
     """lcrc_debug_fail_alloc: each of the staging allocations of a host-pointer call fails in turn (device and
     pinned, frame and offset buffers); the call returns LCRC_E_NOMEM, nothing stays half-allocated, and the
-    next call on the same context succeeds with the right result"""
+    next call on the same context succeeds with the right result.  The hook is inert without LCRC_FAULT_INJECTION=1."""
+    assert capi.load().lcrc_debug_fail_alloc(0) == capi.LCRC_E_UNSUPPORTED
+    monkeypatch.setenv("LCRC_FAULT_INJECTION", "1")
     d = str(tmp_path / "m")
     modelgen.write_model_dir(d, 15, 48, 20, seed=8)
     ctx = capi.Lcrc(d, 15)
@@ -378,6 +380,41 @@ def test_baseline_batch_sizes(capi, oracle_mod, system, batch):
     # and each half equals the stand-alone run of that half
     assert np.array_equal(two[:cut], ctx.posteriors(mel[:cut]))
     assert np.array_equal(two[cut:], ctx.posteriors(mel[cut:]))
+
+
+@pytest.mark.parametrize("system,batch", [("PHN_EN_TIMIT_LCRC_N500", 4096), ("PHN_CZ_SPDAT_LCRC_N1500", 8192)])
+def test_baseline_batches_every_row_against_the_oracle(capi, oracle_mod, system, batch):
+    """configs[1] / configs[2] at full size, EVERY row against the oracle (its frames spread over the host's usable
+    cores: a few seconds), for the launch forms a batch of that size can take: the launcher's own choice, forced
+    16- and 32-frame workgroups, and the batch cut into ragged utterances"""
+    import bench
+    spec = modelgen.SYSTEMS[system]
+    nb = spec["nbanks"]
+    mel = modelgen.synth_mel(batch, nb, seed=78, mean_norm=spec["sent_mean_norm"])
+    o = oracle_mod.Oracle(model_dir(system), nb)
+    want = o.posteriors(mel, threads=bench.usable_cpus())
+    assert want.shape[0] == batch and np.abs(want.sum(axis=1) - 1).max() < 1e-4
+    ctx = capi.Lcrc(model_dir(system), nb)
+    for frames in (0, 16, 32):
+        ctx.set_tile_frames(frames)
+        err = np.abs(ctx.posteriors(mel) - want).max(axis=1)
+        assert err.max() < TOL, (frames, int(err.argmax()), float(err.max()))
+    ctx.set_tile_frames(0)
+    rng = np.random.default_rng(3)
+    cuts = np.sort(rng.choice(np.arange(1, batch), size=23, replace=False))
+    off = np.concatenate([[0], cuts, [batch]]).astype(np.int32)
+    want_b = np.concatenate([o.posteriors(mel[a:b], threads=bench.usable_cpus()) for a, b in zip(off[:-1], off[1:])])
+    assert np.abs(ctx.posteriors_batch(mel, off) - want_b).max() < TOL
+    ctx.close()
+
+
+def test_fuzzed_models(capi, oracle_mod):
+    """tools/fuzz_parity.py with a fixed seed: 30 random model geometries (run-time-shape kernels: banks, hidden sizes,
+    outputs, ragged batches with empty utterances, 16- / 32-frame workgroups, forced hidden splits) and 12 models of
+    the shipped shape classes in the split-f16 arithmetic -- each against the oracle at the 1e-4 bar"""
+    from tools import fuzz_parity
+    ran, worst, worst_s, worst_d = fuzz_parity.fuzz(seed=20261004, n_models=30, n_h2=12, log=lambda *a: None)
+    assert ran >= 20 and worst < TOL and worst_s < TOL and worst_d < 5e-5
 
 
 def test_sharded_file_list_shape(capi, oracle_mod, tmp_path):
@@ -733,8 +770,9 @@ def test_split_f16_streaming_rows_and_large_launch(capi, oracle_mod):
 
 
 def test_split_f16_refused_where_it_does_not_exist(capi, tmp_path):
-    """run-time-shape models and weights beyond f16's range have no split-f16 form: LCRC_E_UNSUPPORTED, the context
-    stays on the f32 kernels; normalised inputs beyond f16's range are clamped"""
+    """run-time-shape models have no split-f16 kernels: LCRC_E_UNSUPPORTED, the context stays on the f32 kernels.  Weights of
+    any finite size DO have the form (each matrix is scaled by a power of two before it is split); normalised inputs beyond
+    +-1023 are clamped"""
     d = str(tmp_path / "gen")
     modelgen.write_model_dir(d, 13, 64, 40, seed=2)
     g = capi.Lcrc(d, 13)
@@ -747,20 +785,34 @@ def test_split_f16_refused_where_it_does_not_exist(capi, tmp_path):
     assert np.array_equal(g.posteriors(mel), before)
     with pytest.raises(capi.LcrcError):
         g.set_arithmetic(7)
-    # a shipped shape with one weight of 1e5
+    # a shipped shape with one weight of 1e5 (beyond f16's range as it stands): scaled into range, same bar
     d2 = str(tmp_path / "big")
     modelgen.write_model_dir(d2, 15, 64, 138, seed=3)
     from oracle import binding as ob
     net = ob.Net(nbin=os.path.join(d2, "weights", "band0.nbin"))
     w = np.ctypeslib.as_array(net.n.W1, shape=(net.n.nHid16, net.n.nInp16))
     w[3, 5] = 1.0e5
+    # (its input is made tiny so that the product stays inside FEXP's sane range: beyond |x| ~ 700 the reference's own
+    #  sigmoid is garbage that no other arithmetic reproduces)
+    np.ctypeslib.as_array(net.n.dev, shape=(net.n.nInp16,))[5] = 1.0e-8
     net.save_nbin(os.path.join(d2, "weights", "band0.nbin"))
     g2 = capi.Lcrc(d2, 15)
+    g2.set_arithmetic(capi.ARITH_SPLIT_F16)
+    mel2 = modelgen.synth_mel(80, 15, seed=12)
+    assert np.abs(g2.posteriors(mel2) - ob.Oracle(d2, 15).posteriors(mel2)).max() < TOL
+    # a non-finite weight has no such form
+    d4 = str(tmp_path / "nan")
+    modelgen.write_model_dir(d4, 15, 64, 138, seed=3)
+    net = ob.Net(nbin=os.path.join(d4, "weights", "merger.nbin"))
+    w = np.ctypeslib.as_array(net.n.W2, shape=(net.n.nOut16, net.n.nHid16))
+    w[1, 2] = np.inf
+    net.save_nbin(os.path.join(d4, "weights", "merger.nbin"))
+    g4 = capi.Lcrc(d4, 15)
     with pytest.raises(capi.LcrcError) as e:
-        g2.set_arithmetic(capi.ARITH_SPLIT_F16)
+        g4.set_arithmetic(capi.ARITH_SPLIT_F16)
     assert e.value.code == capi.LCRC_E_UNSUPPORTED
-    # large inputs inside f16's range: FEXP's tails as in the f32 kernels; beyond it (no audio gets there) the normalised
-    # input is clamped at +-65504 -- finite, normalised posteriors, a documented deviation
+    # large inputs: FEXP's tails as in the f32 kernels; beyond +-1023 (no audio gets there) the normalised input is
+    # clamped -- finite, normalised posteriors, a documented deviation
     d3 = str(tmp_path / "ok")
     modelgen.write_model_dir(d3, 15, 64, 138, seed=3)
     o3 = ob.Oracle(d3, 15)
@@ -775,3 +827,28 @@ def test_split_f16_refused_where_it_does_not_exist(capi, tmp_path):
     got = g3.posteriors(mel)
     assert np.isfinite(got).all() and np.abs(got.sum(axis=1) - 1).max() < 1e-5
     assert np.abs(got[40:] - o3.posteriors(mel)[40:]).max() < TOL          # rows whose context holds no such frame
+
+
+@pytest.mark.parametrize("scale", [1.0e-3, 8.0])
+def test_split_f16_keeps_its_precision_for_small_and_large_weights(capi, tmp_path, scale):
+    """The (high, low) f16 split holds 22 bits only while the low half is a normal f16; the packer therefore scales every
+    weight matrix by a power of two first.  A model whose weights are 1e-3 (or 8) times the usual size must come out
+    as close to the oracle in the split-f16 arithmetic as on the f32 kernels (unscaled, the 1e-3 model would lose ten
+    bits of every weight: an error floor ~1e-6 in the pre-activations, against ~1e-8 in f32)."""
+    from oracle import binding as ob
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 96, 138, seed=21)
+    for name in ("band0", "band1", "merger"):
+        f = os.path.join(d, "weights", name + ".nbin")
+        net = ob.Net(nbin=f)
+        for arr, shape in ((net.n.W1, (net.n.nHid16, net.n.nInp16)), (net.n.W2, (net.n.nOut16, net.n.nHid16))):
+            np.ctypeslib.as_array(arr, shape=shape)[:] *= np.float32(scale)
+        net.save_nbin(f)
+    mel = modelgen.synth_mel(200, 15, seed=5)
+    want = ob.Oracle(d, 15).posteriors(mel)
+    g = capi.Lcrc(d, 15)
+    err32 = float(np.abs(g.posteriors(mel) - want).max())
+    g.set_arithmetic(capi.ARITH_SPLIT_F16)
+    err16 = float(np.abs(g.posteriors(mel) - want).max())
+    assert err16 < TOL and err16 <= 4.0 * err32 + 2e-7, (err16, err32)
+    g.close()

@@ -60,3 +60,25 @@ def test_pairs_hold_22_bits_and_subnormal_tails():
     # a product of two f16 values is exact in f32
     a, b = _f16(rng.standard_normal(1000)), _f16(rng.standard_normal(1000))
     assert np.array_equal((a * b).astype(np.float32).astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+
+
+def test_power_of_two_scaling_restores_the_split_for_small_operands():
+    """What lcrc_set_arithmetic's packer does about the subnormal tails (pack_net_h2, mlp_dev.h "Operand scaling"): a
+    1500-term product with weights of ~0.005 and activations in (0, 1).  Split as they stand, the low halves are f16
+    subnormals and the error floor is ~1e-6 however small the weights; scaled by powers of two first (largest weight into
+    (2^13, 2^14], activations by 2^14) and scaled back exactly, the split is again as good as the f32 chain."""
+    rng = np.random.default_rng(7)
+    k = 1500
+    w = (rng.standard_normal((k, 64)) * 0.005).astype(np.float32)
+    s = rng.uniform(0.0, 1.0, (32, k)).astype(np.float32)
+    exact = s.astype(np.float64) @ w.astype(np.float64)
+    three = [(0, 0), (0, 1), (1, 0)]
+    err_f32 = np.abs(np.float32(s) @ np.float32(w) - exact).max()
+    err_raw = np.abs(_split_product(s, w, _f16, three) - exact).max()
+    e_w = 14 - int(np.floor(np.log2(np.abs(w).max())) + 1)            # max|w| * 2^e in [2^13, 2^14)
+    ws, ss = w * np.float32(2.0 ** e_w), s * np.float32(2.0 ** 14)
+    assert 2.0 ** 13 <= np.abs(ws).max() < 2.0 ** 14
+    err_scaled = np.abs(_split_product(ss, ws, _f16, three) * 2.0 ** -(e_w + 14) - exact).max()
+    assert err_raw > 5e-7                       # the floor the unscaled split runs into
+    assert err_scaled < err_raw / 20.0          # gone
+    assert err_scaled < 2.0 * err_f32 + 1e-9    # back at the f32 chain's own rounding

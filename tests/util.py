@@ -32,7 +32,7 @@ def write_htk(path, a, period=100000, kind=6):
 
 
 def model_dir(system):
-    """Real model directory shipped as test data (CZ and EN only)."""
+    """Real model directory shipped as test data (all four LCRC systems: CZ, HU, RU, EN); None if absent."""
     p = os.path.join(GOLD, "models", system)
     return p if os.path.isdir(p) else None
 
