@@ -20,6 +20,7 @@ struct Label {
 class PhnDec {
 public:
     bool LoadPhnList(const std::string &path);            // one symbol per line (phndec.cpp:305-349)
+    void SetPhonemes(const std::vector<std::string> &names) { phn_ = names; }
     void SetStatesPerPhn(int n) { S_ = n; }
     void SetTimePruning(int n) { prune_ = n; }
     void SetWPenalty(float p) { wpen_ = p; }
@@ -35,10 +36,18 @@ private:
     std::vector<std::string> phn_;
     int S_ = 1, prune_ = 50, nframes_ = 0;
     float wpen_ = 0.0f, prev_alpha_ = 0.0f;
-    std::vector<float> alpha_;      // [nphn][S+1]
-    std::vector<int> prev_, len_;   // [nphn][S+1]
-    std::vector<int> hphn_, hlen_;  // [prune+1] history of network-level winners
+    // Token slots state-major: slot (state j, phoneme i) at j * Pp_ + i, Pp_ = the phoneme count padded to the vector
+    // width -- the state update is then one straight run over the phonemes per state (compare, select, add: it
+    // vectorises), with the same f32 additions and the same tie rules as the reference's phoneme-major loops.
+    // Pad slots hold -FLT_MAX and never win a strict comparison.
+    int Pp_ = 0;
+    std::vector<float> alpha_;      // [S+1][Pp]
+    std::vector<int> prev_, len_;   // [S+1][Pp]
+    std::vector<float> obs_;        // [S][Pp] this frame's log-posteriors, state-major
+    // history of the network-level winners of the last prune+1 frames: a ring, slot of column c = (hpos_ + c) % cols
+    std::vector<int> hphn_, hlen_;
     std::vector<float> halpha_;
+    int hpos_ = 0;
     std::vector<Label> labels_;
 };
 

@@ -280,6 +280,7 @@ bool SpeechRec::Init(const std::string &config_file)
             snprintf(msg, sizeof msg, "Can not load phoneme list: %s", phoneme_list_.c_str());
             return Fail(msg);
         }
+        phn_names_ = probe.Names();          // read once: every utterance's decoder starts from this copy
     }
     if (!wpenalty_set_) wpenalty_ = C.GetFloat("decoder", "wpenalty");
     if (C.GetString("decoder", "mode") == "kws") return Fail("decoder/mode=kws needs the STK decoder, which is outside this path\n");
@@ -350,8 +351,8 @@ std::string SpeechRec::SetUpContext(Traps &t)
     return std::string();
 }
 
-// Contexts: `per_gpu` on each of the -g N GPUs.  A list wants two per GPU (while one's launch is in flight the
-// other stages / decodes / writes); one file wants one.  The first context of a GPU loads the model (GPUs in
+// Contexts: `per_gpu` on each of the -g N GPUs.  A list wants three per GPU (kernel, copy-back and decoding of
+// successive launches overlap); one file wants one.  The first context of a GPU loads the model (GPUs in
 // parallel: one thread each), further ones share its weights on the device (lcrc_clone: no file reads, no
 // packing, no upload).
 bool SpeechRec::EnsureGpus(int per_gpu)
@@ -515,7 +516,7 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
     else if (dec_soft_ == "log") for (size_t i = 0; i < nvals; i++) post[i] = logf(post[i]);
     else for (size_t i = 0; i < nvals; i++) post[i] = Soften(dec_soft_, post[i], dec_soft_arg_);
     PhnDec dec;
-    dec.LoadPhnList(phoneme_list_);
+    dec.SetPhonemes(phn_names_);
     dec.SetStatesPerPhn(states_per_phn_);
     dec.SetTimePruning(time_pruning_);
     dec.SetWPenalty(wpenalty_);
@@ -583,7 +584,7 @@ bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job
 //   feeder (the calling thread)  parses lines and queues stage 1 of each job on the pool: file read [+ host
 //                                front-end + sentence norm]; with -F only a stat() -- the files are then read
 //                                straight into the launching context's pinned byte buffer
-//   GPU workers (one thread per context, two contexts per GPU) each take the next launch -- the longest run of
+//   GPU workers (one thread per context, three contexts per GPU) each take the next launch -- the longest run of
 //                                consecutive staged jobs within batch_frames_ --, gather, run the kernel(s), and
 //                                decode / dump the launch's utterances on the pool (chunks of a blocked worker run
 //                                ahead of queued stage-1 tasks)
@@ -612,7 +613,9 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
-        if (!EnsureGpus(single_file ? 1 : 2)) return false;
+        // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the
+        // kernel itself at 186 outputs per frame) and the third's utterances are decoded (profiles/r03_cli_contexts.txt)
+        if (!EnsureGpus(single_file ? 1 : 3)) return false;
     }
     const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
     std::vector<std::string> phn_names;
@@ -623,11 +626,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         for (auto &g : gpus_)
             if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
         // -D: the decoder runs behind the posterior kernel and only labels cross PCIe
-        if (dev_dec) {
-            PhnDec names;
-            if (!names.LoadPhnList(phoneme_list_)) return Fail("Can not open the phoneme list: " + phoneme_list_ + "\n");
-            phn_names = names.Names();
-        }
+        if (dev_dec) phn_names = phn_names_;
         for (auto &g : gpus_)
             if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
                 return Fail(g->LastError() + "\n");

@@ -130,6 +130,7 @@ private:
     float post_soft_arg_[3] = {0, 0, 0}, dec_soft_arg_[3] = {0, 0, 0};
     std::vector<std::string> phonemes_path_;
     std::string phoneme_list_;
+    std::vector<std::string> phn_names_;              // dicts/phoneme_list, read once in Init
     std::vector<std::unique_ptr<Traps>> gpus_;        // [context k of GPU g] at k * n_gpus + g
     std::vector<int> gpu_devices_;                    // physical device of each logical GPU (PHNREC_DEVICE_MAP)
     std::unique_ptr<ThreadPool> pool_;

@@ -1477,10 +1477,11 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
     if (!c->hist_init) c->ring_rows = 0;
-    // Large pushes (the offline main call of srec.cpp:1048 hands over a whole utterance) go through the device staging
+    // Very large pushes (the offline main call of srec.cpp:1048 hands over a whole utterance) go through the device staging
     // buffers -- [history | frames] copied at PCIe rate, the kernel on HBM -- instead of the kernel reading the frames from
-    // and writing the posteriors to mapped host memory row by row; the strip then only keeps the new history.
-    constexpr int kPushStagedMin = 256;
+    // and writing the posteriors to mapped host memory row by row; the strip then only keeps the new history.  Up to a few
+    // thousand frames the mapped strip wins (512 frames: 70 us against 81 us with the two explicit copies).
+    constexpr int kPushStagedMin = 4096;
     if (needed && c->system == SYS_LCRC && n >= kPushStagedMin && c->hist_init) {
         int rc = ensure_staging(c, H + (size_t)n, 1);
         if (rc) return rc;

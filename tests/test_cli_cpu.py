@@ -209,3 +209,42 @@ def test_long_list_leaves_in_list_order(tmp_path, threads, batch):
     mlf = tmp_path / "out.mlf"
     run("-c", model_dir(CZ), "-s", "post", "-l", lst, "-m", mlf, "-j", threads, "-b", batch)
     assert mlf.read_text() == "#!MLF!#\n" + "".join(entries[n] for n in order)
+
+
+@pytest.mark.parametrize("P,S,prune", [(5, 1, 40), (17, 2, 12), (40, 3, 40), (62, 3, 40), (33, 4, 25), (64, 3, 7), (8, 3, 40)])
+def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, S, prune):
+    """The host Viterbi runs state-major, eight phonemes at a time on AVX2 (and as plain C++ with PHNREC_NO_AVX2=1): both
+    must write exactly what the decoder oracle (the restatement of phndec.cpp:96-303 that reproduces the reference's
+    .rec files) gives -- on posteriors drawn from FOUR values, so that ties between tokens (first strict maximum,
+    phoneme-major order) occur all the time -- for phoneme counts around the vector width, 1-4 states, short horizons"""
+    from oracle import binding as ob
+    from tests.util import write_htk
+    rng = np.random.default_rng(P * 100 + S)
+    d = tmp_path / "m"
+    shutil.copytree(model_dir(CZ), d)
+    cfg, section = (d / "config").read_text().splitlines(True), None
+    for i, line in enumerate(cfg):
+        if line.startswith("["):
+            section = line.strip()
+        if section == "[decoder]" and line.startswith("num_states_per_phn="):
+            cfg[i] = "num_states_per_phn=%d\n" % S
+        if section == "[decoder]" and line.startswith("time_pruning="):
+            cfg[i] = "time_pruning=%d\n" % prune
+    (d / "config").write_text("".join(cfg))
+    (d / "dicts" / "phonemes").write_text("".join("q%d\n" % i for i in range(P)))
+    wpen = -4.6875                                                  # PHN_CZ's decoder/wpenalty
+    for trial, T in enumerate((1, 3, prune, prune + 1, 300)):
+        post = rng.choice(np.array([0.5, 0.25, 0.125, 1e-3], np.float32), size=(T, P * S))
+        hold = rng.integers(0, P * S, size=T // 6 + 1)
+        for t in range(T):                                          # a token that stays a few frames, like speech
+            post[t, hold[t // 6]] = 0.5
+        lop = tmp_path / ("t%d.lop" % trial)
+        write_htk(str(lop), post)
+        want = ob.phndec(np.log(post), P, S, prune, wpen)
+        text = "".join("%d00000 %d00000 q%d %f\n" % (a, b, p, s) for a, b, p, s in want)
+        for env in ({}, {"PHNREC_NO_AVX2": "1"}):
+            rec = tmp_path / "o.rec"
+            p = subprocess.run([BIN, "-c", str(d), "-s", "post", "-i", str(lop), "-o", str(rec)], capture_output=True,
+                               text=True, env=dict(os.environ, **env))
+            assert p.returncode == 0, p.stderr
+            assert rec.read_text() == text, (T, env)

@@ -829,10 +829,10 @@ def test_split_f16_refused_where_it_does_not_exist(capi, tmp_path):
     assert np.abs(got[40:] - o3.posteriors(mel)[40:]).max() < TOL          # rows whose context holds no such frame
 
 
-@pytest.mark.parametrize("scale", [1.0e-3, 8.0])
+@pytest.mark.parametrize("scale", [1.0e-3, 4.0])
 def test_split_f16_keeps_its_precision_for_small_and_large_weights(capi, tmp_path, scale):
     """The (high, low) f16 split holds 22 bits only while the low half is a normal f16; the packer therefore scales every
-    weight matrix by a power of two first.  A model whose weights are 1e-3 (or 8) times the usual size must come out
+    weight matrix by a power of two first.  A model whose weights are 1e-3 (or 4) times the usual size must come out
     as close to the oracle in the split-f16 arithmetic as on the f32 kernels (unscaled, the 1e-3 model would lose ten
     bits of every weight: an error floor ~1e-6 in the pre-activations, against ~1e-8 in f32)."""
     from oracle import binding as ob
