@@ -168,6 +168,9 @@ int fail(lcrc_ctx *c, int code, const std::string &msg)
             return fail(ctx, LCRC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// (the copy is queued on the context's stream: a synchronous hipMemcpy from pageable memory costs a fresh process twice as
+//  much -- 17 ms against 8 ms for the first 6.6 MB, tools/ubench/hip_upload -- and every later use of the buffer is
+//  ordered behind it on that stream anyway; the creating call synchronises once before it hands the context out)
 template <typename T>
 hipError_t dev_upload(lcrc_ctx *c, const std::vector<T> &h, const T **out)
 {
@@ -175,7 +178,8 @@ hipError_t dev_upload(lcrc_ctx *c, const std::vector<T> &h, const T **out)
     hipError_t e = hipMalloc(&d, h.size() * sizeof(T));
     if (e != hipSuccess) return e;
     c->model->allocs.push_back(d);
-    e = hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // pageable source: staged by the call; the wait is short
     *out = static_cast<const T *>(d);
     return e;
 }

@@ -95,10 +95,13 @@ __device__ __forceinline__ f4 split_sum(const f4 *src, size_t stride, int n_part
 }
 
 // SPLIT = false: the fused kernel, one workgroup per frame tile, everything up to the posteriors.
-// SPLIT = true:  band phase of the split-hidden path (small launches): p.split_b workgroups per frame tile,
-//                each runs stages 0/1 and its slice of the band nets' hidden tiles; the last arriver of a tile
-//                adds the partial output tiles, runs the band softmax and hands the merger's operand image to
-//                lcrc_split_merger_kernel through p.gimg.
+// SPLIT = true:  band phase of the split-hidden path (small launches): every frame tile has 2 * p.split_b workgroups,
+//                p.split_b per BAND NET; each runs stages 0/1 for its net only and its slice of that net's hidden
+//                tiles on all four waves.  With one slice per net (the 1025-2048-frame launches) the workgroup owns
+//                the whole net: softmax, ln() and the merger's normalisation follow at once and there is no seam at
+//                all; with more slices the last arriver of a (tile, net) adds the partial output tiles first.  The
+//                normalised band outputs go to p.gimg ([tile][net][16 frames][16 * n_ot]), from which
+//                lcrc_split_merger_kernel builds its operand image.
 // PROBES = true: the diagnostic instantiation behind lcrc_posteriors_probe (stage outputs to global memory);
 //                the production kernels carry no trace of it (as run-time branches the probe stores cost ~30 % of
 //                the band nets' epilogue: their 64-bit address arithmetic was executed for every value).
@@ -142,9 +145,10 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     float *gf = reinterpret_cast<float *>(smem + lp.gf);
     f4 *slab = reinterpret_cast<f4 *>(smem + lp.slab);
 
-    const int split = SPLIT ? p.split_b : 1;
-    const int tile = SPLIT ? (int)blockIdx.x / split : (int)blockIdx.x;
-    const int sp = SPLIT ? (int)blockIdx.x - tile * split : 0;
+    const int split = SPLIT ? p.split_b : 1;                   // slices per band net
+    const int tile = SPLIT ? (int)blockIdx.x / (2 * split) : (int)blockIdx.x;
+    const int snet = SPLIT ? ((int)blockIdx.x - tile * 2 * split) / split : 0;       // this workgroup's band net
+    const int sp = SPLIT ? (int)blockIdx.x - (tile * 2 + snet) * split : 0;
     const int r0 = p.row_first + tile * BM;
     const int tbase = r0 - kShift;
 
@@ -279,66 +283,74 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         const int cc = min(c, kNCoef - 1);       // loads below stay unconditional (clamped index)
         // The clamped source rows of a lane's taps depend on the half context (n) only, not on the band:
         // their tile offsets and the window values are formed once, an item adds its band.
-        int roff[2][FT][4];
-        float wv[2][4];
+        // NN half contexts per workgroup: both (fused kernel), or the one of this workgroup's band net (split path);
+        // slot q of the arrays below is half context nq = n_base + q.
+        constexpr int NN = SPLIT ? 1 : 2;
+        const int n_base = SPLIT ? snet : 0;
+        int roff[NN][FT][4];
+        float wv[NN][4];
 #pragma unroll
-        for (int n = 0; n < 2; n++)
+        for (int q = 0; q < NN; q++)
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
-                const int tap = 4 * s4 + g;
-                wv[n][s4] = win[n * kHalf + tap];
+                const int tap = 4 * s4 + g, n = n_base + q;
+                wv[q][s4] = win[n * kHalf + tap];
 #pragma unroll
                 for (int f = 0; f < FT; f++) {
                     const int srow = max(lo[f], min(hi[f], rr[f] + n * kShift + tap));
-                    roff[n][f][s4] = (srow - tbase) * nb;
+                    roff[q][f][s4] = (srow - tbase) * nb;
                 }
             }
-        // Bands are dealt to the waves; an item is one band's LEFT and RIGHT half context together (2 * FT independent
-        // MFMA chains: with 16-frame workgroups one half alone is a single dependent chain of four).  The operand values and
-        // the normalisation constants of band b + NW are requested (independent LDS reads) before the MFMAs of band b:
-        // the compiler cannot move LDS reads above the previous item's operand-image stores by itself.
+        // Bands are dealt to the waves; an item is one band's half contexts together (NN * FT independent MFMA chains).
+        // The operand values and the normalisation constants of band b + NW are requested (independent LDS reads) before
+        // the MFMAs of band b: the compiler cannot move LDS reads above the previous item's operand-image stores by itself.
         {
-            const float *mean0 = nrm_band, *dev0 = mean0 + 16 * nkq1, *mean1 = nrm_band + 32 * nkq1, *dev1 = mean1 + 16 * nkq1;
-            auto gather = [&](int b, float (&x)[2][FT][4], float (&mk)[2], float (&dk)[2]) {
+            // (offsets, not pointers: through an array of pointers hipcc loses the LDS address space)
+            int mofs[NN];
+#pragma unroll
+            for (int q = 0; q < NN; q++) mofs[q] = (n_base + q) * 32 * nkq1;
+            auto gather = [&](int b, float (&x)[NN][FT][4], float (&mk)[NN], float (&dk)[NN]) {
                 const int bc = min(b, nb - 1);
 #pragma unroll
-                for (int n = 0; n < 2; n++)
+                for (int q = 0; q < NN; q++) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                        for (int f = 0; f < FT; f++) x[n][f][s4] = melT[roff[n][f][s4] + bc] * wv[n][s4];
-                mk[0] = mean0[bc * kNCoef + cc]; dk[0] = dev0[bc * kNCoef + cc];
-                mk[1] = mean1[bc * kNCoef + cc]; dk[1] = dev1[bc * kNCoef + cc];
+                        for (int f = 0; f < FT; f++) x[q][f][s4] = melT[roff[q][f][s4] + bc] * wv[q][s4];
+                    mk[q] = nrm_band[mofs[q] + bc * kNCoef + cc];
+                    dk[q] = nrm_band[mofs[q] + 16 * nkq1 + bc * kNCoef + cc];
+                }
             };
-            float xw[2][FT][4], xn[2][FT][4], mk[2], dk[2], mkn[2], dkn[2];
+            float xw[NN][FT][4], xn[NN][FT][4], mk[NN], dk[NN], mkn[NN], dkn[NN];
             gather(wave, xw, mk, dk);
             for (int b = wave; b < nb; b += NW) {
                 gather(b + NW, xn, mkn, dkn);
                 const int k = b * kNCoef + cc;
-                f4 acc[2][FT];
+                f4 acc[NN][FT];
 #pragma unroll
-                for (int n = 0; n < 2; n++)
+                for (int q = 0; q < NN; q++)
 #pragma unroll
-                    for (int f = 0; f < FT; f++) acc[n][f] = (f4){0.f, 0.f, 0.f, 0.f};
+                    for (int f = 0; f < FT; f++) acc[q][f] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
-                    for (int n = 0; n < 2; n++)
+                    for (int q = 0; q < NN; q++)
 #pragma unroll
-                        for (int f = 0; f < FT; f++) acc[n][f] = mfma16x16x4(xw[n][f][s4], basis[s4], acc[n][f]);
+                        for (int f = 0; f < FT; f++) acc[q][f] = mfma16x16x4(xw[q][f][s4], basis[s4], acc[q][f]);
                 if (c < kNCoef) {                    // D layout: row = frame 16f + 4g + reg, col = c
                     // B-image address of (frame fr, input k): see xf_store; only `fr` varies below
                     const int kbase = (((k >> 4) * 64) + 16 * (k & 3)) * 4 + ((k >> 2) & 3);
 #pragma unroll
-                    for (int n = 0; n < 2; n++) {
+                    for (int q = 0; q < NN; q++) {
+                        const int n = n_base + q;
                         float *img = xf + (size_t)n * (FT * nkq1 * 256);
 #pragma unroll
                         for (int f = 0; f < FT; f++) {
 #pragma unroll
                             for (int reg = 0; reg < 4; reg++) {
-                                const float val = acc[n][f][reg] * normc;        // CalcC0 / sDCT scaling
-                                float v = val - mk[n];                           // Normalize nn.cpp:702-716
-                                v *= dk[n];
+                                const float val = acc[q][f][reg] * normc;        // CalcC0 / sDCT scaling
+                                float v = val - mk[q];                           // Normalize nn.cpp:702-716
+                                v *= dk[q];
                                 if constexpr (ARITH == 1)
                                     h2_img_store(img, f * (2 * NS1 * 1024) + (4 * g + reg) * 16 + h2_k_ofs(k), NS1 * 1024, v);
                                 else img[f * nkq1 * 256 + (4 * g + reg) * 4 + kbase] = v;
@@ -351,19 +363,19 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
                                 for (int reg = 0; reg < 4; reg++) {
                                     const int fr = 16 * f + 4 * g + reg;
-                                    if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[n][f][reg] * normc;
+                                    if (r0 + fr < row_end) dbg[(size_t)(r0 + fr) * K + k] = acc[q][f][reg] * normc;
                                 }
                         }
                     }
                 }
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
+                for (int q = 0; q < NN; q++) {
 #pragma unroll
                     for (int f = 0; f < FT; f++)
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; s4++) xw[n][f][s4] = xn[n][f][s4];
-                    mk[n] = mkn[n];
-                    dk[n] = dkn[n];
+                        for (int s4 = 0; s4 < 4; s4++) xw[q][f][s4] = xn[q][f][s4];
+                    mk[q] = mkn[q];
+                    dk[q] = dkn[q];
                 }
             }
         }
@@ -430,46 +442,65 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
             }
         };
         if constexpr (SPLIT) {
-            // ---- band phase of the split-hidden path: this workgroup's slice of both nets' hidden tiles ----
+            // ---- band phase of the split-hidden path: slice `sp` of band net `snet`'s hidden tiles, on all four waves ----
             constexpr int NTH = NW * 64;
-            const int grp = wave / 2, wig = wave % 2;           // waves 0,1: left context; 2,3: right context
-            const NetDev &nd = p.net[grp];
+            constexpr int OV = EXACT ? 16 * (NOT - 1) : 0;
+            const NetDev &nd = p.net[snet];
             const int hbeg = min(nd.nht, sp * p.tps_b), hend = min(nd.nht, hbeg + p.tps_b);
-            const int tpw = (hend - hbeg + 1) / 2;
-            const int ht0 = hbeg + wig * tpw;
+            const int tpw = (hend - hbeg + NW - 1) / NW;
+            const int ht0 = hbeg + wave * tpw;
             const int slab_f4 = FT * n_ot * 64;
             f4 *const slab23 = reinterpret_cast<f4 *>(smem + lp.slab23);
             {
                 f4 acc[NOT][FT];
-                hidden_range<KS1, NOT, EXACT, FT>(nd, reinterpret_cast<const f4 *>(xf) + (size_t)grp * (FT * nkq1 * 64), ht0,
-                                                  min(hend, ht0 + tpw), sp == 0 && wig == 0, lane, acc);
+                hidden_range<KS1, NOT, EXACT, FT>(nd, reinterpret_cast<const f4 *>(xf) + (size_t)snet * (FT * nkq1 * 64), min(hend, ht0),
+                                                  min(hend, ht0 + tpw), sp == 0 && wave == 0, lane, acc);
                 __syncthreads();                                 // slab23 lies over the operand images
-                store_partial<NOT, EXACT, FT>((grp == 0 ? slab : slab23) + wig * slab_f4, EXACT ? NOT : nd.n_ot, lane, acc);
+                store_partial<NOT, EXACT, FT>((wave < 2 ? slab : slab23) + (wave & 1) * slab_f4, EXACT ? NOT : nd.n_ot, lane, acc);
                 __syncthreads();
             }
-            // the workgroup's partial tiles (wave 0 + wave 1 per net) leave as whole 1-KiB write-through wave stores
-            const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * 2 * slab_f4, 0, 2 * slab_f4 * 16, 0x00020000);
-            for (int i = tid; i < 2 * slab_f4; i += NTH) {
-                const int gq = i >= slab_f4 ? 1 : 0, j = i - gq * slab_f4;
-                const f4 *b = gq ? slab23 : slab;
-                store_through(b[j] + b[slab_f4 + j], mine, i);
-            }
-            int *const ticket = reinterpret_cast<int *>(smem + lp.total);
-            if (!split_arrive(p.cnt + 2 * tile, split, ticket, tid)) return;
-            // last arriver: add the tile's partials in slice order, then softmax + ln() as in the fused kernel
-            const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)tile * split * 2 * slab_f4;
-            for (int i = tid; i < 2 * slab_f4; i += NTH) {
-                const int gq = i >= slab_f4 ? 1 : 0, j = i - gq * slab_f4;
-                (gq ? slab23 : slab)[j] = split_sum(first + i, (size_t)2 * slab_f4, split);
-            }
-            __syncthreads();
+            // Row epilogue: a lane's band posteriors of frame i -> ln(), the merger's normalisation (its mean / dev of
+            // inputs snet * O0 + o) -> the (tile, net) block of p.gimg, rows of 16 * n_ot floats
+            const int OP = 16 * n_ot;
+            float *const blk = reinterpret_cast<float *>(p.gimg) + (size_t)(tile * 2 + snet) * (BM * OP);
+            auto epi_split = [&](int, int i, int part, auto lpf, const auto &q, int O) {
+                constexpr int LPF = decltype(lpf)::value;
+                constexpr int NV = sizeof(q) / sizeof(float);
+                const int kb = snet * O0 + part;
+                float gl[NV], mk[NV], dk[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) {                       // (reads past n_inp stay inside the padded arrays)
+                    mk[j] = mmean[kb + LPF * j];
+                    dk[j] = mdev[kb + LPF * j];
+                }
+#pragma unroll
+                for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? logf(q[j]) : 0.0f;     // sLn dspc.h:155-160
+                float *const row = blk + i * OP + part;
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    float v = gl[j] - mk[j];                         // Normalize nn.cpp:702-716
+                    v *= dk[j];
+                    if ((EXACT && LPF * j + LPF <= OV) || part + LPF * j < O) row[LPF * j] = v;
+                }
+            };
             const float *s01 = reinterpret_cast<const float *>(slab), *s23 = reinterpret_cast<const float *>(slab23);
-            softmax_rows<NOT, NW, FT, 2, 1, (EXACT ? 16 * (NOT - 1) : 0)>(p, p.net, s01, s01, s01, s01, s23, s23, lane, wave, epi);
+            if (split == 1) {
+                // the whole net is here: the four waves' partial tiles are added while the softmax reads them -- no seam
+                softmax_rows<NOT, NW, FT, 1, 4, OV>(p, &nd, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi_split);
+                return;
+            }
+            // the workgroup's partial tile ((wave 0 + 1) + (wave 2 + 3)) leaves as whole 1-KiB write-through wave stores
+            const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * slab_f4, 0, slab_f4 * 16, 0x00020000);
+            for (int i = tid; i < slab_f4; i += NTH)
+                store_through((slab[i] + slab[slab_f4 + i]) + (slab23[i] + slab23[slab_f4 + i]), mine, i);
+            int *const ticket = reinterpret_cast<int *>(smem + lp.total);
+            if (!split_arrive(p.cnt + 4 * tile + snet, split, ticket, tid)) return;
+            // last arriver of (tile, net): add the slices' partials in slice order, then softmax + ln()
+            const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)(tile * 2 + snet) * split * slab_f4;
+            for (int i = tid; i < slab_f4; i += NTH) slab[i] = split_sum(first + i, (size_t)slab_f4, split);
             __syncthreads();
-            f4 *const dst = reinterpret_cast<f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
-            const f4 *const src = reinterpret_cast<const f4 *>(gf);
-            for (int i = tid; i < FT * nkqm * 64; i += NTH) dst[i] = src[i];
+            softmax_rows<NOT, NW, FT, 1, 1, OV>(p, &nd, s01, s01, s01, s01, s01, s01, lane, wave, epi_split);
             return;
         } else {
         // (the sequential alternative -- one band net after the other on four waves -- was 1.6-3 % slower in
@@ -545,8 +576,19 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
     const int r0 = p.row_first + tile * BM;
 
     {
-        const f4 *const src = reinterpret_cast<const f4 *>(p.gimg) + (size_t)tile * (FT * nkqm * 64);
-        for (int i = tid; i < FT * nkqm * 64; i += NT) gf[i] = src[i];
+        // operand image from the band phase's outputs ([tile][net][16 frames][16 * n_ot_band], already ln()ed and
+        // normalised): zero pads first, then 16 threads per frame scatter that frame's values (merger input k = net * O0 + o)
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < FT * nkqm * 64; i += NT) gf[i] = zero;
+        __syncthreads();
+        const int O0 = p.net[0].n_out, O1 = p.net[1].n_out, OP = 16 * n_ot;
+        const float *const blk = reinterpret_cast<const float *>(p.gimg) + (size_t)tile * 2 * (BM * OP);
+        float *const img = reinterpret_cast<float *>(gf);
+        for (int fr = tid >> 4; fr < BM; fr += NT / 16) {
+            const int u = tid & 15;
+            for (int o = u; o < O0; o += 16) xf_store(img, nkqm, fr, o, blk[fr * OP + o]);
+            for (int o = u; o < O1; o += 16) xf_store(img, nkqm, fr, O0 + o, blk[(BM + fr) * OP + o]);
+        }
     }
     __syncthreads();
     {
@@ -562,7 +604,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
         reinterpret_cast<f4 *>(p.part) + (size_t)blockIdx.x * slab_f4, 0, slab_f4 * 16, 0x00020000);
     for (int i = tid; i < slab_f4; i += NT)
         store_through((slab[i] + slab[slab_f4 + i]) + (slab[2 * slab_f4 + i] + slab[3 * slab_f4 + i]), mine, i);
-    if (!split_arrive(p.cnt + 2 * tile + 1, split, ticket, tid)) return;
+    if (!split_arrive(p.cnt + 4 * tile + 2, split, ticket, tid)) return;
     const f4 *const first = reinterpret_cast<const f4 *>(p.part) + (size_t)tile * split * slab_f4;
     for (int i = tid; i < slab_f4; i += NT) slab[i] = split_sum(first + i, (size_t)slab_f4, split);
     __syncthreads();
@@ -664,9 +706,9 @@ bool lcrc_has_split_f16(const NetDev *nets)
 void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes)
 {
     const size_t slab = (size_t)lcrc_n_ot_slab(nets) * 1024u;          // one 16-frame partial tile
-    *part_bytes = (size_t)wgs * 2 * slab;
-    *gimg_bytes = (size_t)wgs * nets[2].nkq * 1024u;
-    *cnt_bytes = (size_t)wgs * 2 * sizeof(unsigned);
+    *part_bytes = (size_t)wgs * slab;                                  // one per workgroup in either phase
+    *gimg_bytes = (size_t)wgs * slab;                                  // band outputs: [tile][net][16][16 * n_ot]; tiles <= wgs / 2
+    *cnt_bytes = (size_t)wgs * 4 * sizeof(unsigned);                   // [tile][band net 0, band net 1, merger, -]
 }
 
 namespace {
@@ -761,8 +803,9 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     const int split = p.tile_frames == 32 ? 1 : choose_split(p, tiles16, n_cu);
     if (split > 1) {
         const int nht_b = max(p.net[0].nht, p.net[1].nht), nht_m = p.net[2].nht;
-        // at least one hidden tile per wave: two waves per band net, four on the merger
-        const int sb = max(1, min(split, nht_b / 2)), sm = max(1, min(split, nht_m / 4));
+        // band phase: `split` workgroups per tile = split / 2 slices per band net (each workgroup runs ONE net on its four
+        // waves); merger phase: `split` slices.  At least one hidden tile per wave.
+        const int sb = max(1, min(split / 2, nht_b / 4)), sm = max(1, min(split, nht_m / 4));
         args.tps_b = (nht_b + sb - 1) / sb;
         args.split_b = (nht_b + args.tps_b - 1) / args.tps_b;      // no empty slices
         args.tps_m = (nht_m + sm - 1) / sm;
@@ -772,7 +815,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         if (e != hipSuccess) return e;
         e = grant_lds(v->split_merger, vi, 3, dev);
         if (e != hipSuccess) return e;
-        e = hipLaunchKernel(v->split_band, dim3(tiles16 * args.split_b), block, kargs, lp.total + 16, stream);
+        e = hipLaunchKernel(v->split_band, dim3(tiles16 * 2 * args.split_b), block, kargs, lp.total + 16, stream);
         if (e != hipSuccess) return e;
         return hipLaunchKernel(v->split_merger, dim3(tiles16 * args.split_m), block, kargs,
                                lcrc_split_merger_lds(p.net[2].nkq, args.n_ot_slab), stream);

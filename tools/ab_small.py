@@ -42,7 +42,7 @@ def main():
         mel = torch.from_numpy(modelgen.synth_mel(2048, nb, seed=1)).cuda()
         posts = [torch.empty((2048, n_out), device="cuda") for _ in libs]
         print(system)
-        for n in (5, 64, 256, 512, 1024, 2048):
+        for n in (5, 64, 256, 512, 1024, 1536, 2048):
             t = [[], []]
             for rnd in range(7):
                 for k in ((0, 1) if rnd % 2 == 0 else (1, 0)):
@@ -57,7 +57,8 @@ def main():
                     t[k].append(e0.elapsed_time(e1) / 200)
             a, b = np.median(t[0][1:]), np.median(t[1][1:])
             same = bool(torch.equal(posts[0][:n], posts[1][:n]))
-            print("  %5d frames: A %.4f ms  B %.4f ms  B/A %.3f  identical: %s" % (n, a, b, b / a, same))
+            diff = float((posts[0][:n] - posts[1][:n]).abs().max().item())
+            print("  %5d frames: A %.4f ms  B %.4f ms  B/A %.3f  identical: %s (max |A-B| %.2g)" % (n, a, b, b / a, same, diff))
         hmel = modelgen.synth_mel(4000, nb, seed=2)
         out = np.empty((5, n_out), np.float32)
         t = [[], []]
