@@ -551,7 +551,7 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     }
     if (row_count == 0) return LCRC_OK;
     // (the scratch's clears run on the context's stream: a launch on another stream waits for them once)
-    if (!c->d_part && c->split_hint != 1 && c->arith == 0 && !dbg && row_count <= kSplitMaxRows) {
+    if (!c->d_part && c->split_hint != 1 && c->arith == 0 && !dbg) {      // (any size: a large launch may end in a split tail)
         ensure_split_scratch(c);
         if (c->d_part && s != c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

@@ -187,7 +187,6 @@ constexpr int kSplitCapWgs = 512;    // workgroups of a split launch (tiles x sp
 const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes);
 // whether split-f16 kernels exist for the model's shape (a shipped shape)
 bool lcrc_has_split_f16(const NetDev *nets);
-constexpr int kSplitMaxRows = 4096;  // launches above it never take the split-hidden path
 
 }  // namespace phnrec
 #endif

@@ -798,43 +798,91 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         return hipLaunchKernel(v->h2[ft - 1], dim3((rows + bm - 1) / bm), block, kargs, lp.total, stream);
     }
 
-    // ---- split-hidden path: two launches (band phase, merger phase) on 16-frame tiles ----
-    const int tiles16 = (rows + 15) / 16;
-    const int split = p.tile_frames == 32 ? 1 : choose_split(p, tiles16, n_cu);
-    if (split > 1) {
-        const int nht_b = max(p.net[0].nht, p.net[1].nht), nht_m = p.net[2].nht;
-        // band phase: `split` workgroups per tile = split / 2 slices per band net (each workgroup runs ONE net on its four
-        // waves); merger phase: `split` slices.  At least one hidden tile per wave.
-        const int sb = max(1, min(split / 2, nht_b / 4)), sm = max(1, min(split, nht_m / 4));
-        args.tps_b = (nht_b + sb - 1) / sb;
-        args.split_b = (nht_b + args.tps_b - 1) / args.tps_b;      // no empty slices
-        args.tps_m = (nht_m + sm - 1) / sm;
-        args.split_m = (nht_m + args.tps_m - 1) / args.tps_m;
-        const LdsPlan lp = lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, args.n_ot_slab);
-        e = grant_lds(v->split_band, vi, 2, dev);
-        if (e != hipSuccess) return e;
-        e = grant_lds(v->split_merger, vi, 3, dev);
-        if (e != hipSuccess) return e;
-        e = hipLaunchKernel(v->split_band, dim3(tiles16 * 2 * args.split_b), block, kargs, lp.total + 16, stream);
-        if (e != hipSuccess) return e;
-        return hipLaunchKernel(v->split_merger, dim3(tiles16 * args.split_m), block, kargs,
-                               lcrc_split_merger_lds(p.net[2].nkq, args.n_ot_slab), stream);
-    }
-
-    // 32-frame workgroups load every weight fragment once per 32 frames; 16-frame workgroups twice as
-    // often, but there are twice as many of them: they win while the 32-frame grid would leave at
-    // least half of the CUs without work.
-    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
-    if (!fits32) ft = 1;
+    // ---- launch plan --------------------------------------------------------------------------------------------
+    // One launch of 32-frame workgroups costs a whole "round" (every CU one workgroup, ~t32) per n_cu * 32 rows or part
+    // thereof; 16-frame workgroups cost half a round each (~t32 / 2) per n_cu * 16 rows; and up to n_cu / 2 tiles the
+    // split-hidden path is cheaper still.  So a launch is cut into a MAIN part of whole rounds and a TAIL that takes
+    // the cheapest form for its size -- e.g. 12 288 rows = 8192 as 32-frame tiles + 4096 as 16-frame tiles (1.5
+    // rounds instead of 2), 4100 rows = 4096 as 16-frame tiles + 4 on the split path.  Both fused forms give the same
+    // bits, so cutting never changes a frame's result; the split tail exists only with lcrc_set_hidden_split(h, 0).
     const bool probes = p.dbg_in0 || p.dbg_in1 || p.dbg_p0 || p.dbg_p1 || p.dbg_g;
-    if (probes) ft = 1;
-    const void *fn = probes ? v->probe : v->fn[ft - 1];
-    e = grant_lds(fn, vi, probes ? 4 : ft - 1, dev);
-    if (e != hipSuccess) return e;
-    const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
-    const int bm = 16 * ft;
-    const dim3 grid((rows + bm - 1) / bm);
-    return hipLaunchKernel(fn, grid, block, kargs, lp.total, stream);
+    const int round32 = n_cu * 32, round16 = n_cu * 16;
+    struct Part { int first, count, ft; bool split; };
+    Part parts[3];
+    int n_parts = 0;
+    const bool free_choice = p.tile_frames == 0 && fits32 && !probes && !p.stamps;
+    const int tiles16_all = (rows + 15) / 16;
+    const bool small_splits = p.tile_frames != 32 && choose_split(p, tiles16_all, n_cu) > 1;
+    if (!free_choice || rows <= round16 || small_splits) {
+        // forced tile size, probes, or a launch that fits one half round: a single part (as ever)
+        int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((rows + 31) / 32 <= n_cu / 2 ? 1 : 2);
+        if (!fits32 || probes) ft = 1;
+        parts[n_parts++] = Part{args.row_first, rows, ft, small_splits};
+    } else {
+        const int main_rows = rows / round32 * round32;
+        const int rem = rows - main_rows;
+        // would the split path take a tail of `r` rows?
+        auto splits = [&](int r) { return r > 0 && choose_split(p, (r + 15) / 16, n_cu) > 1; };
+        if (rem == 0) {
+            parts[n_parts++] = Part{args.row_first, rows, 2, false};
+        } else if (rem <= round16) {
+            // whole rounds of 32-frame tiles, then half a round (or less) of 16-frame tiles / the split path
+            if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, 2, false};
+            parts[n_parts++] = Part{args.row_first + main_rows, rem, 1, splits(rem)};
+        } else if (splits(rem - round16)) {
+            // between half a round and a round, and what lies beyond the half round is small enough for the split
+            // path: half a round of 16-frame tiles + the split tail beat the full round of 32-frame tiles
+            if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, 2, false};
+            parts[n_parts++] = Part{args.row_first + main_rows, round16, 1, false};
+            parts[n_parts++] = Part{args.row_first + main_rows + round16, rem - round16, 1, true};
+        } else {
+            parts[n_parts++] = Part{args.row_first, rows, 2, false};
+        }
+    }
+    float *const post0 = args.post;
+    const int row_first0 = args.row_first;
+    const size_t n_out = (size_t)p.net[2].n_out;
+    for (int k = 0; k < n_parts; k++) {
+        const Part &pt = parts[k];
+        args.row_first = pt.first;
+        args.row_end = pt.first + pt.count;
+        args.post = post0 + (size_t)(pt.first - row_first0) * n_out;
+        const int tiles16 = (pt.count + 15) / 16;
+        const int split = pt.split ? choose_split(p, tiles16, n_cu) : 1;
+        if (split > 1) {
+            // ---- split-hidden path: two launches (band phase, merger phase) on 16-frame tiles ----
+            const int nht_b = max(p.net[0].nht, p.net[1].nht), nht_m = p.net[2].nht;
+            // band phase: `split` workgroups per tile = split / 2 slices per band net (each workgroup runs ONE net on its four
+            // waves); merger phase: `split` slices.  At least one hidden tile per wave.
+            const int sb = max(1, min(split / 2, nht_b / 4)), sm = max(1, min(split, nht_m / 4));
+            args.tps_b = (nht_b + sb - 1) / sb;
+            args.split_b = (nht_b + args.tps_b - 1) / args.tps_b;      // no empty slices
+            args.tps_m = (nht_m + sm - 1) / sm;
+            args.split_m = (nht_m + args.tps_m - 1) / args.tps_m;
+            const LdsPlan lp = lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, args.n_ot_slab);
+            e = grant_lds(v->split_band, vi, 2, dev);
+            if (e != hipSuccess) return e;
+            e = grant_lds(v->split_merger, vi, 3, dev);
+            if (e != hipSuccess) return e;
+            e = hipLaunchKernel(v->split_band, dim3(tiles16 * 2 * args.split_b), block, kargs, lp.total + 16, stream);
+            if (e != hipSuccess) return e;
+            e = hipLaunchKernel(v->split_merger, dim3(tiles16 * args.split_m), block, kargs,
+                                lcrc_split_merger_lds(p.net[2].nkq, args.n_ot_slab), stream);
+            if (e != hipSuccess) return e;
+            continue;
+        }
+        // 32-frame workgroups load every weight fragment once per 32 frames; 16-frame workgroups twice as often, but
+        // there are twice as many of them: they win while the 32-frame grid would leave at least half of the CUs idle
+        const int ft = pt.ft;
+        const void *fn = probes ? v->probe : v->fn[ft - 1];
+        e = grant_lds(fn, vi, probes ? 4 : ft - 1, dev);
+        if (e != hipSuccess) return e;
+        const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
+        const int bm = 16 * ft;
+        e = hipLaunchKernel(fn, dim3((pt.count + bm - 1) / bm), block, kargs, lp.total, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace phnrec

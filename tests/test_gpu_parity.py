@@ -408,6 +408,31 @@ def test_baseline_batches_every_row_against_the_oracle(capi, oracle_mod, system,
     ctx.close()
 
 
+def test_cut_launches_give_the_bits_of_uncut_ones(capi):
+    """lcrc_launch cuts a launch into whole rounds of 32-frame workgroups plus a cheaper tail (16-frame workgroups, or the
+    split-hidden path when that is allowed).  Sizes around every cut point: with the fused kernels only (as the CLI runs)
+    the result is bit-identical to the uncut launch of forced 32-frame tiles -- also for ragged utterances that straddle
+    the cuts; with the split tail allowed, within its usual distance of the fused kernels"""
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    ctx = capi.Lcrc(model_dir(system), 15)
+    rng = np.random.default_rng(11)
+    for n in (4097, 4112, 5000, 6144, 6200, 8193, 8200, 12288, 12305, 16500):
+        mel = modelgen.synth_mel(n, 15, seed=n, mean_norm=True)
+        cuts = np.sort(rng.choice(np.arange(1, n), size=9, replace=False))
+        off = np.concatenate([[0], cuts, [n]]).astype(np.int32)
+        ctx.set_hidden_split(1)
+        ctx.set_tile_frames(32)
+        want, want_b = ctx.posteriors(mel), ctx.posteriors_batch(mel, off)
+        ctx.set_tile_frames(0)
+        assert np.array_equal(ctx.posteriors(mel), want), n
+        assert np.array_equal(ctx.posteriors_batch(mel, off), want_b), n
+        ctx.set_hidden_split(0)
+        got = ctx.posteriors(mel)
+        assert np.abs(got - want).max() < 1e-5 and np.abs(got.sum(axis=1) - 1).max() < 1e-5, n
+        assert np.abs(ctx.posteriors_batch(mel, off) - want_b).max() < 1e-5, n
+    ctx.close()
+
+
 def test_fuzzed_models(capi, oracle_mod):
     """tools/fuzz_parity.py with a fixed seed: 30 random model geometries (run-time-shape kernels: banks, hidden sizes,
     outputs, ragged batches with empty utterances, 16- / 32-frame workgroups, forced hidden splits) and 12 models of

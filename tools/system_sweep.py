@@ -30,6 +30,8 @@ def main():
             mdir = "/tmp/sweep_model_" + system
             modelgen.write_system(mdir, system, seed=1)
         ctx = capi.Lcrc(mdir, spec["nbanks"])
+        if os.environ.get("SWEEP_NO_SPLIT"):        # as the CLI runs: fused kernels only (batch-invariant bits)
+            ctx.set_hidden_split(1)
         for n in sizes:
             mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
             post = torch.empty((n, ctx.n_out), device="cuda")
