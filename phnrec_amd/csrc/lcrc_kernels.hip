@@ -128,8 +128,12 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = p.nbanks;
-    const int nkq1 = ARITH ? 2 * NS1 : EXACT ? (KS1 + 3) / 4 : p.net[0].nkq;
-    const int nkqm = ARITH ? 2 * NSM : EXACT ? (KSM + 3) / 4 : p.net[2].nkq;
+    // k-groups per frame tile of the operand images.  Run-time shapes use their CLASS's counts as well (groups past the
+    // net's own hold zeros): image addresses are then compile-time offsets in the hidden loops (mlp_dev.h RingLoop);
+    // only the staging of the normalisation vectors knows the net's own sizes (nkq1_net, nkqm_net).
+    const int nkq1 = ARITH ? 2 * NS1 : (KS1 + 3) / 4;
+    const int nkqm = ARITH ? 2 * NSM : (KSM + 3) / 4;
+    const int nkq1_net = EXACT ? nkq1 : p.net[0].nkq, nkqm_net = EXACT ? nkqm : p.net[2].nkq;
     const int n_ot = EXACT ? NOT : p.n_ot_slab;
     const LdsPlan lp = lcrc_lds_plan(FT, nb, nkq1, nkqm, n_ot);
 
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         constexpr int kMaxBanks = 23, kMaxW1 = 16 * 16, kMaxWm = 16 * 26;      // the variants' upper bounds
         constexpr int MPT = (kTileRows * kMaxBanks + NT - 1) / NT;             // mel values per thread
         constexpr int WPT = (kMaxW1 + NT - 1) / NT, GPT = (kMaxWm + NT - 1) / NT;
-        const int w1n = 16 * nkq1, wmn = 16 * nkqm, ntile = kTileRows * nb;
+        const int w1n = 16 * nkq1, wmn = 16 * nkqm, ntile = kTileRows * nb;          // LDS layout
+        const int w1v = 16 * nkq1_net, wmv = 16 * nkqm_net;                            // what the nets' arrays hold
         const int nmel = p.n_rows * nb;          // (rows * banks < 2^31: the API bounds a call's frames)
         float mv[MPT], tv, wv[WPT][4], gv[GPT][2];
 #pragma unroll
@@ -212,13 +217,13 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
         tv = *tsrc;
 #pragma unroll
         for (int q = 0; q < WPT; q++) {
-            const unsigned i = (unsigned)min(tid + q * NT, w1n - 1);     // unsigned: 32-bit offset from a scalar base
+            const unsigned i = (unsigned)min(tid + q * NT, w1v - 1);     // unsigned: 32-bit offset from a scalar base
             wv[q][0] = p.net[0].mean[i]; wv[q][1] = p.net[0].dev[i];
             wv[q][2] = p.net[1].mean[i]; wv[q][3] = p.net[1].dev[i];
         }
 #pragma unroll
         for (int q = 0; q < GPT; q++) {
-            const unsigned i = (unsigned)min(tid + q * NT, wmn - 1);
+            const unsigned i = (unsigned)min(tid + q * NT, wmv - 1);
             gv[q][0] = p.net[2].mean[i]; gv[q][1] = p.net[2].dev[i];
         }
         LCRC_FENCE();
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
         for (int q = 0; q < WPT; q++) {
             const int i = tid + q * NT;
-            if (i < w1n) {
+            if (i < w1v) {
                 nrm_band[i] = wv[q][0]; nrm_band[w1n + i] = wv[q][1];
                 nrm_band[2 * w1n + i] = wv[q][2]; nrm_band[3 * w1n + i] = wv[q][3];
             }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 #pragma unroll
         for (int q = 0; q < GPT; q++) {
             const int i = tid + q * NT;
-            if (i < wmn) { nrm_merger[i] = gv[q][0]; nrm_merger[wmn + i] = gv[q][1]; }
+            if (i < wmv) { nrm_merger[i] = gv[q][0]; nrm_merger[wmn + i] = gv[q][1]; }
         }
     }
     __syncthreads();
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_split_merger_kernel(const LcrcPa
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const NetDev &nm = p.net[2];
-    const int nkqm = EXACT ? (KSM + 3) / 4 : nm.nkq;
+    constexpr int nkqm = (KSM + 3) / 4;                         // the class's k-groups (see lcrc_fused_kernel)
     const int n_ot = EXACT ? NOT : p.n_ot_slab;
     const int slab_f4 = FT * n_ot * 64;
     f4 *const gf = reinterpret_cast<f4 *>(smem);
@@ -690,8 +695,10 @@ const char *lcrc_variant_for(const NetDev *nets, int nbanks, unsigned *lds_bytes
     const Variant *v = pick(nets);
     if (!v) return nullptr;
     // 32-frame workgroups when their LDS image fits, else 16-frame ones only (same results)
-    unsigned total = lcrc_lds_plan(2, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets)).total;
-    if (total > 160u * 1024u) total = lcrc_lds_plan(1, nbanks, nets[0].nkq, nets[2].nkq, lcrc_n_ot_slab(nets)).total;
+    // (operand images are laid out with the variant's -- for run-time shapes: the class's -- k-groups)
+    const int k1 = (v->ks1 + 3) / 4, km = (v->ksm + 3) / 4;
+    unsigned total = lcrc_lds_plan(2, nbanks, k1, km, lcrc_n_ot_slab(nets)).total;
+    if (total > 160u * 1024u) total = lcrc_lds_plan(1, nbanks, k1, km, lcrc_n_ot_slab(nets)).total;
     if (lds_bytes) *lds_bytes = total;
     if (total > 160u * 1024u) return nullptr;
     return v->name;
@@ -757,8 +764,9 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
 {
     const Variant *v = pick(p.net);
     if (!v) return hipErrorInvalidValue;
-    const bool fits32 = lcrc_lds_plan(2, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
-    if (!fits32 && lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
+    const int k1 = (v->ks1 + 3) / 4, km = (v->ksm + 3) / 4;     // k-groups of the operand images (the class's for run-time shapes)
+    const bool fits32 = lcrc_lds_plan(2, p.nbanks, k1, km, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
+    if (!fits32 && lcrc_lds_plan(1, p.nbanks, k1, km, lcrc_n_ot_slab(p.net)).total > 160u * 1024u)
         return hipErrorInvalidValue;
     if (variant_name) *variant_name = v->name;
     LcrcParams args = p;
@@ -859,7 +867,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
             args.split_b = (nht_b + args.tps_b - 1) / args.tps_b;      // no empty slices
             args.tps_m = (nht_m + sm - 1) / sm;
             args.split_m = (nht_m + args.tps_m - 1) / args.tps_m;
-            const LdsPlan lp = lcrc_lds_plan(1, p.nbanks, p.net[0].nkq, p.net[2].nkq, args.n_ot_slab);
+            const LdsPlan lp = lcrc_lds_plan(1, p.nbanks, k1, km, args.n_ot_slab);
             e = grant_lds(v->split_band, vi, 2, dev);
             if (e != hipSuccess) return e;
             e = grant_lds(v->split_merger, vi, 3, dev);
@@ -867,7 +875,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
             e = hipLaunchKernel(v->split_band, dim3(tiles16 * 2 * args.split_b), block, kargs, lp.total + 16, stream);
             if (e != hipSuccess) return e;
             e = hipLaunchKernel(v->split_merger, dim3(tiles16 * args.split_m), block, kargs,
-                                lcrc_split_merger_lds(p.net[2].nkq, args.n_ot_slab), stream);
+                                lcrc_split_merger_lds(km, args.n_ot_slab), stream);
             if (e != hipSuccess) return e;
             continue;
         }
@@ -877,7 +885,7 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         const void *fn = probes ? v->probe : v->fn[ft - 1];
         e = grant_lds(fn, vi, probes ? 4 : ft - 1, dev);
         if (e != hipSuccess) return e;
-        const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, p.net[0].nkq, p.net[2].nkq, lcrc_n_ot_slab(p.net));
+        const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, k1, km, lcrc_n_ot_slab(p.net));
         const int bm = 16 * ft;
         e = hipLaunchKernel(fn, dim3((pt.count + bm - 1) / bm), block, kargs, lp.total, stream);
         if (e != hipSuccess) return e;

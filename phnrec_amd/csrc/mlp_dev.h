@@ -324,6 +324,7 @@ struct RingLoop {
 
     const f4 *w1, *w2;
     const f4 *z1, *z2;          // the all-zero fragment behind w1p / w2p (run-time shapes)
+    int zi1, zi2;               // ... as fragment indices: nht * nkq, nht * n_ot
     const float *b1;
     const f4 *XF;
     int hlast, lane;
@@ -335,24 +336,28 @@ struct RingLoop {
     // Generic shapes: entries beyond the run-time sizes re-request the last valid fragment (a load
     // under a branch would make the compiler drain all requests at the join); they are never consumed.
     __device__ __forceinline__ void request(int slot, int e, int t) { request(slot, e, t, nkq, n_ot); }
+    // fragment index `a` if `valid`, else `b`, WITHOUT control flow: as a conditional expression hipcc sinks the address
+    // arithmetic into a branch, and one branch per 8-MFMA group cuts the hidden loop into as many basic blocks -- no
+    // load or LDS read is then scheduled ahead across them (the run-time-shape loops ran at 59 % MFMA occupancy so)
+    static __device__ __forceinline__ int pick_index(bool valid, int a, int b) { return b + (-(int)valid & (a - b)); }
     __device__ __forceinline__ void request(int slot, int e, int t, int nkq, int n_ot)
     {
         if (e < NOT) {
             if (EXACT) {
                 const f4 *tb = w2 + (size_t)max(0, min(t, hlast)) * NOT * 64;
                 ring[slot] = scalar_ptr(tb + (e & ~3) * 64)[(e & 3) * 64 + lane];
-            } else {                                   // past this net's output tiles: the zero fragment
-                const f4 *fr = e < n_ot ? w2 + ((size_t)max(0, min(t, hlast)) * n_ot + e) * 64 : z2;
-                ring[slot] = scalar_ptr(fr)[lane];
+            } else {                                   // past this net's output tiles: the zero fragment behind w2p
+                const int idx = pick_index(e < n_ot, max(0, min(t, hlast)) * n_ot + e, zi2);
+                ring[slot] = scalar_ptr(w2 + (size_t)idx * 64)[lane];
             }
         } else if (e - NOT < NKQ) {
             const int kq = e - NOT;
             if (EXACT) {
                 const f4 *tb = w1 + (size_t)min(t + 1, hlast) * NKQ * 64;
                 ring[slot] = load_w1_frag<KS, NKQ, true>(scalar_ptr(tb + (kq & ~3) * 64), kq & 3, kq, lane);
-            } else {                                   // past this net's k-groups: the zero fragment
-                const f4 *fr = kq < nkq ? w1 + ((size_t)min(t + 1, hlast) * nkq + kq) * 64 : z1;
-                ring[slot] = scalar_ptr(fr)[lane];
+            } else {                                   // past this net's k-groups: the zero fragment behind w1p
+                const int idx = pick_index(kq < nkq, min(t + 1, hlast) * nkq + kq, zi1);
+                ring[slot] = scalar_ptr(w1 + (size_t)idx * 64)[lane];
             }
         }
     }
@@ -387,7 +392,9 @@ struct RingLoop {
         if (MODE != LAST && !kSkipLd)              // bias of the tile after next: requested first, so
             bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
         f4 xb[2][FT];
-        const int nkq_x = EXACT ? NKQ : nkq;      // row stride of the B image
+        // The B image's row stride is the CLASS's k-groups (NKQ) for run-time shapes too: every read below is then the
+        // image base plus a compile-time offset (groups past the net's own are zeros, and so are their weights)
+        constexpr int nkq_x = NKQ;
         if (MODE != LAST && BKQ == 0) {
 #pragma unroll
             for (int f = 0; f < FT; f++) xb[0][f] = XF[f * nkq_x * 64 + lane];
@@ -399,7 +406,7 @@ struct RingLoop {
             } else if (i - NOT < NKQ) {
                 const int kq = i - NOT;
                 if (kq + 1 < NKQ && kq + 1 >= BKQ) {   // B fragments of the next group, ahead of the MFMAs
-                    const int kn = EXACT ? kq + 1 : min(kq + 1, nkq - 1);
+                    const int kn = kq + 1;
 #pragma unroll
                     for (int f = 0; f < FT; f++) xb[(kq + 1) & 1][f] = XF[(f * nkq_x + kn) * 64 + lane];
                 }
@@ -447,7 +454,7 @@ struct RingLoop {
 #pragma unroll
             for (int kq = 0; kq < BKQ; kq++)
 #pragma unroll
-                for (int f = 0; f < FT; f++) bimg[kq][f] = XF[(f * (EXACT ? NKQ : nkq) + kq) * 64 + lane];
+                for (int f = 0; f < FT; f++) bimg[kq][f] = XF[(f * NKQ + kq) * 64 + lane];
         }
         f4 bias = bias0;
         f4 pre[FT];
@@ -468,6 +475,7 @@ struct RingLoop {
         hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
         ks = nd.ksteps; nkq = nd.nkq; n_ot = nd.n_ot;
         z1 = w1 + (size_t)nd.nht * nd.nkq * 64; z2 = w2 + (size_t)nd.nht * nd.n_ot * 64;
+        zi1 = nd.nht * nd.nkq; zi2 = nd.nht * nd.n_ot;
     }
 };
 
@@ -703,6 +711,7 @@ __device__ __forceinline__ void hidden_range(const NetDev &nd, const f4 *XF, int
     loop.hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
     loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
     loop.z1 = loop.w1 + (size_t)nd.nht * nd.nkq * 64; loop.z2 = loop.w2 + (size_t)nd.nht * nd.n_ot * 64;
+    loop.zi1 = nd.nht * nd.nkq; loop.zi2 = nd.nht * nd.n_ot;
     loop.run(acc, ht0, ht1);
 }
 
@@ -875,6 +884,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         loop.w1 = w1; loop.w2 = w2; loop.b1 = b1; loop.XF = XF; loop.hlast = hlast; loop.lane = lane;
         loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
         loop.z1 = w1 + (size_t)nd.nht * nd.nkq * 64; loop.z2 = w2 + (size_t)nd.nht * nd.n_ot * 64;
+        loop.zi1 = nd.nht * nd.nkq; loop.zi2 = nd.nht * nd.n_ot;
         loop.run(acc, ht0, ht1);
     }
 

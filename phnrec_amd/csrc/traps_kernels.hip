@@ -124,7 +124,11 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     const NetDev nd = BATCHED ? uniform_net(p.nets_dev + blockIdx.y) : p.net;
     const float *const in = BATCHED ? p.in + (size_t)blockIdx.y * p.in_net_stride : p.in;
     float *const out = BATCHED ? p.out + __builtin_amdgcn_readfirstlane(p.out_col[blockIdx.y]) : p.out;
-    const int nkq = EXACT ? (KS + 3) / 4 : nd.nkq, n_ot = EXACT ? NOT : nd.n_ot, K = nd.n_inp, O = nd.n_out;
+    // the operand image is laid out with the CLASS's k-groups (run-time shapes: groups past the net's own hold zeros),
+    // so that its addresses are compile-time offsets in the hidden loop (mlp_dev.h RingLoop); nkq_net: the net's own
+    constexpr int nkq = (KS + 3) / 4;
+    const int nkq_net = EXACT ? nkq : nd.nkq;
+    const int n_ot = EXACT ? NOT : nd.n_ot, K = nd.n_inp, O = nd.n_out;
     const bool dct = !BATCHED && p.dct.mel != nullptr;
     const MlpLds L = mlp_lds_plan(nkq, n_ot, FT, dct ? p.dct.trap_bands : 0, dct ? p.dct.shift : 0);
     float *nrm = reinterpret_cast<float *>(smem + L.nrm);
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     f4 *slab = reinterpret_cast<f4 *>(smem + L.slab);
     const int r0 = blockIdx.x * BM;
 
-    for (int i = tid; i < 16 * nkq; i += NT) {
+    for (int i = tid; i < 16 * nkq_net; i += NT) {
         nrm[i] = nd.mean[i];
         nrm[16 * nkq + i] = nd.dev[i];
     }
@@ -207,13 +211,27 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         }
     } else {
         __syncthreads();
-        for (int idx = tid; idx < BM * K; idx += NT) {
-            const int i = idx / K, k = idx - i * K;
-            const int r = r0 + i;
-            float v = r < p.n_rows ? in[(size_t)r * p.in_ld + k] : 0.0f;
-            v = v - nrm[k];                                      // Normalize nn.cpp:702-716
-            v *= nrm[16 * nkq + k];
-            xf_store(xf, nkq, i, k, v);
+        // Row by row, a thread per input column (coalesced; no index division), eight rows' values requested before the
+        // first is used: the 32 x 360 inputs of a 1BT merger cost 45 dependent load-divide-store rounds per thread before.
+        constexpr int RB = 8;
+        for (int k0 = 0; k0 < K; k0 += NT) {
+            const int k = k0 + tid;
+            const bool kin = k < K;
+            const float mk = kin ? nrm[k] : 0.0f, dk = kin ? nrm[16 * nkq + k] : 0.0f;
+            for (int i0 = 0; i0 < BM; i0 += RB) {
+                float v[RB];
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const int r = r0 + i0 + u;
+                    v[u] = (kin && r < p.n_rows) ? in[(size_t)r * p.in_ld + k] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    float w = v[u] - mk;                                 // Normalize nn.cpp:702-716
+                    w *= dk;
+                    if (kin) xf_store(xf, nkq, i0 + u, k, (r0 + i0 + u) < p.n_rows ? w : 0.0f);
+                }
+            }
         }
     }
     __syncthreads();
@@ -233,15 +251,14 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     run_net<KS, NOT, NW, EXACT, FT, 1>(p, 0, &nd, reinterpret_cast<const f4 *>(xf), 0, slab, slab + 2 * FT * n_ot * 64, n_ot,
                                        lane, wave, per_value(epi));
     const int rows = min(BM, p.n_rows - r0);
-    for (int idx = tid; idx < rows * O; idx += NT) {
-        const int i = idx / O, o = idx - i * O;
-        out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[idx];
-    }
+    for (int o = tid; o < O; o += NT)                        // a thread per output column, row by row (coalesced)
+        for (int i = 0; i < rows; i++) out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[i * O + o];
 }
 
 bool mlp_supports(const NetDev &net)
 {
-    return net.ksteps <= kMlpKS && net.n_ot <= kMlpNOT && mlp_lds_plan(net.nkq, net.n_ot, 1, 64, kTrapLen).total <= 160u * 1024u;
+    // (LDS: the largest size class's image, 16-frame workgroups, the fused 1BT_DCT input at its largest)
+    return net.ksteps <= kMlpKS && net.n_ot <= kMlpNOT && mlp_lds_plan((kMlpKS + 3) / 4, net.n_ot, 1, 64, kTrapLen).total <= 160u * 1024u;
 }
 
 hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream)
@@ -277,6 +294,8 @@ const MlpVariant kMlp[] = {
     {"mlp_le128", 128, kMlpNOT, false, false, {MLP_FN(128, kMlpNOT, false, 1, false), MLP_FN(128, kMlpNOT, false, 2, false)}},
     {"mlp_le256", kMlpKS, kMlpNOT, false, false, {MLP_FN(kMlpKS, kMlpNOT, false, 1, false), MLP_FN(kMlpKS, kMlpNOT, false, 2, false)}},
     // many nets in one launch (grid.y = net): the band classifiers of 1BT / 3BT take 31 inputs
+    // (32-frame workgroups were tried for them: 61 us against 45 us for the 15 band nets of a 1BT model at 8192 frames --
+    //  these launches are bound by per-workgroup fixed costs, and halving the workgroups halves what overlaps them)
     {"mlp_nets_le8_4", 8, 4, false, true, {MLP_FN(8, 4, true, 1, false), nullptr}},
     {"mlp_nets_le64", 64, kMlpNOT, false, true, {MLP_FN(64, kMlpNOT, true, 1, false), nullptr}},
 };
@@ -304,16 +323,23 @@ hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **varia
     // 32-frame workgroups (every weight fragment serves two frame tiles) once they fill at least half of the CUs
     int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 > n_cu / 2 ? 2 : 1);
     const int dct_banks = (!batched && p.dct.mel) ? p.dct.trap_bands : 0, dct_shift = dct_banks ? p.dct.shift : 0;
-    if (batched || mlp_lds_plan(p.net.nkq, p.net.n_ot, ft, dct_banks, dct_shift).total > 160u * 1024u) ft = 1;
-    const MlpVariant *v = nullptr;
-    for (const MlpVariant &c : kMlp) {
-        if (c.batched != batched || !c.fn[ft - 1]) continue;
-        if (c.exact ? (c.ks == p.net.ksteps && c.n_ot == p.net.n_ot) : (p.net.ksteps <= c.ks && p.net.n_ot <= c.n_ot)) {
-            v = &c;
-            break;
+    auto pick = [&](int f) -> const MlpVariant * {
+        for (const MlpVariant &c : kMlp) {
+            if (c.batched != batched || !c.fn[f - 1]) continue;
+            if (c.exact ? (c.ks == p.net.ksteps && c.n_ot == p.net.n_ot) : (p.net.ksteps <= c.ks && p.net.n_ot <= c.n_ot)) return &c;
         }
+        return nullptr;
+    };
+    // LDS: the operand image has the VARIANT's k-groups (the class's for run-time shapes), see mlp_kernel
+    auto lds_of = [&](const MlpVariant *c, int f) {
+        return mlp_lds_plan((c->ks + 3) / 4, p.net.n_ot, f, dct_banks, dct_shift).total;
+    };
+    const MlpVariant *v = pick(ft);
+    if (ft == 2 && (!v || lds_of(v, 2) > 160u * 1024u)) {
+        ft = 1;
+        v = pick(1);
     }
-    if (!v) return hipErrorInvalidValue;                     // (batched nets beyond 64 k-steps: band classifiers take 31 inputs)
+    if (!v || lds_of(v, ft) > 160u * 1024u) return hipErrorInvalidValue;   // (batched nets beyond 64 k-steps: band classifiers take 31 inputs)
     if (variant) *variant = v->name;
     const void *fn = v->fn[ft - 1];
     static std::atomic<bool> granted[kNMlp][2][64] = {};
@@ -327,7 +353,7 @@ hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **varia
     void *kargs[] = {&args};
     const int bm = 16 * ft;
     return hipLaunchKernel(fn, dim3((p.n_rows + bm - 1) / bm, batched ? p.n_nets : 1), dim3(kMlpNW * 64), kargs,
-                           mlp_lds_plan(p.net.nkq, p.net.n_ot, ft, dct_banks, dct_shift).total, stream);
+                           lds_of(v, ft), stream);
 }
 
 }  // namespace phnrec
