@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 SYSTEM = "PHN_CZ_SPDAT_LCRC_N1500"
 BATCH = 8192
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+_RECORD_OUT = sys.stdout         # main() replaces it with a private copy of the original stdout
 
 
 def algorithmic_flops_per_frame(dims):
@@ -637,11 +638,12 @@ def stub_main(args, ranks):
     elapsed = distrun.timed_steps(ranks, step, lambda: None, args.steps, args.warmup)
     total = ranks.sum_int(state["n"])
     if ranks.rank == 0:
-        print(json.dumps({"stub": True, "metric": "launcher self-test (no GPU work)", "n_gpus": 0,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "frames_all_ranks": total,
-                          "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
-                                    "device_map": distrun.device_map(ranks.world)}}), flush=True)
+        _RECORD_OUT.write(json.dumps({"stub": True, "metric": "launcher self-test (no GPU work)", "n_gpus": 0,
+                                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                                      "frames_all_ranks": total,
+                                      "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
+                                                "device_map": distrun.device_map(ranks.world)}}) + "\n")
+        _RECORD_OUT.flush()
     ranks.finish()
 
 
@@ -683,6 +685,15 @@ def main():
                                  "one GPU for a functional test and labels the output accordingly)"
                                  % (args.gpus, have, args.gpus))
         sys.exit(distrun.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    # (a self-launching parent has left above: its ranks inherit the untouched stdout)
+    # stdout carries exactly ONE line, the JSON record.  Libraries print there too (gloo announces its ranks on stdout
+    # from C++, child programs inherit it), so file descriptor 1 is pointed at stderr for the life of the process and the
+    # record goes out through a private copy of the original stdout.
+    global _RECORD_OUT
+    sys.stdout.flush()
+    _RECORD_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     ranks = distrun.Ranks(args.gpus)
     if ranks.world != args.gpus:
@@ -877,7 +888,8 @@ def main():
     ranks.host_barrier()     # rank 0's side legs are over (a CPU-side wait: the other ranks' GPUs stay idle meanwhile)
     ranks.finish()
     if line is not None:
-        print(json.dumps(line), flush=True)
+        _RECORD_OUT.write(json.dumps(line) + "\n")
+        _RECORD_OUT.flush()
 
 
 if __name__ == "__main__":

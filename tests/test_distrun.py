@@ -101,6 +101,9 @@ def test_bench_self_launch_starts_n_ranks():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub"],
                        capture_output=True, text=True, env=env, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
+    # stdout is the record and nothing else (gloo announces its ranks on stdout from C++: bench.py points fd 1 at stderr)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1, p.stdout[:500]
     line = _last_json(p.stdout)
     assert line["ranks"] == {"world": 2, "launcher": "self", "backend": "gloo", "device_map": [0, 1]}
     assert line["frames_all_ranks"] == 2 * (4 + 1) * 8192          # both ranks stepped, warm-up included
@@ -116,6 +119,7 @@ def test_bench_under_torch_distributed_run():
                         BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1, p.stdout[:500]      # the record, alone
     line = _last_json(p.stdout)
     assert line["ranks"]["world"] == 2 and line["ranks"]["launcher"] == "torch.distributed.run"
     assert line["frames_all_ranks"] == 2 * (3 + 1) * 8192
