@@ -77,7 +77,8 @@ struct lcrc_ctx {
     float normc31 = 0.f;
     float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
     size_t cap_feat_rows = 0;
-    bool traps_unfused = false;          // PHNREC_TRAPS_UNFUSED=1: 1BT_DCT as features + MLP launches (A/B, tests)
+    bool traps_unfused = false;          // PHNREC_TRAPS_UNFUSED=1: every system as separate features / MLP launches (A/B, tests)
+    bool bt_unfused = false;             // 1BT / 3BT model that no fused size class holds
     const char *mlp_variant = "none";    // kernel of the last merger launch (1BT_DCT / 1BT / 3BT)
     // staging for the host-pointer entry points (grown on demand)
     float *d_mel = nullptr, *d_post = nullptr;
@@ -468,7 +469,8 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     if (n_rows <= 0) return LCRC_OK;
     const size_t Km = c->nets[2].n_inp;
     const bool fused_dct = c->system == SYS_1BT_DCT && !c->traps_unfused;
-    if (!fused_dct && (size_t)n_rows > c->cap_feat_rows) {
+    const bool fused_bt = c->system != SYS_1BT_DCT && !c->traps_unfused && !c->bt_unfused;
+    if (!fused_dct && !fused_bt && (size_t)n_rows > c->cap_feat_rows) {
         const size_t cap = (size_t)n_rows + n_rows / 4 + 64;
         if (c->d_feat) (void)hipFree(c->d_feat);
         if (c->d_minp) (void)hipFree(c->d_minp);
@@ -488,11 +490,29 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     f.hamming = c->d_hamm31; f.costab = c->d_costab31; f.normc = c->normc31;
     f.out = c->d_feat;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
-    if (!fused_dct) HIP_TRY(c, traps_features_launch(f, s));
     MlpParams m;
     memset(&m, 0, sizeof m);
     m.n_rows = n_rows;
     m.tile_frames = c->tile_frames;
+    if (fused_bt) {
+        // 1BT / 3BT in ONE launch: every wave runs whole band classifiers on the LDS-staged mel tile, the merger follows
+        m.net = c->nets[2];
+        m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = c->trap_bands;
+        m.lds_nkq = c->band_max.nkq; m.lds_n_ot = c->band_max.n_ot;
+        m.dct = f;
+        m.out = d_post; m.out_ld = c->nets[2].n_out;
+        fill_output_transform(c, m.out_func, m.out_c, m.out_l, &m.out_be);
+        const hipError_t e = traps_1bt_launch(m, s, &c->mlp_variant);
+        if (e == hipSuccess) {
+            if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
+            return LCRC_OK;
+        }
+        if (e != hipErrorNotSupported) return fail(c, LCRC_E_DEVICE, std::string("traps_1bt_launch: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+        c->bt_unfused = true;                // no size class holds this model: the three-launch form from now on
+        return launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
+    }
+    if (!fused_dct) HIP_TRY(c, traps_features_launch(f, s));
     const float *merger_in = c->d_feat;
     if (c->system != SYS_1BT_DCT) {
         m.net = c->band_max;                 // one launch, grid.y = band
@@ -983,7 +1003,7 @@ int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src)
     c->band_nets = src->band_nets; c->d_band_nets = src->d_band_nets; c->d_band_col = src->d_band_col;
     c->band_max = src->band_max;
     c->d_hamm31 = src->d_hamm31; c->d_costab31 = src->d_costab31; c->normc31 = src->normc31;
-    c->traps_unfused = src->traps_unfused;
+    c->traps_unfused = src->traps_unfused; c->bt_unfused = src->bt_unfused;
     c->variant = src->variant; c->lds_bytes = src->lds_bytes;
     *out = c;
     return LCRC_OK;

@@ -163,6 +163,8 @@ struct MlpParams {
 constexpr int kMlpKS = 256, kMlpNOT = 13;   // <= 1024 inputs, <= 208 outputs per net
 hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream);
 hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **variant = nullptr);
+// 1BT / 3BT in one launch (traps_1bt_kernel); hipErrorNotSupported when no size class holds the model
+hipError_t traps_1bt_launch(const MlpParams &p, hipStream_t stream, const char **variant = nullptr);
 bool mlp_supports(const NetDev &net);
 
 // ---- phoneme-loop Viterbi decoder (phndec_kernels.hip; "next" row f3, optional) ---------------------

@@ -255,6 +255,225 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
         for (int i = 0; i < rows; i++) out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[i * O + o];
 }
 
+// ---- 1BT / 3BT in ONE launch ------------------------------------------------------------------------------------------
+// A workgroup owns 16*FT frames.  The band classifiers (31 -> H -> O_b, one per band) are tiny: as launches of their own
+// (traps_features_kernel -> mlp_kernel with grid.y = band -> mlp_kernel for the merger) they cost 45 us + 10 us per 8192
+// frames for 9 us of MFMA work, plus two round trips through HBM (15 MB of trajectories, 12 MB of merger inputs).
+// Here each WAVE runs whole band classifiers by itself (bands b = wave, wave + 4, ...): it builds the band's normalised
+// trajectory image from the LDS-staged mel tile, runs the hidden loop over all of the net's hidden tiles
+// (hidden_range: the accumulators end up complete in its registers), takes them through a wave-private slab to the
+// per-frame softmax, -ln() and the merger's normalisation, and scatters the values into the merger's operand image --
+// no barrier until the merger starts, nothing leaves the CU.  Arithmetic: the band nets' products and FEXP as everywhere;
+// their softmax sums four strided partials per frame, (P0 + P1) + (P2 + P3), whatever the tile size (16- and 32-frame
+// workgroups agree bit for bit).  (traps.cpp:180-283,409-433)
+struct Bt1Lds {
+    unsigned nrm, gf, slab, tile, rowinfo, hamming, bimg, bnrm, total;
+};
+__host__ __device__ inline Bt1Lds bt1_lds_plan(int nkqm, int n_ot_m, int ft, int tile_banks)
+{
+    Bt1Lds l;
+    unsigned o = 0;
+    const unsigned n_ot = n_ot_m < 4 ? 4u : (unsigned)n_ot_m;     // the waves' band slabs (4 output tiles each) lie over the merger's
+    l.nrm = o;     o += 2u * 16u * nkqm * 4u;
+    l.gf = o;      o += (unsigned)ft * nkqm * 1024u;
+    l.slab = o;    o += 4u * (unsigned)ft * n_ot * 1024u;
+    l.tile = o;    o += lcrc_round16((16u * ft + 2u * kShift) * tile_banks * 4u);
+    l.rowinfo = o; o += 2u * 16u * ft * 4u;
+    l.hamming = o; o += 32u * 4u;
+    l.bimg = o;    o += 4u * (unsigned)ft * 2u * 1024u;           // [wave][f][2 k-groups][64] float4
+    l.bnrm = o;    o += (unsigned)tile_banks * 64u * 4u;          // [band][mean 32 | dev 32] of the band classifiers
+    l.total = o;
+    return l;
+}
+
+constexpr int kBandKS = 8, kBandNOT = 4;       // band classifiers: 31 inputs = 8 k-steps; two size classes: <= 32 / <= 64 outputs
+
+template <int KSM, int NOTM, int BNOT, int NW, int FT>
+__global__ __launch_bounds__(NW * 64) void traps_1bt_kernel(const MlpParams p)
+{
+    static_assert(BNOT <= kBandNOT, "band slabs are laid out for kBandNOT output tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = NW * 64, BM = 16 * FT, nkqm = (KSM + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const NetDev nm = p.net;
+    const TrapsFeatParams &d = p.dct;
+    const int tb = d.trap_bands, nb = d.nbanks, n_rows = d.n_rows;
+    const int n_ot_m = nm.n_ot, O = nm.n_out;
+    const Bt1Lds L = bt1_lds_plan(nkqm, n_ot_m, FT, tb);
+    float *nrm = reinterpret_cast<float *>(smem + L.nrm);
+    float *gf = reinterpret_cast<float *>(smem + L.gf);
+    f4 *slab = reinterpret_cast<f4 *>(smem + L.slab);
+    float *tile = reinterpret_cast<float *>(smem + L.tile);
+    int *rowlo = reinterpret_cast<int *>(smem + L.rowinfo), *rowhi = rowlo + BM;
+    float *hm = reinterpret_cast<float *>(smem + L.hamming);
+    const int r0 = blockIdx.x * BM, tbase = r0 - kShift, trows = BM + 2 * kShift;
+
+    // ---- prologue: merger normalisation vectors, zeroed merger image, mel tile, row bounds, Hamming window ----
+    for (int i = tid; i < 16 * nm.nkq; i += NT) {
+        nrm[i] = nm.mean[i];
+        nrm[16 * nkqm + i] = nm.dev[i];
+    }
+    {
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        f4 *z = reinterpret_cast<f4 *>(gf);
+        for (int i = tid; i < FT * nkqm * 64; i += NT) z[i] = zero;
+    }
+    for (int i = tid; i < trows * tb; i += NT) {                 // bands >= trap_bands are never used (3BT)
+        const int row = tbase + i / tb, b = i - (i / tb) * tb;
+        tile[i] = (row >= 0 && row < n_rows) ? d.mel[(size_t)row * nb + b] : 0.0f;
+    }
+    if (tid < 32) hm[tid] = (tid < kTrapLen && d.use_hamming) ? d.hamming[tid] : 1.0f;
+    float *bnrm = reinterpret_cast<float *>(smem + L.bnrm);
+    for (int i = tid; i < p.n_nets * 64; i += NT) {              // (mean / dev are padded to 32 floats per net)
+        const NetDev *nb_ = p.nets_dev + (i >> 6);
+        bnrm[i] = (i & 32) ? nb_->dev[i & 31] : nb_->mean[i & 31];
+    }
+    if (tid < BM) {
+        const int r = min(r0 + tid, n_rows - 1);
+        int lo = 0, hi = n_rows - 1;
+        if (d.off) {                                             // largest u with off[u] <= r
+            int a = 0, e = d.n_utts;
+            while (e - a > 1) {
+                const int mid = (a + e) >> 1;
+                if (d.off[mid] <= r) a = mid; else e = mid;
+            }
+            lo = d.off[a];
+            hi = d.off[a + 1] - 1;
+        }
+        rowlo[tid] = lo;
+        rowhi[tid] = hi;
+    }
+    __syncthreads();
+
+    // ---- the band classifiers, whole nets per wave ----
+    {
+        f4 *const bimg = reinterpret_cast<f4 *>(smem + L.bimg) + wave * (FT * 2 * 64);
+        f4 *const bslab = slab + wave * (FT * kBandNOT * 64);
+        float *const bs = reinterpret_cast<float *>(bslab);
+        const float *mmean = nrm, *mdev = nrm + 16 * nkqm;
+        const int c = lane & 15, g = lane >> 4;
+        // this lane's source rows in the tile for its 2 k-groups x 4 taps per frame tile: tap k = 16 kq + 4 j + g
+        int lo[FT], hi[FT], rc[FT];
+#pragma unroll
+        for (int f = 0; f < FT; f++) {
+            const int i = 16 * f + c;
+            lo[f] = rowlo[i]; hi[f] = rowhi[i];
+            rc[f] = min(r0 + i, n_rows - 1) - kShift;
+        }
+        // softmax lanes: frame i = lane % BM, quarter h of the outputs: NH = 64 / BM lanes per frame, each carries 4 / NH of
+        // the four strided partial sums
+        constexpr int NH = 64 / BM, PPL = 4 / NH;
+        const int si = lane % BM, sh = lane / BM;
+        const int sbase = (((si >> 4) * 64) + (si & 15)) * 4;     // float index of (o = 0, frame si) in a slab tile row
+        // (a) a band's normalised trajectories as its net's operand image (sMultVect traps.cpp:236-243, Normalize nn.cpp:702-716)
+        auto build_image = [&](int b, f4 *img) {
+            const float *bm_ = bnrm + b * 64;
+#pragma unroll
+            for (int f = 0; f < FT; f++)
+#pragma unroll
+                for (int kq = 0; kq < 2; kq++) {
+                    f4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int k = 16 * kq + 4 * j + g;
+                        const int kc = min(k, kTrapLen - 1);
+                        const int srow = max(lo[f], min(hi[f], rc[f] + kc));
+                        const float x = tile[(srow - tbase) * tb + b] * hm[kc];      // (window of ones without Hamming)
+                        float w = x - bm_[kc];
+                        w *= bm_[32 + kc];
+                        v[j] = k < kTrapLen ? w : 0.0f;
+                    }
+                    img[(f * 2 + kq) * 64 + lane] = v;
+                }
+        };
+        for (int b = wave; b < p.n_nets; b += NW) {
+            const NetDev nd = uniform_net(p.nets_dev + b);
+            const int mycol = __builtin_amdgcn_readfirstlane(p.out_col[b]);
+            build_image(b, bimg);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (b) both layers on this wave alone: complete output tiles in registers
+            f4 acc[BNOT][FT];
+            hidden_range<kBandKS, BNOT, false, FT>(nd, bimg, 0, nd.nht, true, lane, acc);
+            // (c) through the wave's slab to a per-frame view
+            store_partial<BNOT, false, FT>(bslab, nd.n_ot, lane, acc);
+            const int Ob = nd.n_out;
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (d) softmax (nn.cpp:822-855), -ln (traps.cpp:424-425), the merger's normalisation, into its operand image.
+            //     A lane's outputs o = sh + NH t sit in registers; element (o, frame si) of the slab: o = 16 ot + 4 g' + rr.
+            //     Whole steps t past the net's outputs are skipped (a wave-uniform test).
+            constexpr int MAXV = 16 * BNOT / NH;
+            float v[MAXV];
+            float m = -FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < MAXV; t++) {
+                v[t] = -FLT_MAX;
+                if (NH * t < Ob) {
+                    const int o = sh + NH * t;
+                    const int oc = min(o, 16 * BNOT - 1);
+                    const float x = bs[((oc >> 4) * FT * 64 + ((oc >> 2) & 3) * 16) * 4 + (oc & 3) + sbase];
+                    v[t] = o < Ob ? x : -FLT_MAX;
+                    m = fmaxf(m, v[t]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, BM));
+            if (NH == 4) m = fmaxf(m, __shfl_xor(m, 2 * BM));
+            float ps[PPL];
+#pragma unroll
+            for (int q = 0; q < PPL; q++) ps[q] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < MAXV; t++) {                      // partial (o mod 4) = sh + NH (t mod PPL), summed in order of o
+                if (NH * t < Ob) {
+                    const float e = fexp_nonpos_f(v[t] - m);
+                    v[t] = (sh + NH * t) < Ob ? e : 0.0f;
+                    ps[t % PPL] += v[t];
+                }
+            }
+            float sum;
+            if (NH == 4) {                               // lane h holds P_h: (P0 + P1) + (P2 + P3)
+                const float t01 = ps[0] + __shfl_xor(ps[0], BM);
+                sum = t01 + __shfl_xor(t01, 2 * BM);
+            } else {                                     // lane h holds P_h and P_{h+2}
+                const float t01 = ps[0] + __shfl_xor(ps[0], BM), t23 = ps[PPL - 1] + __shfl_xor(ps[PPL - 1], BM);
+                sum = t01 + t23;
+            }
+            const float scale = 1.0f / sum;
+#pragma unroll
+            for (int t = 0; t < MAXV; t++) {
+                if (NH * t < Ob) {
+                    const int o = sh + NH * t;
+                    float q = v[t] * scale;
+                    q = (q > 0.0f ? logf(q) : 0.0f) * -1.0f;
+                    const int k = min(mycol + o, 16 * nkqm - 1);
+                    float w = q - mmean[k];
+                    w *= mdev[k];
+                    if (o < Ob) xf_store(gf, nkqm, si, k, w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the merger on all four waves (as mlp_kernel) ----
+    float *outbuf = reinterpret_cast<float *>(slab);
+    const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
+    auto epi = [&](int, int i, int o, float q, bool valid) {
+        if (transform) {
+            q = soften(p.out_func[0], p.out_c[0], p.out_l[0], q);
+            q = soften(p.out_func[1], p.out_c[1], p.out_l[1], q);
+            if (p.out_be) q = __builtin_bit_cast(float, __builtin_bswap32(__builtin_bit_cast(unsigned, q)));
+        }
+        if (valid) outbuf[i * O + o] = q;
+    };
+    run_net<KSM, NOTM, NW, false, FT, 1>(p, 0, &nm, reinterpret_cast<const f4 *>(gf), 0, slab, slab + 2 * FT * n_ot_m * 64, n_ot_m,
+                                         lane, wave, per_value(epi));
+    const int rows = min(BM, n_rows - r0);
+    for (int o = tid; o < O; o += NT)
+        for (int i = 0; i < rows; i++) p.out[(size_t)(r0 + i) * p.out_ld + o] = outbuf[i * O + o];
+}
+
 bool mlp_supports(const NetDev &net)
 {
     // (LDS: the largest size class's image, 16-frame workgroups, the fused 1BT_DCT input at its largest)
@@ -354,6 +573,64 @@ hipError_t mlp_launch(const MlpParams &p, hipStream_t stream, const char **varia
     const int bm = 16 * ft;
     return hipLaunchKernel(fn, dim3((p.n_rows + bm - 1) / bm, batched ? p.n_nets : 1), dim3(kMlpNW * 64), kargs,
                            lds_of(v, ft), stream);
+}
+
+// ---- 1BT / 3BT fused launch: merger size classes as mlp_kernel's (k-steps, output tiles), first fit ----
+namespace {
+struct Bt1Variant {
+    const char *name;
+    int ks, n_ot, band_n_ot;
+    const void *fn[2];       // [FT - 1]
+};
+#define BT1_FN(KS, NOT, BNOT, FT) reinterpret_cast<const void *>(&traps_1bt_kernel<KS, NOT, BNOT, kMlpNW, FT>)
+const Bt1Variant kBt1[] = {     // merger class (k-steps, output tiles) x band class (output tiles), first fit
+    {"traps_1bt_le96_9_b2", 96, 9, 2, {BT1_FN(96, 9, 2, 1), BT1_FN(96, 9, 2, 2)}},
+    {"traps_1bt_le96_9_b4", 96, 9, 4, {BT1_FN(96, 9, 4, 1), BT1_FN(96, 9, 4, 2)}},
+    {"traps_1bt_le128_13_b2", 128, kMlpNOT, 2, {BT1_FN(128, kMlpNOT, 2, 1), BT1_FN(128, kMlpNOT, 2, 2)}},
+    {"traps_1bt_le128_13_b4", 128, kMlpNOT, 4, {BT1_FN(128, kMlpNOT, 4, 1), BT1_FN(128, kMlpNOT, 4, 2)}},
+    {"traps_1bt_le256_13_b4", kMlpKS, kMlpNOT, 4, {BT1_FN(kMlpKS, kMlpNOT, 4, 1), nullptr}},
+};
+constexpr int kNBt1 = sizeof kBt1 / sizeof kBt1[0];
+}  // namespace
+
+// p.net = the merger, p.nets_dev / p.out_col / p.n_nets = the band classifiers (p.lds_n_ot = their largest n_ot),
+// p.dct = mel / offsets / banks / Hamming window (mode 0).  hipErrorNotSupported: no class holds this model (the caller
+// falls back to the three-launch form).
+hipError_t traps_1bt_launch(const MlpParams &p, hipStream_t stream, const char **variant)
+{
+    if (p.n_rows <= 0) return hipSuccess;
+    if (!p.nets_dev || p.n_nets <= 0 || p.n_nets > 64 || p.lds_n_ot > kBandNOT || p.lds_nkq > 2) return hipErrorNotSupported;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int n_cu = 0;
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    int ft = p.tile_frames == 16 ? 1 : p.tile_frames == 32 ? 2 : ((p.n_rows + 31) / 32 > n_cu / 2 ? 2 : 1);
+    auto pick = [&](int f) -> const Bt1Variant * {
+        for (const Bt1Variant &c : kBt1)
+            if (c.fn[f - 1] && p.net.ksteps <= c.ks && p.net.n_ot <= c.n_ot && p.lds_n_ot <= c.band_n_ot &&
+                bt1_lds_plan((c.ks + 3) / 4, p.net.n_ot, f, p.dct.trap_bands).total <= 160u * 1024u) return &c;
+        return nullptr;
+    };
+    const Bt1Variant *v = pick(ft);
+    if (!v && ft == 2) { ft = 1; v = pick(1); }
+    if (!v) return hipErrorNotSupported;
+    if (variant) *variant = v->name;
+    const void *fn = v->fn[ft - 1];
+    static std::atomic<bool> granted[kNBt1][2][64] = {};
+    const int vi = (int)(v - kBt1);
+    const bool cached = dev >= 0 && dev < 64;
+    if (!cached || !granted[vi][ft - 1][dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        if (cached) granted[vi][ft - 1][dev] = true;
+    }
+    MlpParams args = p;
+    void *kargs[] = {&args};
+    const int bm = 16 * ft;
+    return hipLaunchKernel(fn, dim3((p.n_rows + bm - 1) / bm), dim3(kMlpNW * 64), kargs,
+                           bt1_lds_plan((v->ks + 3) / 4, p.net.n_ot, ft, p.dct.trap_bands).total, stream);
 }
 
 }  // namespace phnrec
