@@ -176,6 +176,66 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
             rowhi[tid] = hi;
         }
         __syncthreads();
+        if (shift <= 16) {
+            // C0 / DCT of every band's trajectory as small MFMA products, like the LCRC projection (lcrc_kernels.hip stage 1):
+            //   out[frame][c] = sum_tap (x[frame][tap] * hamming[tap]) * D[tap][c],   D[:, 0] = 1 (C0, with add_c0), then cos rows
+            // A = 16 frames x 4 taps per step (gathered from the tile with clamped rows), B = the basis (8 registers per
+            // lane, tap 31 = 0), taps summed in ascending order; an item = one (band, frame tile), dealt to the waves two at
+            // a time (two independent chains of eight MFMAs).  The MFMA fuses each multiply-add, <= 1 ulp per term apart from
+            // the features kernel's separate multiply and add: the fused and the three-launch form agree to ~1e-6, not
+            // bit for bit.  (A workgroup's 480 (frame, band) pairs took ~4 us as 341 dependent LDS-fed FMAs per thread.)
+            const int g = lane >> 4, c = lane & 15;
+            const int c0 = d.add_c0 ? 1 : 0;
+            float basis[8];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; s8++) {
+                const int tap = 4 * s8 + g;
+                float v = 0.0f;
+                if (tap < kTrapLen && c < shift) v = (c0 && c == 0) ? 1.0f : ct[(c - c0) * kTrapLen + tap];
+                basis[s8] = v;
+            }
+            const float normc = d.normc;
+            const int n_items = tb * FT;
+            for (int it0 = 2 * wave; it0 < n_items; it0 += 2 * NW) {
+                f4 acc[2];
+                float x[2][8];
+                int ib[2], ifr[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int it = min(it0 + u, n_items - 1);
+                    ib[u] = it / FT; ifr[u] = it - ib[u] * FT;
+                    const int i = 16 * ifr[u] + c;                 // this lane's frame as an A-operand row
+                    const int r = min(r0 + i, d.n_rows - 1), lo = rowlo[i], hi = rowhi[i];
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; s8++) {
+                        const int tap = min(4 * s8 + g, kTrapLen - 1);
+                        const int srow = max(lo, min(hi, r - kShift + tap));
+                        float v = tile[(srow - tbase) * tb + ib[u]];
+                        if (d.use_hamming) v = v * hm[tap];      // sMultVect, traps.cpp:236-243
+                        x[u][s8] = v;
+                    }
+                    acc[u] = (f4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) acc[u] = mfma16x16x4(x[u][s8], basis[s8], acc[u]);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (it0 + u < n_items && c < shift) {          // D layout: row = frame 4g + reg, col = c
+                        const int k = ib[u] * shift + c;
+                        const float mk = nrm[k], dk = nrm[16 * nkq + k];
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const float val = acc[u][reg] * normc;       // CalcC0 / sDCT scaling
+                            float v = val - mk;                          // Normalize nn.cpp:702-716
+                            v *= dk;
+                            xf_store(xf, nkq, 16 * ifr[u] + 4 * g + reg, k, v);
+                        }
+                    }
+                }
+            }
+        } else
         for (int pair = tid; pair < BM * tb; pair += NT) {
             const int i = pair / tb, b = pair - i * tb;
             const int r = min(r0 + i, d.n_rows - 1), lo = rowlo[i], hi = rowhi[i];

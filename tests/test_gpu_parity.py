@@ -632,25 +632,22 @@ def test_other_posterior_systems(capi, oracle_mod, tmp_path):
         assert np.abs(got2 - o.posteriors_batch(mel2, off2)).max() < TOL, name
         assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2)                  # deterministic
         assert np.array_equal(ctx.posteriors_staged(mel2, off2), got2)
-        # 16- and 32-frame workgroups give the same bits; so does 1BT_DCT's separate-launch form (features
-        # kernel + MLP kernel) against the fused default (the projection's arithmetic is the same code)
+        # 16- and 32-frame workgroups give the same bits
         for frames in (16, 32):
             ctx.set_tile_frames(frames)
             assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2), (name, frames)
         ctx.set_tile_frames(0)
-        # the separate-launch forms (PHNREC_TRAPS_UNFUSED=1: features kernel, band nets with grid.y = band, merger): 1BT_DCT's
-        # projection is the same code in both forms -> the same bits; 1BT / 3BT's fused kernel groups the band nets' softmax
-        # sums differently (four strided partials per frame) -> the last bits
+        # the separate-launch forms (PHNREC_TRAPS_UNFUSED=1: features kernel, band nets with grid.y = band, merger) against
+        # the one-launch defaults: the last bits differ -- 1BT_DCT's fused projection runs as MFMA products (fused
+        # multiply-adds) where the features kernel multiplies and adds separately; 1BT / 3BT's fused kernel groups the band
+        # nets' softmax sums differently (four strided partials per frame)
         os.environ["PHNREC_TRAPS_UNFUSED"] = "1"
         try:
             ctx2 = capi.Lcrc(d, nb, system=system, add_c0=add_c0, hamming=hamming)
         finally:
             del os.environ["PHNREC_TRAPS_UNFUSED"]
         other = ctx2.posteriors_batch(mel2, off2)
-        if system == "1BT_DCT":
-            assert np.array_equal(other, got2), name
-        else:
-            assert np.abs(other - got2).max() < 2e-6 and np.abs(other - o.posteriors_batch(mel2, off2)).max() < TOL, name
+        assert np.abs(other - got2).max() < 5e-6 and np.abs(other - o.posteriors_batch(mel2, off2)).max() < TOL, name
         ctx2.close()
         # streaming form == whole-utterance form (window ending at pushed frame i is centred at i - 15)
         u = mel2[int(off2[2]):int(off2[3])][:60]
