@@ -50,6 +50,13 @@
 
 namespace phnrec {
 
+// ln() of a band posterior on its way into the merger (sLn, dspc.h:155-160).
+#ifdef LCRC_FAST_LN     // A/B switch (tools/build_ab_lib.sh): v_log_f32 * ln 2 -- 2 instructions instead of logf's ~25
+__device__ __forceinline__ float band_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+#else
+__device__ __forceinline__ float band_ln(float x) { return logf(x); }
+#endif
+
 // The last-arriver seam of the split-hidden path (guide recipe, write-through form: the partial tiles are stored
 // sc1 -- straight through the XCD's L2, so no release fence (an L2 write-back, ~6 us under load) is needed --,
 // every wave drains its stores, barrier, ONE lane draws a ticket with a relaxed agent-scope add; the workgroup that
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                 dk[j] = mdev[kb + LPF * j];
             }
 #pragma unroll
-            for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? logf(q[j]) : 0.0f;     // sLn dspc.h:155-160
+            for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? band_ln(q[j]) : 0.0f;     // sLn dspc.h:155-160
             if (PROBES && probes && r0 + i < n_rows) {
                 float *dp = n == 0 ? dbg_p0 : dbg_p1;
 #pragma unroll
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
                     dk[j] = mdev[kb + LPF * j];
                 }
 #pragma unroll
-                for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? logf(q[j]) : 0.0f;     // sLn dspc.h:155-160
+                for (int j = 0; j < NV; j++) gl[j] = q[j] > 0.0f ? band_ln(q[j]) : 0.0f;     // sLn dspc.h:155-160
                 float *const row = blk + i * OP + part;
 #pragma unroll
                 for (int j = 0; j < NV; j++) {

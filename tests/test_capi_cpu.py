@@ -124,6 +124,7 @@ def test_no_cpu_fallback():
     with pytest.raises(capi.LcrcError) as e:
         capi.Lcrc(model_dir("PHN_CZ_SPDAT_LCRC_N1500"), 15)
     assert e.value.code == capi.LCRC_E_DEVICE
+    assert capi.load().lcrc_device_warmup(0) == capi.LCRC_E_DEVICE          # the start-up helper says so too
     # and nothing in the product imports, links or loads anything under oracle/
     pat = re.compile(r"from\s+oracle|import\s+oracle|lcrc_oracle|liblcrc_oracle|libphnrec_ref|orc_[a-z_]+\(")
     for root, _, files in os.walk(os.path.join(ROOT, "phnrec_amd")):

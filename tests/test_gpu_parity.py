@@ -408,6 +408,59 @@ def test_baseline_batches_every_row_against_the_oracle(capi, oracle_mod, system,
     ctx.close()
 
 
+def test_clone_shares_the_model_and_outlives_its_source(capi, oracle_mod):
+    """lcrc_clone: a further context over the same weights on the same GPU (what the CLI's second and third context per
+    GPU are).  Same bits as the source; its own settings, staging and streaming state; usable from another thread at the
+    same time; and it keeps the shared device buffers alive after the source is destroyed.  lcrc_device_warmup is the
+    start-up half a caller may run on a helper thread."""
+    import threading
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    assert capi.load().lcrc_device_warmup(0) == 0
+    assert capi.load().lcrc_device_warmup(4096) == capi.LCRC_E_DEVICE
+    a = capi.Lcrc(model_dir(system), 15)
+    a.set_hidden_split(1)
+    b = a.clone()
+    assert b.n_out == a.n_out and b.kernel_name == a.kernel_name and b.net_dims(2) == a.net_dims(2)
+    b.set_hidden_split(1)
+    mel = modelgen.synth_mel(700, 15, seed=31, mean_norm=True)
+    want = a.posteriors(mel)
+    assert np.array_equal(b.posteriors(mel), want)
+    # settings are per context: the clone in the split-f16 arithmetic, the source stays on f32
+    b.set_arithmetic(capi.ARITH_SPLIT_F16)
+    assert np.array_equal(a.posteriors(mel), want)
+    assert 0 < np.abs(b.posteriors(mel) - want).max() < 2e-5
+    b.set_arithmetic(capi.ARITH_F32)
+    # both at once, each on its own thread / stream / staging buffers
+    out = {}
+
+    def work(ctx, key, seed):
+        m = modelgen.synth_mel(3000, 15, seed=seed, mean_norm=True)
+        out[key] = (m, [ctx.posteriors(m) for _ in range(5)])
+
+    ts = [threading.Thread(target=work, args=(a, "a", 1)), threading.Thread(target=work, args=(b, "b", 2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for key, ctx in (("a", a), ("b", b)):
+        m, res = out[key]
+        assert all(np.array_equal(r, res[0]) for r in res)
+    o = oracle_mod.Oracle(model_dir(system), 15)
+    rows = slice(1000, 1064)
+    assert np.abs(out["b"][1][0][rows] - o.posteriors(out["b"][0][1000 - 15:1064 + 15])[15:15 + 64]).max() < TOL
+    # streaming state is the clone's own
+    a.reset()
+    b.reset()
+    pa = a.push(mel[:40])
+    assert np.array_equal(b.push(mel[:40]), pa)
+    a.close()                                   # the clone holds the weights from here on
+    assert np.array_equal(b.posteriors(mel), want)
+    c = b.clone()
+    b.close()
+    assert np.array_equal(c.posteriors(mel), want)
+    c.close()
+
+
 def test_cut_launches_give_the_bits_of_uncut_ones(capi):
     """lcrc_launch cuts a launch into whole rounds of 32-frame workgroups plus a cheaper tail (16-frame workgroups, or the
     split-hidden path when that is allowed).  Sizes around every cut point: with the fused kernels only (as the CLI runs)
