@@ -178,8 +178,10 @@ int main(int argc, char **argv)
     }
     // Every output file is closed by now.  Leave without tearing the HIP runtime down piece by piece (contexts, streams,
     // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.
+    // (tools that live on exit handlers -- rocprofv3 and other preloaded profilers -- get the ordinary exit)
     SR.JoinWarmUp();
     fflush(stdout);
     fflush(stderr);
+    if (getenv("LD_PRELOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("PHNREC_CLEAN_EXIT")) return 0;
     _Exit(0);
 }

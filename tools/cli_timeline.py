@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Where a CLI list run's wall clock goes on the GPU: runs `phnrec` on the configs[3] list under rocprofv3 --kernel-trace
+and reports, per kernel, calls / total / average, and the UNION of the kernels' busy intervals against the span from the
+first launch to the last (idle share = the host could not keep the device fed).  usage: cli_timeline.py [files] [flags...]"""
+import csv
+import glob
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    flags = sys.argv[2:] or ["-F"]
+    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+    mdir = os.path.join(ROOT, "tests", "golden", "models", bench.HU)
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        lst, names, frames = bench.synthetic_list(td, n_files)
+        out = os.path.join(td, "prof")
+        env = dict(os.environ, PHNREC_STATS="1", TMPDIR="/tmp")
+        subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "w.mlf")] + flags, env=env, capture_output=True)   # page cache
+        p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                            exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "o.mlf")] + flags, env=env, capture_output=True, text=True)
+        print([l for l in p.stderr.splitlines() if l.startswith("phnrec:")][-1:])
+        rows = []
+        for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+            rows += list(csv.DictReader(open(f)))
+        iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:]) for r in rows)
+        per = {}
+        for s, e, n in iv:
+            c = per.setdefault(n, [0, 0])
+            c[0] += 1
+            c[1] += e - s
+        span = iv[-1][1] - iv[0][0]
+        busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+        for s, e, _ in iv[1:]:
+            if s > cur_e:
+                busy += cur_e - cur_s
+                cur_s, cur_e = s, e
+            else:
+                cur_e = max(cur_e, e)
+        busy += cur_e - cur_s
+        print("files %d frames %d flags %s" % (n_files, frames, " ".join(flags)))
+        print("span first launch -> last end: %.1f ms; device busy (union of kernels): %.1f ms = %.0f %%; sum of kernel times %.1f ms"
+              % (span / 1e6, busy / 1e6, 100.0 * busy / span, sum(c[1] for c in per.values()) / 1e6))
+        for n, (calls, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            print("  %-62s calls %5d  total %8.2f ms  avg %8.1f us" % (n, calls, tot / 1e6, tot / calls / 1e3))
+
+
+if __name__ == "__main__":
+    main()
