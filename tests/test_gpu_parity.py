@@ -455,7 +455,8 @@ def test_clone_shares_the_model_and_outlives_its_source(capi, oracle_mod):
     assert np.array_equal(b.push(mel[:40]), pa)
     a.close()                                   # the clone holds the weights from here on
     assert np.array_equal(b.posteriors(mel), want)
-    c = b.clone()
+    c = b.clone()                               # (a clone starts from the default settings: automatic hidden split)
+    c.set_hidden_split(1)
     b.close()
     assert np.array_equal(c.posteriors(mel), want)
     c.close()
