@@ -209,7 +209,101 @@ void Fft8(float *d, unsigned nn, const double *tw)
     }
 }
 
+// Sixteen frames per step where the host has AVX-512 (the same operations once more, one frame per lane of a 512-bit
+// register; PHNREC_NO_AVX512=1 keeps to eight).
+bool UseAvx512()
+{
+    static const bool v = UseAvx2() && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&
+                          !getenv("PHNREC_NO_AVX512");
+    return v;
+}
+
+__attribute__((target("avx512f,avx512dq")))
+void Fft16(float *d, unsigned nn, const double *tw)
+{
+    const unsigned n = nn << 1;
+    for (unsigned i = 1, j = 1; i < n; i += 2) {          // bit reversal: whole rows of sixteen
+        if (j > i) {
+            const __m512 a0 = _mm512_loadu_ps(d + 16 * j), a1 = _mm512_loadu_ps(d + 16 * (j + 1));
+            _mm512_storeu_ps(d + 16 * j, _mm512_loadu_ps(d + 16 * i));
+            _mm512_storeu_ps(d + 16 * (j + 1), _mm512_loadu_ps(d + 16 * (i + 1)));
+            _mm512_storeu_ps(d + 16 * i, a0);
+            _mm512_storeu_ps(d + 16 * (i + 1), a1);
+        }
+        unsigned m = n >> 1;
+        while (m >= 2 && j > m) { j -= m; m >>= 1; }
+        j += m;
+    }
+    for (unsigned span = 2; n > span; span <<= 1) {
+        const unsigned stride = span << 1;
+        const double *stage = tw + 2 * (size_t)(span / 2 - 1);
+        for (unsigned m = 1; m < span; m += 2) {
+            const __m512d wr = _mm512_set1_pd(stage[m - 1]), wi = _mm512_set1_pd(stage[m]);
+            for (unsigned i = m; i <= n; i += stride) {
+                const unsigned j = i + span;
+                const __m512 xr = _mm512_loadu_ps(d + 16 * j), xi = _mm512_loadu_ps(d + 16 * (j + 1));
+                const __m512d xr0 = _mm512_cvtps_pd(_mm512_castps512_ps256(xr)), xr1 = _mm512_cvtps_pd(_mm512_extractf32x8_ps(xr, 1));
+                const __m512d xi0 = _mm512_cvtps_pd(_mm512_castps512_ps256(xi)), xi1 = _mm512_cvtps_pd(_mm512_extractf32x8_ps(xi, 1));
+                // tr = (float)(wr * d[j] - wi * d[j+1]),  ti = (float)(wr * d[j+1] + wi * d[j]): products and sum in double
+                const __m256 tr0 = _mm512_cvtpd_ps(_mm512_sub_pd(_mm512_mul_pd(wr, xr0), _mm512_mul_pd(wi, xi0)));
+                const __m256 tr1 = _mm512_cvtpd_ps(_mm512_sub_pd(_mm512_mul_pd(wr, xr1), _mm512_mul_pd(wi, xi1)));
+                const __m256 ti0 = _mm512_cvtpd_ps(_mm512_add_pd(_mm512_mul_pd(wr, xi0), _mm512_mul_pd(wi, xr0)));
+                const __m256 ti1 = _mm512_cvtpd_ps(_mm512_add_pd(_mm512_mul_pd(wr, xi1), _mm512_mul_pd(wi, xr1)));
+                const __m512 tr = _mm512_insertf32x8(_mm512_castps256_ps512(tr0), tr1, 1);
+                const __m512 ti = _mm512_insertf32x8(_mm512_castps256_ps512(ti0), ti1, 1);
+                const __m512 ar = _mm512_loadu_ps(d + 16 * i), ai = _mm512_loadu_ps(d + 16 * (i + 1));
+                _mm512_storeu_ps(d + 16 * j, _mm512_sub_ps(ar, tr));
+                _mm512_storeu_ps(d + 16 * (j + 1), _mm512_sub_ps(ai, ti));
+                _mm512_storeu_ps(d + 16 * i, _mm512_add_ps(ar, tr));
+                _mm512_storeu_ps(d + 16 * (i + 1), _mm512_add_ps(ai, ti));
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// ... and for sixteen frames (AVX-512): layout [i * 16 + f]
+__attribute__((target("avx512f,avx512dq")))
+void MelBanks::Frame16(const float *s, float *out)
+{
+    float *x = x8_.data(), *d = d8_.data(), *en = en8_.data();
+    for (int i = 0; i < vs_; i++)
+        for (int f = 0; f < 16; f++) x[16 * i + f] = s[(size_t)f * step_ + i];
+    if (zmean_) {                                       // sSubtractAverage dspc.h:64-75
+        __m512 avg = _mm512_setzero_ps();
+        for (int i = 0; i < vs_; i++) avg = _mm512_add_ps(avg, _mm512_loadu_ps(x + 16 * i));
+        avg = _mm512_div_ps(avg, _mm512_set1_ps((float)vs_));
+        for (int i = 0; i < vs_; i++) _mm512_storeu_ps(x + 16 * i, _mm512_sub_ps(_mm512_loadu_ps(x + 16 * i), avg));
+    }
+    if (preem_ != 0.0f) {                               // sPreemphasisBW dspc.h:77-84
+        const __m512 pc = _mm512_set1_ps(preem_);
+        for (int n = vs_ - 1; n > 0; --n)
+            _mm512_storeu_ps(x + 16 * n, _mm512_sub_ps(_mm512_loadu_ps(x + 16 * n), _mm512_mul_ps(pc, _mm512_loadu_ps(x + 16 * (n - 1)))));
+        _mm512_storeu_ps(x, _mm512_mul_ps(_mm512_loadu_ps(x), _mm512_set1_ps(1.0f - preem_)));
+    }
+    const __m512 zero = _mm512_setzero_ps();
+    _mm512_storeu_ps(d, zero);
+    for (int i = 0; i < fft_; i++) {
+        _mm512_storeu_ps(d + 16 * (1 + 2 * i), i < vs_ ? _mm512_mul_ps(_mm512_loadu_ps(x + 16 * i), _mm512_set1_ps(hamming_[i])) : zero);
+        _mm512_storeu_ps(d + 16 * (2 + 2 * i), zero);
+    }
+    Fft16(d, (unsigned)fft_, twiddle_.data());
+    for (int b = 0; b < nbanks_full_; b++) _mm512_storeu_ps(en + 16 * b, zero);
+    for (int i = fftlo_; i <= ffthi_; i++) {            // _mbApply dspc.cpp:236-269
+        const __m512 re = _mm512_loadu_ps(d + 16 * (1 + 2 * i)), im = _mm512_loadu_ps(d + 16 * (2 + 2 * i));
+        const __m512 p = _mm512_add_ps(_mm512_mul_ps(re, re), _mm512_mul_ps(im, im));     // cPower dspc.h:141-146
+        const __m512 v = _mm512_mul_ps(_mm512_set1_ps(coeffs_[i]), p);
+        const int b = bank_of_[i];
+        if (b > 0) _mm512_storeu_ps(en + 16 * (b - 1), _mm512_add_ps(_mm512_loadu_ps(en + 16 * (b - 1)), v));
+        if (b < nbanks_full_) _mm512_storeu_ps(en + 16 * b, _mm512_add_ps(_mm512_loadu_ps(en + 16 * b), _mm512_sub_ps(p, v)));
+    }
+    for (int f = 0; f < 16; f++)
+        for (int b = 0; b < nbanks_; b++) {
+            const float e = en[16 * b + f];
+            out[(size_t)f * nbanks_ + b] = e > 0.0f ? logf(e) : 0.0f;                    // sLn (libm's scalar logf)
+        }
+}
 
 // MelBanks::ProcessFrame for the eight frames that start at s, s + step, ...: out[f * nbanks + b]
 __attribute__((target("avx2")))
@@ -264,9 +358,12 @@ void MelBanks::Compute(std::vector<float> &samples, int n, std::vector<float> &o
     out.assign((size_t)frames * nbanks_, 0.0f);
     int t = 0;
     if (UseAvx2() && frames >= 8) {
-        x8_.resize(8 * (size_t)vs_);
-        d8_.resize(8 * (2 * (size_t)fft_ + 1));
-        en8_.resize(8 * (size_t)nbanks_full_);
+        const size_t w = UseAvx512() && frames >= 16 ? 16 : 8;
+        x8_.resize(w * (size_t)vs_);
+        d8_.resize(w * (2 * (size_t)fft_ + 1));
+        en8_.resize(w * (size_t)nbanks_full_);
+        if (w == 16)
+            for (; t + 16 <= frames; t += 16) Frame16(s + (size_t)t * step_, &out[(size_t)t * nbanks_]);
         for (; t + 8 <= frames; t += 8) Frame8(s + (size_t)t * step_, &out[(size_t)t * nbanks_]);
     }
     std::vector<float> frame(vs_);

@@ -46,11 +46,12 @@ private:
     void Init();
     void Frame(float *frame, float *out);
     void Frame8(const float *first, float *out);      // eight consecutive frames in lockstep (AVX2), same arithmetic per frame
+    void Frame16(const float *first, float *out);     // sixteen (AVX-512)
     int nbanks_ = 15, nbanks_full_ = -1, fs_ = 8000, vs_ = 200, step_ = 80, fft_ = 256;
     float preem_ = 0.0f, lo_ = 64.0f, hi_ = 4000.0f;
     bool zmean_ = false, init_ = false;
     std::vector<float> hamming_, coeffs_, fft_buf_, en_;
-    std::vector<float> x8_, d8_, en8_;               // scratch of Frame8: [index][8 frames]
+    std::vector<float> x8_, d8_, en8_;               // scratch of Frame8 / Frame16: [index][8 or 16 frames]
     std::vector<double> twiddle_;
     std::vector<short> bank_of_;
     int fftlo_ = 0, ffthi_ = 0;

@@ -253,10 +253,11 @@ def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, 
 @pytest.mark.parametrize("system,options", [(CZ, {}), (EN, {}), (CZ, {"preem_coef": "0.97", "z_mean_source": "true"}),
                                            (CZ, {"nbanks_full": "19"})])
 def test_front_end_eight_frames_in_lockstep_equals_the_plain_form(tmp_path, system, options):
-    """The host front-end runs eight frames side by side on AVX2 (one frame per vector lane, the scalar code's IEEE
-    operations in the scalar code's order) and the tail one frame at a time; PHNREC_NO_AVX2=1 runs every frame the plain
-    way.  The `-t par` dumps must be the same bytes -- also with pre-emphasis, source mean removal and a wider filter
-    bank switched on, for lin16 and A-law, and for lengths around the group size (0 ... 9 frames, and a long one)."""
+    """The host front-end runs sixteen (AVX-512) or eight (AVX2) frames side by side -- one frame per vector lane, the
+    scalar code's IEEE operations in the scalar code's order -- and the tail one frame at a time; PHNREC_NO_AVX512=1
+    keeps to groups of eight, PHNREC_NO_AVX2=1 runs every frame the plain way.  The `-t par` dumps must be the same
+    bytes -- also with pre-emphasis, source mean removal and a wider filter bank switched on, for lin16 and A-law, and
+    for lengths around the group sizes (1 ... 33 frames, and a long one)."""
     d = tmp_path / "m"
     shutil.copytree(model_dir(system), d)
     if options:
@@ -277,18 +278,18 @@ def test_front_end_eight_frames_in_lockstep_equals_the_plain_form(tmp_path, syst
     rng = np.random.default_rng(5)
     rate = modelgen.SYSTEMS[system]["sample_freq"]
     vs, step = rate // 40, rate // 100
-    for frames in (1, 7, 8, 9, 17, 1203):
+    for frames in (1, 7, 8, 9, 15, 16, 17, 25, 33, 1203):
         n = (frames - 1) * step + vs + int(rng.integers(0, step))
         sig = (rng.normal(0, 3000, n) + 8000 * np.sin(np.arange(n) * 0.05)).clip(-32768, 32767).astype("<i2")
         raw = tmp_path / "x.raw"
         sig.tofile(raw)
         for fmt in ("lin16", "alaw"):
             outs = []
-            for env in ({}, {"PHNREC_NO_AVX2": "1"}):
+            for env in ({}, {"PHNREC_NO_AVX512": "1"}, {"PHNREC_NO_AVX2": "1"}):
                 out = tmp_path / ("o%d.mel" % len(outs))
                 p = subprocess.run([BIN, "-c", str(d), "-w", fmt, "-i", str(raw), "-t", "par", "-o", str(out)],
                                    capture_output=True, text=True, env=dict(os.environ, **env))
                 assert p.returncode == 0, p.stderr
                 outs.append(out.read_bytes())
-            assert outs[0] == outs[1], (frames, fmt)
+            assert outs[0] == outs[1] == outs[2], (frames, fmt)
             assert read_htk_header(str(tmp_path / "o0.mel"))[0] == (frames if fmt == "lin16" else (2 * n - vs) // step + 1)
