@@ -185,7 +185,20 @@ void Fft8(float *d, unsigned nn, const double *tw)
     for (unsigned span = 2; n > span; span <<= 1) {
         const unsigned stride = span << 1;
         const double *stage = tw + 2 * (size_t)(span / 2 - 1);
-        for (unsigned m = 1; m < span; m += 2) {
+        // The first butterfly of every stage has the twiddle (1, 0) exactly (the recurrence starts there): its
+        // (float)(1.0 * re - 0.0 * im) is `re` itself and (float)(1.0 * im + 0.0 * re) is `im` -- up to the sign of a
+        // zero, which no later operation can turn into a different value (zeros only meet sums, products and the
+        // power spectrum's squares).  A quarter of all butterflies: they skip the conversions and the products.
+        for (unsigned i = 1; i <= n; i += stride) {
+            const unsigned j = i + span;
+            const __m256 tr = _mm256_loadu_ps(d + 8 * j), ti = _mm256_loadu_ps(d + 8 * (j + 1));
+            const __m256 ar = _mm256_loadu_ps(d + 8 * i), ai = _mm256_loadu_ps(d + 8 * (i + 1));
+            _mm256_storeu_ps(d + 8 * j, _mm256_sub_ps(ar, tr));
+            _mm256_storeu_ps(d + 8 * (j + 1), _mm256_sub_ps(ai, ti));
+            _mm256_storeu_ps(d + 8 * i, _mm256_add_ps(ar, tr));
+            _mm256_storeu_ps(d + 8 * (i + 1), _mm256_add_ps(ai, ti));
+        }
+        for (unsigned m = 3; m < span; m += 2) {
             const __m256d wr = _mm256_set1_pd(stage[m - 1]), wi = _mm256_set1_pd(stage[m]);
             for (unsigned i = m; i <= n; i += stride) {
                 const unsigned j = i + span;
@@ -237,7 +250,16 @@ void Fft16(float *d, unsigned nn, const double *tw)
     for (unsigned span = 2; n > span; span <<= 1) {
         const unsigned stride = span << 1;
         const double *stage = tw + 2 * (size_t)(span / 2 - 1);
-        for (unsigned m = 1; m < span; m += 2) {
+        for (unsigned i = 1; i <= n; i += stride) {         // twiddle (1, 0): see Fft8
+            const unsigned j = i + span;
+            const __m512 tr = _mm512_loadu_ps(d + 16 * j), ti = _mm512_loadu_ps(d + 16 * (j + 1));
+            const __m512 ar = _mm512_loadu_ps(d + 16 * i), ai = _mm512_loadu_ps(d + 16 * (i + 1));
+            _mm512_storeu_ps(d + 16 * j, _mm512_sub_ps(ar, tr));
+            _mm512_storeu_ps(d + 16 * (j + 1), _mm512_sub_ps(ai, ti));
+            _mm512_storeu_ps(d + 16 * i, _mm512_add_ps(ar, tr));
+            _mm512_storeu_ps(d + 16 * (i + 1), _mm512_add_ps(ai, ti));
+        }
+        for (unsigned m = 3; m < span; m += 2) {
             const __m512d wr = _mm512_set1_pd(stage[m - 1]), wi = _mm512_set1_pd(stage[m]);
             for (unsigned i = m; i <= n; i += stride) {
                 const unsigned j = i + span;
