@@ -31,6 +31,16 @@ def main():
         for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
             rows += list(csv.DictReader(open(f)))
         iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:]) for r in rows)
+        if os.environ.get("TIMELINE_ROWS"):          # the first launches one by one, and every idle gap above 0.3 ms
+            t0 = iv[0][0]
+            q = {(int(r["Start_Timestamp"]), int(r["End_Timestamp"])): r.get("Queue_Id", "?") for r in rows}
+            for s_, e_, n_ in iv[:int(os.environ["TIMELINE_ROWS"])]:
+                print("    +%9.3f ms  %8.1f us  queue %-3s %s" % ((s_ - t0) / 1e6, (e_ - s_) / 1e3, q[(s_, e_)], n_[-40:]))
+            end = iv[0][1]
+            for s_, e_, n_ in iv[1:]:
+                if s_ - end > 300000:
+                    print("    idle %7.3f ms before +%9.3f ms (%s)" % ((s_ - end) / 1e6, (s_ - t0) / 1e6, n_[-30:]))
+                end = max(end, e_)
         per = {}
         for s, e, n in iv:
             c = per.setdefault(n, [0, 0])
