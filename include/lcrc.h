@@ -41,7 +41,7 @@ enum {
     LCRC_E_MODEL   = -3,   /* a model file is malformed or nets are inconsistent       */
     LCRC_E_DEVICE  = -4,   /* no usable HIP device / kernel launch or copy failed      */
     LCRC_E_NOMEM   = -5,
-    LCRC_E_UNSUPPORTED = -6 /* posteriors/system other than LCRC, trap_len != 31, ...    */
+    LCRC_E_UNSUPPORTED = -6 /* a call that exists for the fused LCRC kernels only, nets too large, ... */
 };
 
 typedef struct lcrc_ctx lcrc_ctx;
@@ -54,9 +54,15 @@ typedef struct lcrc_ctx lcrc_ctx;
  * DIR/weights/merger.*, DIR/norms/merger.norms (path macros config.h:31-39;
  * .nbin preferred, ASCII parsed otherwise, nn.cpp:594-621), re-packs the
  * weights into MFMA fragment order and uploads them to GPU `device_id`.
- * trap_len must be 31 and add_c0 non-zero (the only LCRC geometry the shipped
- * systems and traps.cpp:285-343 define).  Unlike Traps::Init it returns an
- * error instead of exit(1). */
+ * trap_len = 31, add_c0 non-zero and band nets of nbanks * 11 inputs -- the
+ * geometry of every shipped system -- run the fused kernels.  Any other geometry
+ * Traps accepts (SetTrapLen 2..255, odd or even; SetAddC0(false); another number
+ * of coefficients per band, traps.cpp:285-343 as written, incl. its walk over
+ * be_mat for even lengths) is computed by general kernels in three launches
+ * (features, the two band nets, the merger: lcrc_kernel_name "lcrc_general"):
+ * correct to the same tolerance, not tuned; lcrc_posteriors_rows, the stage
+ * probes, lcrc_model_info and the split-f16 arithmetic exist for the fused
+ * kernels only.  Unlike Traps::Init it returns an error instead of exit(1). */
 int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
                 int add_c0, int device_id);
 /* Optional: starts the HIP runtime and GPU `device_id`'s context (~0.2 s in a fresh process, by far the largest part of
@@ -75,7 +81,8 @@ int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src);
 /* The other values of posteriors/system ("next" row f4): "1BT_DCT" (the schema default, srec.cpp:69: C0 / DCT
  * of every band's 31-point trajectory into one net), "1BT" (one 31-input net per band, -ln of their outputs
  * into the merger) and "3BT" (as the reference codes it: 1BT over the first nbanks - 2 bands), with
- * posteriors/hamming and posteriors/add_c0 (traps.cpp:88-171,220-283,347-358,409-433); "LCRC" forwards to
+ * posteriors/hamming and posteriors/add_c0 (traps.cpp:88-171,220-283,347-358,409-433), at any posteriors/length in
+ * 2..255 (31: one fused launch per batch; other lengths: features / band nets / merger launches); "LCRC" forwards to
  * lcrc_create (which ignores hamming, as the reference does).  All entry points below work on such a
  * context except lcrc_posteriors_probe and lcrc_model_info.  These systems run as separate feature /
  * MLP launches, not as one fused kernel.  lcrc_net_dims: band classifiers first, the merger last. */

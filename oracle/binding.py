@@ -238,20 +238,22 @@ def phndec(logpost, n_phonemes, states=3, time_pruning=40, wpenalty=0.0):
 
 
 class TrapsOracle:
-    """traps_oracle.c: the 1BT_DCT / 1BT / 3BT variants of Traps (stateless whole-utterance form)."""
+    """traps_oracle.c: the 1BT_DCT / 1BT / 3BT variants of Traps at any posteriors/length, and LCRC with run-time
+    geometry (any length, add_c0 on or off, any number of coefficients per band) -- stateless whole-utterance form."""
 
-    def __init__(self, model_dir, system, nbanks, add_c0=True, hamming=False):
+    def __init__(self, model_dir, system, nbanks, add_c0=True, hamming=False, trap_len=31):
         L = lib()
-        L.orc_traps_create.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_traps_create_geometry.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_traps_destroy.argtypes = [C.c_void_p]
         L.orc_traps_num_outputs.argtypes = [C.c_void_p]
         L.orc_traps_num_band_nets.argtypes = [C.c_void_p]
         L.orc_traps_posteriors_batch.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int, _f32p, C.c_void_p]
         self.L = L
         self.h = C.c_void_p()
-        rc = L.orc_traps_create(C.byref(self.h), model_dir.encode(), system.encode(), nbanks, int(add_c0), int(hamming))
+        rc = L.orc_traps_create_geometry(C.byref(self.h), model_dir.encode(), system.encode(), nbanks, int(add_c0),
+                                         int(hamming), int(trap_len))
         if rc:
-            raise OSError("orc_traps_create(%s, %s) -> %d" % (model_dir, system, rc))
+            raise OSError("orc_traps_create_geometry(%s, %s, length %d) -> %d" % (model_dir, system, trap_len, rc))
         self.nbanks = nbanks
         self.n_out = L.orc_traps_num_outputs(self.h)
         self.n_band_nets = L.orc_traps_num_band_nets(self.h)
@@ -302,6 +304,8 @@ def _ref(blas):
         L.refshim_traps_create.argtypes = [C.c_char_p, C.c_int, C.c_int]
         L.refshim_traps_create_system.restype = C.c_void_p
         L.refshim_traps_create_system.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.refshim_traps_create_geometry.restype = C.c_void_p
+        L.refshim_traps_create_geometry.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.refshim_traps_destroy.argtypes = [C.c_void_p]
         L.refshim_traps_reset.argtypes = [C.c_void_p]
         L.refshim_traps_num_outs.argtypes = [C.c_void_p]
@@ -321,13 +325,13 @@ def _ref(blas):
 class RefTraps:
     """The reference's own Traps object (traps.h:59-75) via ref_shim.cpp."""
 
-    def __init__(self, model_dir, nbanks, bunch=5, blas=False, system="LCRC", add_c0=True, hamming=False):
+    def __init__(self, model_dir, nbanks, bunch=5, blas=False, system="LCRC", add_c0=True, hamming=False, trap_len=31):
         self.L = _ref(blas)
         self.nbanks = nbanks
         self.bunch = bunch
         d = model_dir if model_dir.endswith("/") else model_dir + "/"     # Traps::Init concatenates dir + "weights/..."
-        self.h = self.L.refshim_traps_create_system(d.encode(), system.encode(), nbanks, bunch,
-                                                    int(add_c0), int(hamming))
+        self.h = self.L.refshim_traps_create_geometry(d.encode(), system.encode(), nbanks, bunch,
+                                                      int(add_c0), int(hamming), int(trap_len))
         if not self.h:
             raise ValueError("unknown posteriors/system " + system)
         self.n_out = self.L.refshim_traps_num_outs(self.h)

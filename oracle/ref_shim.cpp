@@ -34,15 +34,15 @@ extern "C" {
 
 // SpeechRec::Init's setter sequence for system=LCRC (srec.cpp:605-624), then
 // Traps::Init(dir).  Init exit(1)s on a bad model directory (traps.cpp:141-145).
-void *refshim_traps_create_system(const char *dir, const char *system, int nbanks, int bunch, int add_c0,
-                                  int hamming)
+void *refshim_traps_create_geometry(const char *dir, const char *system, int nbanks, int bunch, int add_c0,
+                                    int hamming, int trap_len)
 {
     TrapsProbe *t = new TrapsProbe;
     char *sys = strdup(system);
     const bool known = t->SetSystem(sys);
     free(sys);
     if (!known) { delete t; return 0; }
-    t->SetTrapLen(31);
+    t->SetTrapLen(trap_len);
     t->SetHamming(hamming != 0);
     t->SetNBanks(nbanks);
     t->SetAddC0(add_c0 != 0);
@@ -51,6 +51,12 @@ void *refshim_traps_create_system(const char *dir, const char *system, int nbank
     t->Init(d);
     free(d);
     return t;
+}
+
+void *refshim_traps_create_system(const char *dir, const char *system, int nbanks, int bunch, int add_c0,
+                                  int hamming)
+{
+    return refshim_traps_create_geometry(dir, system, nbanks, bunch, add_c0, hamming, 31);
 }
 
 void *refshim_traps_create(const char *dir, int nbanks, int bunch)

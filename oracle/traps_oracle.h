@@ -25,10 +25,15 @@ typedef struct orc_traps orc_traps;
  * system: "1BT_DCT" (merger only), "1BT" (nbanks band nets), "3BT" (nbanks - 2 band nets). */
 int  orc_traps_create(orc_traps **out, const char *model_dir, const char *system, int nbanks,
                       int add_c0, int hamming);
+/* ... at any posteriors/length (Traps::SetTrapLen), and for system "LCRC" as well (two band nets, windows from files,
+ * traps.cpp:285-343,435-461) -- the LCRC restatement with run-time geometry, incl. add_c0 = 0; lcrc_oracle.h is the one
+ * for the shipped geometry (length 31) and also knows the streaming form. */
+int  orc_traps_create_geometry(orc_traps **out, const char *model_dir, const char *system, int nbanks,
+                               int add_c0, int hamming, int trap_len);
 void orc_traps_destroy(orc_traps *t);
 int  orc_traps_num_outputs(const orc_traps *t);
 int  orc_traps_num_band_nets(const orc_traps *t);
-/* post[r] = F(mel[clamp(r-15..r+15)]) per utterance b = rows [off[b], off[b+1]) -- what ProcessOffline's
+/* post[r] = F(mel[clamp(r-15..r+15)]) (length 31; in general r - (L-1 - (L-1)/2) .. + L - 1) per utterance b = rows [off[b], off[b+1]) -- what ProcessOffline's
  * prime / main / flush sequence yields for any system (srec.cpp:1035-1059).
  * merger_in (optional, [n][merger inputs]) receives the merger's input rows. */
 void orc_traps_posteriors_batch(const orc_traps *t, const float *mel, const int *off, int n_utts,

@@ -245,16 +245,22 @@ bool SpeechRec::Init(const std::string &config_file)
     }
     traps_enabled_ = C.GetBool("posteriors", "enabled");
     if (traps_enabled_) {
-        if (C.GetInt("posteriors", "length") != 31 || (sys == "LCRC" && !C.GetBool("posteriors", "add_c0")))
-            return Fail("the GPU path implements posteriors/length=31 (and add_c0=true for system=LCRC)\n");
+        const int length = C.GetInt("posteriors", "length");
+        if (length < 2 || length > 255) return Fail("posteriors/length must lie in 2..255\n");
         // host-only validation of the model directory (the GPU is claimed lazily, when a
-        // par -> post conversion is actually requested)
+        // par -> post conversion is actually requested).  LCRC at the shipped geometry (31 frames, C0, 11 inputs per
+        // band): all three nets and the windows; any other geometry or system: the merger (the rest when a context is
+        // created).
         int dims[9];
-        if (sys == "LCRC") {
-            if (lcrc_model_info(config_dir_.c_str(), nbanks_, dims, nullptr, 0, nullptr) != LCRC_OK) {
+        int info = LCRC_E_UNSUPPORTED;
+        if (sys == "LCRC" && length == 31 && C.GetBool("posteriors", "add_c0")) {
+            info = lcrc_model_info(config_dir_.c_str(), nbanks_, dims, nullptr, 0, nullptr);
+            if (info != LCRC_OK && info != LCRC_E_UNSUPPORTED) {
                 snprintf(msg, sizeof msg, "%s\n", lcrc_last_error(nullptr));
                 return Fail(msg);
             }
+        }
+        if (info == LCRC_OK) {
             n_out_ = dims[8];
         } else {
             n_out_ = lcrc_model_outputs(config_dir_.c_str(), sys.c_str());

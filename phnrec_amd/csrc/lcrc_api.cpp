@@ -30,7 +30,9 @@
 
 using namespace phnrec;
 
-enum { SYS_LCRC = 0, SYS_1BT_DCT = 1, SYS_1BT = 2, SYS_3BT = 3 };
+// SYS_LCRC: the fused kernels (length 31, add_c0, 11 coefficients per band: every shipped model); SYS_LCRC_GEN: LCRC at any
+// other geometry the reference accepts, composed from the general features / MLP kernels like the unfused other systems
+enum { SYS_LCRC = 0, SYS_1BT_DCT = 1, SYS_1BT = 2, SYS_3BT = 3, SYS_LCRC_GEN = 4 };
 
 // split-f16 operand images of one net (pack_net_h2)
 struct H2Images {
@@ -73,8 +75,10 @@ struct lcrc_ctx {
     const NetDev *d_band_nets = nullptr; // the same on the device (one launch runs them all)
     const int *d_band_col = nullptr;     // first merger-input column of each band net
     NetDev band_max = {};                // maxima of ksteps / nkq / n_ot over the band nets
-    float *d_hamm31 = nullptr, *d_costab31 = nullptr;
+    float *d_hamm31 = nullptr, *d_costab31 = nullptr;    // (named for the usual length; sized by trap_len)
     float normc31 = 0.f;
+    int trap_len = kTrapLen;             // posteriors/length; anything but 31 runs the general (unfused) kernels
+    float *d_win_gen = nullptr;          // SYS_LCRC_GEN: [2][half] windows
     float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
     size_t cap_feat_rows = 0;
     bool traps_unfused = false;          // PHNREC_TRAPS_UNFUSED=1: every system as separate features / MLP launches (A/B, tests)
@@ -476,7 +480,9 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
         if (c->d_minp) (void)hipFree(c->d_minp);
         c->d_feat = c->d_minp = nullptr;
         c->cap_feat_rows = 0;
-        const size_t feat = c->system == SYS_1BT_DCT ? cap * Km : cap * (size_t)c->trap_bands * kTrapLen;
+        const size_t feat = c->system == SYS_1BT_DCT ? cap * Km
+                            : c->system == SYS_LCRC_GEN ? cap * 2 * (size_t)c->band_nets[0].n_inp
+                                                        : cap * (size_t)c->trap_bands * c->trap_len;
         HIP_TRY(c, hipMalloc((void **)&c->d_feat, feat * sizeof(float)));
         if (c->system != SYS_1BT_DCT) HIP_TRY(c, hipMalloc((void **)&c->d_minp, cap * Km * sizeof(float)));
         c->cap_feat_rows = cap;
@@ -485,9 +491,11 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     memset(&f, 0, sizeof f);
     f.mel = d_mel; f.off = d_off; f.n_utts = n_utts; f.n_rows = n_rows;
     f.nbanks = c->nbanks; f.trap_bands = c->trap_bands;
-    f.mode = c->system == SYS_1BT_DCT ? 1 : 0;
+    f.mode = c->system == SYS_1BT_DCT ? 1 : c->system == SYS_LCRC_GEN ? 2 : 0;
     f.use_hamming = c->use_hamming ? 1 : 0; f.add_c0 = c->add_c0 ? 1 : 0; f.shift = c->shift;
     f.hamming = c->d_hamm31; f.costab = c->d_costab31; f.normc = c->normc31;
+    f.trap_len = c->trap_len; f.back = c->trap_len - 1 - (c->trap_len - 1) / 2; f.half = (c->trap_len - 1) / 2 + 1;
+    f.win = c->d_win_gen;
     f.out = c->d_feat;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
     MlpParams m;
@@ -515,11 +523,12 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     if (!fused_dct) HIP_TRY(c, traps_features_launch(f, s));
     const float *merger_in = c->d_feat;
     if (c->system != SYS_1BT_DCT) {
-        m.net = c->band_max;                 // one launch, grid.y = band
-        m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = c->trap_bands;
-        m.in = c->d_feat; m.in_ld = kTrapLen; m.in_net_stride = (long)n_rows * kTrapLen;
+        m.net = c->band_max;                 // one launch, grid.y = band net
+        const long in_ld = c->system == SYS_LCRC_GEN ? c->band_nets[0].n_inp : c->trap_len;
+        m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = (int)c->band_nets.size();
+        m.in = c->d_feat; m.in_ld = in_ld; m.in_net_stride = (long)n_rows * in_ld;
         m.out = c->d_minp; m.out_ld = (long)Km;
-        m.neg_log = 1;
+        m.neg_log = c->system == SYS_LCRC_GEN ? 2 : 1;
         HIP_TRY(c, mlp_launch(m, s));
         m.nets_dev = nullptr; m.out_col = nullptr; m.n_nets = 0;
         merger_in = c->d_minp;
@@ -688,7 +697,8 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
 }
 
 // Files + consistency checks shared by lcrc_create and lcrc_model_info (no GPU needed).
-int load_model(const char *model_dir, int nbanks, HostNet *nets, std::vector<float> *win)
+// half: taps per half context (windows/band{0,1}.window hold that many values); *ncoef: inputs per band of the band nets.
+int load_model(const char *model_dir, int nbanks, HostNet *nets, std::vector<float> *win, int half = kHalf, int *ncoef = nullptr)
 {
     const std::string dir(model_dir);
     const char *names[3] = {"band0", "band1", "merger"};
@@ -702,10 +712,16 @@ int load_model(const char *model_dir, int nbanks, HostNet *nets, std::vector<flo
     }
     for (int i = 0; i < 2; i++) {
         const std::string w = dir + "/windows/band" + std::to_string(i) + ".window";
-        if (!load_window(w, kHalf, win[i]))
+        if (!load_window(w, half, win[i]))
             return fail(nullptr, LCRC_E_IO, "ERROR: Unable load window: " + w);
     }
-    if (nets[0].n_inp != nbanks * kNCoef || nets[1].n_inp != nbanks * kNCoef)
+    // (the reference derives the coefficients per band from net 0 and strides both nets' rows by their own sizes,
+    //  traps.cpp:318-334: anything but equal sizes that nbanks divides reads or leaves garbage there)
+    if (nets[0].n_inp != nets[1].n_inp || nets[0].n_inp % nbanks != 0)
+        return fail(nullptr, LCRC_E_MODEL, "band classifier input size " + std::to_string(nets[0].n_inp) +
+                    " is not nbanks x (coefficients per band), nbanks = " + std::to_string(nbanks));
+    if (ncoef) *ncoef = nets[0].n_inp / nbanks;
+    else if (nets[0].n_inp != nbanks * kNCoef)
         return fail(nullptr, LCRC_E_MODEL, "band classifier input size " + std::to_string(nets[0].n_inp) +
                     " != nbanks*11 = " + std::to_string(nbanks * kNCoef));
     if (nets[0].n_out + nets[1].n_out != nets[2].n_inp)
@@ -735,8 +751,12 @@ int lcrc_model_info(const char *model_dir, int nbanks, int *dims9, char *kernel,
     if (!model_dir || nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_model_info: bad argument");
     HostNet nets[3];
     std::vector<float> win[2];
-    int rc = load_model(model_dir, nbanks, nets, win);
+    int ncoef = 0;
+    int rc = load_model(model_dir, nbanks, nets, win, kHalf, &ncoef);
     if (rc) return rc;
+    if (ncoef != kNCoef)
+        return fail(nullptr, LCRC_E_UNSUPPORTED, "band classifiers take " + std::to_string(ncoef) +
+                    " inputs per band: a geometry of the general kernels, not of the fused kernel (11)");
     NetDev nd[3];
     for (int i = 0; i < 3; i++) {
         shape_of(nets[i], nd[i]);
@@ -791,6 +811,138 @@ static int open_context(lcrc_ctx **out, int nbanks, int device_id)
     return LCRC_OK;
 }
 
+// The systems that are composed of general kernels: 1BT_DCT / 1BT / 3BT at any posteriors/length (with fused forms at
+// the usual 31), and LCRC at a geometry other than the shipped models' (SYS_LCRC_GEN).
+static int create_traps(lcrc_ctx **out, const char *model_dir, int sys, int nbanks, int trap_len, int add_c0, int hamming, int device_id)
+{
+    *out = nullptr;
+    if (nbanks <= (sys == SYS_3BT ? 2 : 0)) return fail(nullptr, LCRC_E_ARG, "lcrc_create_system: nbanks too small");
+    if (trap_len < 2 || trap_len > kMaxTrapLen)
+        return fail(nullptr, LCRC_E_ARG, "posteriors/length must lie in 2.." + std::to_string(kMaxTrapLen));
+    const int trap_bands = sys == SYS_3BT ? nbanks - 2 : nbanks;        // traps.cpp:95-97
+    const int half = (trap_len - 1) / 2 + 1;                            // traps.cpp:93,288
+    const bool lcrc = sys == SYS_LCRC_GEN;
+
+    // -- files first (traps.cpp:119-166)
+    const std::string dir(model_dir);
+    std::vector<HostNet> band(sys == SYS_1BT_DCT ? 0 : lcrc ? 2 : trap_bands);
+    std::vector<float> win[2];
+    HostNet merger;
+    auto load = [&](const std::string &name, HostNet &net) -> int {
+        const std::string w = dir + "/weights/" + name + ".weights", n = dir + "/norms/" + name + ".norms";
+        NetStatus s = load_net(w, n, net);
+        if (s != NET_OK)
+            return fail(nullptr, s == NET_NOWEIGHTS || s == NET_NONORMS ? LCRC_E_IO : LCRC_E_MODEL,
+                        "ERROR: Loading neural network: weights " + w + ", norms " + n + " (" + net_status_str(s) + ")");
+        return LCRC_OK;
+    };
+    size_t merger_in = 0;
+    for (int i = 0; i < (int)band.size(); i++) {
+        int rc = load("band" + std::to_string(i), band[i]);
+        if (rc) return rc;
+        // the reference hands every band net exactly trap_len values per frame (traps.cpp:253-259)
+        if (!lcrc && band[i].n_inp != trap_len)
+            return fail(nullptr, LCRC_E_MODEL, "band classifier " + std::to_string(i) + " takes " +
+                        std::to_string(band[i].n_inp) + " inputs, the trajectory has " + std::to_string(trap_len));
+        merger_in += band[i].n_out;
+    }
+    if (lcrc) {
+        for (int i = 0; i < 2; i++) {
+            const std::string w = dir + "/windows/band" + std::to_string(i) + ".window";
+            if (!load_window(w, half, win[i])) return fail(nullptr, LCRC_E_IO, "ERROR: Unable load window: " + w);
+        }
+        // (coefficients per band from net 0, both nets' rows strided by their own sizes, traps.cpp:318-334)
+        if (band[0].n_inp != band[1].n_inp || band[0].n_inp % nbanks != 0 || band[0].n_inp / nbanks - (add_c0 ? 1 : 0) < 0)
+            return fail(nullptr, LCRC_E_MODEL, "band classifier input size " + std::to_string(band[0].n_inp) +
+                        " is not nbanks x (coefficients per band), nbanks = " + std::to_string(nbanks));
+    }
+    {
+        int rc = load("merger", merger);
+        if (rc) return rc;
+    }
+    // values per band of the C0 / DCT features: merger_input_shift (traps.cpp:170), LCRC: the band nets' inputs per band
+    const int shift = lcrc ? band[0].n_inp / nbanks : merger.n_inp / trap_bands;
+    if (sys == SYS_1BT_DCT) {
+        if (shift * trap_bands != merger.n_inp || shift < 1 || shift - (add_c0 ? 1 : 0) > trap_len)
+            return fail(nullptr, LCRC_E_MODEL, "merger input size " + std::to_string(merger.n_inp) +
+                        " is not nbanks x (coefficients per band)");
+    } else if ((int)merger_in != merger.n_inp) {
+        return fail(nullptr, LCRC_E_MODEL, "merger input size does not equal the band classifiers' outputs");
+    }
+
+    lcrc_ctx *c = nullptr;
+    {
+        int rc = open_context(&c, nbanks, device_id);
+        if (rc) return rc;
+    }
+    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
+    c->system = sys;
+    c->trap_len = trap_len;
+    {
+        const char *e = getenv("PHNREC_TRAPS_UNFUSED");
+        c->traps_unfused = (e && *e == '1') || trap_len != kTrapLen || lcrc;     // the fused forms are written for 31
+    }
+    c->trap_bands = trap_bands;
+    c->shift = shift;
+    c->use_hamming = hamming != 0;
+    c->add_c0 = add_c0 != 0;
+    c->band_nets.resize(band.size());
+    for (size_t i = 0; i < band.size(); i++) {
+        int rc = pack_net(c, band[i], c->band_nets[i]);
+        if (rc) return bail(rc);
+        if (!mlp_supports(c->band_nets[i])) { c->err = "band classifier too large (<= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
+    }
+    if (!c->band_nets.empty()) {
+        std::vector<int> col(c->band_nets.size());
+        int acc_col = 0;
+        c->band_max = c->band_nets[0];
+        for (size_t i = 0; i < c->band_nets.size(); i++) {
+            col[i] = acc_col;
+            acc_col += c->band_nets[i].n_out;
+            c->band_max.ksteps = std::max(c->band_max.ksteps, c->band_nets[i].ksteps);
+            c->band_max.nkq = std::max(c->band_max.nkq, c->band_nets[i].nkq);
+            c->band_max.n_ot = std::max(c->band_max.n_ot, c->band_nets[i].n_ot);
+        }
+        if (dev_upload(c, c->band_nets, &c->d_band_nets) != hipSuccess || dev_upload(c, col, &c->d_band_col) != hipSuccess) {
+            c->err = "upload failed";
+            return bail(LCRC_E_DEVICE);
+        }
+    }
+    c->model->host[2] = merger;
+    {
+        int rc = pack_net(c, merger, c->nets[2]);
+        if (rc) return bail(rc);
+    }
+    if (!mlp_supports(c->nets[2])) { c->err = "merger too large (<= 1024 inputs, <= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
+    // Hamming window over ones (traps.cpp:107-109, dspc.h:162-167) and sDCT's basis (dspc.h:206-221) over n points:
+    // the trajectory's length, LCRC: a half context's
+    const int n = lcrc ? half : trap_len, n_basis = lcrc ? std::max(1, shift) : trap_len;
+    std::vector<float> hamm(trap_len), cosv((size_t)n_basis * n, 0.f);
+    for (int i = 0; i < trap_len; i++)
+        hamm[i] = 1.0f * (0.54f - 0.46f * cosf(2.0f * (float)M_PI * i / (trap_len - 1)));
+    const float pibyn = (float)M_PI / (float)n;
+    for (int k = 0; k < n_basis; k++) {
+        const float v = pibyn * (float)(k + 1);
+        for (int j = 0; j < n; j++) cosv[(size_t)k * n + j] = cosf(v * ((float)j + 0.5f));
+    }
+    c->normc31 = sqrtf(2.0f / (float)n);
+    const float *p = nullptr;
+    if (lcrc) {
+        std::vector<float> w2(win[0]);
+        w2.insert(w2.end(), win[1].begin(), win[1].end());
+        if (dev_upload(c, w2, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+        c->d_win_gen = const_cast<float *>(p);
+    }
+    if (dev_upload(c, hamm, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_hamm31 = const_cast<float *>(p);
+    if (dev_upload(c, cosv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
+    c->d_costab31 = const_cast<float *>(p);
+    c->variant = sys == SYS_1BT_DCT ? "traps_1bt_dct" : sys == SYS_1BT ? "traps_1bt" : sys == SYS_3BT ? "traps_3bt" : "lcrc_general";
+    *out = c;
+    return LCRC_OK;
+}
+
+
 int lcrc_device_warmup(int device_id)
 {
     int ndev = 0;
@@ -807,16 +959,21 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
     if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");
     *out = nullptr;
     if (nbanks <= 0) return fail(nullptr, LCRC_E_ARG, "lcrc_create: nbanks must be positive");
-    if (trap_len != kTrapLen || !add_c0)
-        return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create: posteriors/system=LCRC is implemented for length=31, add_c0=true");
+    if (trap_len < 2 || trap_len > kMaxTrapLen)
+        return fail(nullptr, LCRC_E_ARG, "lcrc_create: posteriors/length must lie in 2.." + std::to_string(kMaxTrapLen));
+    // Any geometry but the shipped models' (31 frames, C0 + 10 coefficients per band and half context) takes the general
+    // kernels: correct, composed of three launches, not the fused kernel this library is about (lcrc.h).
+    if (trap_len != kTrapLen || !add_c0) return create_traps(out, model_dir, SYS_LCRC_GEN, nbanks, trap_len, add_c0, 0, device_id);
 
     // -- files first, so that a bad model directory is reported even without a GPU
     StartupTrace trace;
     HostNet nets[3];
     std::vector<float> win[2];
     {
-        int rc = load_model(model_dir, nbanks, nets, win);
+        int ncoef = 0;
+        int rc = load_model(model_dir, nbanks, nets, win, kHalf, &ncoef);
         if (rc) return rc;
+        if (ncoef != kNCoef) return create_traps(out, model_dir, SYS_LCRC_GEN, nbanks, trap_len, add_c0, 0, device_id);
     }
     trace.mark("model files");
     // fragment order on the host first (no GPU involved: a caller that started lcrc_device_warmup on another thread has
@@ -880,106 +1037,7 @@ int lcrc_create_system(lcrc_ctx **out, const char *model_dir, const char *system
     else if (!strcmp(system, "1BT")) sys = SYS_1BT;
     else if (!strcmp(system, "3BT")) sys = SYS_3BT;
     else return fail(nullptr, LCRC_E_ARG, std::string("Unknown posterior estimator system: ") + system);   // srec.cpp:605-611
-    if (nbanks <= (sys == SYS_3BT ? 2 : 0)) return fail(nullptr, LCRC_E_ARG, "lcrc_create_system: nbanks too small");
-    if (trap_len != kTrapLen) return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_create_system: implemented for length=31");
-    const int trap_bands = sys == SYS_3BT ? nbanks - 2 : nbanks;        // traps.cpp:95-97
-
-    // -- files first (traps.cpp:119-166)
-    const std::string dir(model_dir);
-    std::vector<HostNet> band(sys == SYS_1BT_DCT ? 0 : trap_bands);
-    HostNet merger;
-    auto load = [&](const std::string &name, HostNet &net) -> int {
-        const std::string w = dir + "/weights/" + name + ".weights", n = dir + "/norms/" + name + ".norms";
-        NetStatus s = load_net(w, n, net);
-        if (s != NET_OK)
-            return fail(nullptr, s == NET_NOWEIGHTS || s == NET_NONORMS ? LCRC_E_IO : LCRC_E_MODEL,
-                        "ERROR: Loading neural network: weights " + w + ", norms " + n + " (" + net_status_str(s) + ")");
-        return LCRC_OK;
-    };
-    size_t merger_in = 0;
-    for (int i = 0; i < (int)band.size(); i++) {
-        int rc = load("band" + std::to_string(i), band[i]);
-        if (rc) return rc;
-        // the reference hands every band net exactly trap_len values per frame (traps.cpp:253-259)
-        if (band[i].n_inp != kTrapLen)
-            return fail(nullptr, LCRC_E_MODEL, "band classifier " + std::to_string(i) + " takes " +
-                        std::to_string(band[i].n_inp) + " inputs, the trajectory has 31");
-        merger_in += band[i].n_out;
-    }
-    {
-        int rc = load("merger", merger);
-        if (rc) return rc;
-    }
-    const int shift = merger.n_inp / trap_bands;                         // merger_input_shift, traps.cpp:170
-    if (sys == SYS_1BT_DCT) {
-        if (shift * trap_bands != merger.n_inp || shift < 1 || shift - (add_c0 ? 1 : 0) > kTrapLen)
-            return fail(nullptr, LCRC_E_MODEL, "merger input size " + std::to_string(merger.n_inp) +
-                        " is not nbanks x (coefficients per band)");
-    } else if ((int)merger_in != merger.n_inp) {
-        return fail(nullptr, LCRC_E_MODEL, "merger input size does not equal the band classifiers' outputs");
-    }
-
-    lcrc_ctx *c = nullptr;
-    {
-        int rc = open_context(&c, nbanks, device_id);
-        if (rc) return rc;
-    }
-    auto bail = [&](int code) { g_create_err = c->err; lcrc_destroy(c); return code; };
-    c->system = sys;
-    {
-        const char *e = getenv("PHNREC_TRAPS_UNFUSED");
-        c->traps_unfused = e && *e == '1';
-    }
-    c->trap_bands = trap_bands;
-    c->shift = shift;
-    c->use_hamming = hamming != 0;
-    c->add_c0 = add_c0 != 0;
-    c->band_nets.resize(band.size());
-    for (size_t i = 0; i < band.size(); i++) {
-        int rc = pack_net(c, band[i], c->band_nets[i]);
-        if (rc) return bail(rc);
-        if (!mlp_supports(c->band_nets[i])) { c->err = "band classifier too large (<= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
-    }
-    if (!c->band_nets.empty()) {
-        std::vector<int> col(c->band_nets.size());
-        int acc_col = 0;
-        c->band_max = c->band_nets[0];
-        for (size_t i = 0; i < c->band_nets.size(); i++) {
-            col[i] = acc_col;
-            acc_col += c->band_nets[i].n_out;
-            c->band_max.ksteps = std::max(c->band_max.ksteps, c->band_nets[i].ksteps);
-            c->band_max.nkq = std::max(c->band_max.nkq, c->band_nets[i].nkq);
-            c->band_max.n_ot = std::max(c->band_max.n_ot, c->band_nets[i].n_ot);
-        }
-        if (dev_upload(c, c->band_nets, &c->d_band_nets) != hipSuccess || dev_upload(c, col, &c->d_band_col) != hipSuccess) {
-            c->err = "upload failed";
-            return bail(LCRC_E_DEVICE);
-        }
-    }
-    c->model->host[2] = merger;
-    {
-        int rc = pack_net(c, merger, c->nets[2]);
-        if (rc) return bail(rc);
-    }
-    if (!mlp_supports(c->nets[2])) { c->err = "merger too large (<= 1024 inputs, <= 208 outputs)"; return bail(LCRC_E_UNSUPPORTED); }
-    // Hamming window over ones (traps.cpp:107-109, dspc.h:162-167) and sDCT's basis for n = 31 (dspc.h:206-221)
-    std::vector<float> hamm(kTrapLen), cosv((size_t)kTrapLen * kTrapLen, 0.f);
-    for (int i = 0; i < kTrapLen; i++)
-        hamm[i] = 1.0f * (0.54f - 0.46f * cosf(2.0f * (float)M_PI * i / (kTrapLen - 1)));
-    const float pibyn = (float)M_PI / (float)kTrapLen;
-    for (int k = 0; k < kTrapLen; k++) {
-        const float v = pibyn * (float)(k + 1);
-        for (int j = 0; j < kTrapLen; j++) cosv[(size_t)k * kTrapLen + j] = cosf(v * ((float)j + 0.5f));
-    }
-    c->normc31 = sqrtf(2.0f / (float)kTrapLen);
-    const float *p = nullptr;
-    if (dev_upload(c, hamm, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
-    c->d_hamm31 = const_cast<float *>(p);
-    if (dev_upload(c, cosv, &p) != hipSuccess) { c->err = "upload failed"; return bail(LCRC_E_DEVICE); }
-    c->d_costab31 = const_cast<float *>(p);
-    c->variant = sys == SYS_1BT_DCT ? "traps_1bt_dct" : sys == SYS_1BT ? "traps_1bt" : "traps_3bt";
-    *out = c;
-    return LCRC_OK;
+    return create_traps(out, model_dir, sys, nbanks, trap_len, add_c0, hamming, device_id);
 }
 
 int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src)
@@ -1003,6 +1061,7 @@ int lcrc_clone(lcrc_ctx **out, const lcrc_ctx *src)
     c->band_nets = src->band_nets; c->d_band_nets = src->d_band_nets; c->d_band_col = src->d_band_col;
     c->band_max = src->band_max;
     c->d_hamm31 = src->d_hamm31; c->d_costab31 = src->d_costab31; c->normc31 = src->normc31;
+    c->trap_len = src->trap_len; c->d_win_gen = src->d_win_gen;
     c->traps_unfused = src->traps_unfused; c->bt_unfused = src->bt_unfused;
     c->variant = src->variant; c->lds_bytes = src->lds_bytes;
     *out = c;
@@ -1044,7 +1103,7 @@ void lcrc_destroy(lcrc_ctx *c)
 
 int lcrc_num_outputs(const lcrc_ctx *c) { return c ? c->nets[2].n_out : LCRC_E_ARG; }
 int lcrc_num_banks(const lcrc_ctx *c) { return c ? c->nbanks : LCRC_E_ARG; }
-int lcrc_trap_shift(const lcrc_ctx *c) { return c ? kShift : LCRC_E_ARG; }
+int lcrc_trap_shift(const lcrc_ctx *c) { return c ? (c->trap_len - 1) / 2 : LCRC_E_ARG; }
 int lcrc_device(const lcrc_ctx *c) { return c ? c->device : LCRC_E_ARG; }
 const char *lcrc_kernel_name(const lcrc_ctx *c) { return c ? c->variant : "none"; }
 
@@ -1454,7 +1513,7 @@ int lcrc_delay(const lcrc_ctx *c) { return c ? c->delay : LCRC_E_ARG; }
 // Room for `n` more rows behind the history in the pinned strip, and for n rows of output.
 static int ensure_ring(lcrc_ctx *c, size_t n)
 {
-    const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
+    const size_t nb = c->nbanks, H = (size_t)c->trap_len - 1, O = c->nets[2].n_out;
     if (c->ring_rows + n > c->ring_cap) {
         if (H + n + n / 2 + 256 > c->ring_cap) {            // grow (keeps the history)
             const size_t cap = std::max<size_t>(4096, 2 * (H + n) + 256);
@@ -1499,7 +1558,7 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
     if (n < 0 || (n > 0 && !mel) || (n > 0 && needed && !post)) return fail(c, LCRC_E_ARG, "lcrc_push: bad argument");
     if (n == 0) return LCRC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t nb = c->nbanks, H = kTrapLen - 1, O = c->nets[2].n_out;
+    const size_t nb = c->nbanks, H = (size_t)c->trap_len - 1, O = c->nets[2].n_out;
     if (!c->hist_init) c->ring_rows = 0;
     // Very large pushes (the offline main call of srec.cpp:1048 hands over a whole utterance) go through the device staging
     // buffers -- [history | frames] copied at PCIe rate, the kernel on HBM -- instead of the kernel reading the frames from
@@ -1543,7 +1602,9 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
         } else {                             // the unfused systems compute the whole strip
             rc = run_host(c, c->h_ring + first * nb, nullptr, 1, (int)(H + n), nullptr, nullptr, false);
             if (rc) return rc;
-            memcpy(post, c->h_post + (size_t)kShift * O, (size_t)n * O * sizeof(float));
+            // (row of the first pushed frame's window: the output frame's tap, 15 at the usual length)
+            const size_t back = (size_t)(c->trap_len - 1 - (c->trap_len - 1) / 2);
+            memcpy(post, c->h_post + back * O, (size_t)n * O * sizeof(float));
         }
     }
     if (!c->hist_init) { c->hist_init = true; c->delay = n - 1; }

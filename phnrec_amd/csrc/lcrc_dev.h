@@ -15,6 +15,7 @@ constexpr int kTrapLen = 31;   // posteriors/length
 constexpr int kHalf = 16;      // taps per half context
 constexpr int kShift = 15;     // Traps::GetTrapShift
 constexpr int kNCoef = 11;     // C0 + 10 DCT coefficients
+constexpr int kMaxTrapLen = 255;   // longest posteriors/length the general kernels take
 
 // One MLP in MFMA fragment order (see lcrc_pack.cpp for the element maps).
 struct NetDev {
@@ -127,12 +128,17 @@ struct TrapsFeatParams {
     const float *mel;    // [n_rows][nbanks]
     const int *off;      // [n_utts + 1] or NULL (one utterance)
     int n_utts, n_rows, nbanks, trap_bands;
-    int mode;            // 0 = trajectories [trap_bands][n_rows][31], 1 = C0/DCT rows [n_rows][trap_bands*shift]
+    int mode;            // 0 = trajectories [trap_bands][n_rows][L], 1 = C0/DCT rows [n_rows][trap_bands*shift],
+                         // 2 = LCRC at any geometry: [2 half contexts][n_rows][nbanks*shift] (general kernel only)
     int use_hamming, add_c0, shift;
-    const float *hamming;   // [31]  sWindow_Hamming over ones (dspc.h:162-167)
-    const float *costab;    // [shift][31]  cosf(v_k * (j + 0.5f)) as sDCT evaluates it (dspc.h:206-221)
-    float normc;            // sqrtf(2/31)
+    const float *hamming;   // [L]  sWindow_Hamming over ones (dspc.h:162-167)
+    const float *costab;    // [shift][n]  cosf(v_k * (j + 0.5f)) as sDCT evaluates it (dspc.h:206-221); n = L, mode 2: half
+    float normc;            // sqrtf(2/n)
     float *out;
+    // posteriors/length L (Traps::SetTrapLen): 31 runs the kernels written for it; any other length (and mode 2) the
+    // general features kernel.  back = L - 1 - (L - 1) / 2: the output frame's tap (taps 0 .. L-1 = frames r - back .. ).
+    int trap_len, back, half;   // half = (L - 1) / 2 + 1 (traps.cpp:288)
+    const float *win;           // mode 2: [2][half] the half contexts' windows (windows/band{0,1}.window)
 };
 
 struct MlpParams {
@@ -147,7 +153,7 @@ struct MlpParams {
     const int *out_col;
     long in_net_stride;
     int n_nets, lds_nkq, lds_n_ot;
-    int neg_log;         // 1: store -(x > 0 ? ln x : 0)   (sLn + sMultiplication(-1), traps.cpp:424-425)
+    int neg_log;         // 1: store -(x > 0 ? ln x : 0)   (sLn + sMultiplication(-1), traps.cpp:424-425); 2: +ln (LCRC, :458)
     int out_func[2];     // else: softening stages / byte order of lcrc_output_configure
     float out_c[2][4];
     float out_l[2][2];

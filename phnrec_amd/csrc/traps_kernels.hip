@@ -68,6 +68,85 @@ __global__ __launch_bounds__(256) void traps_features_kernel(const TrapsFeatPara
     }
 }
 
+// Any posteriors/length, and LCRC at any geometry (a length other than 31, add_c0 = false, another number of
+// coefficients per band): the same features with run-time sizes, a thread per (frame, band), every value re-read from the
+// L1-resident mel rows instead of a register array.  No shipped model takes this path (all are LCRC, 31, add_c0).
+//   modes 0 / 1: as traps_features_kernel
+//   mode 2 (traps.cpp:285-343): LC = taps [0, half), RC = taps [half - 1, 2 half - 1) of each band, times the half
+//     context's window, then [C0,] DCT over `half` points.  The reference walks be_mat ([band][L], flat) with a stride
+//     of 2 half - 1 per band (traps.cpp:296-306): the same thing for odd L, and for even L a walk that drifts one slot
+//     per band across the band rows -- restated as it is: flat index q = b (2 half - 1) + j -> band q / L, tap q % L.
+__global__ __launch_bounds__(256) void traps_features_general_kernel(const TrapsFeatParams p)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(idx / p.trap_bands), b = (int)(idx % p.trap_bands);
+    if (r >= p.n_rows) return;
+    int lo = 0, hi = p.n_rows - 1;
+    if (p.off) {                                 // largest u with off[u] <= r
+        int a = 0, e = p.n_utts;
+        while (e - a > 1) {
+            const int mid = (a + e) >> 1;
+            if (p.off[mid] <= r) a = mid; else e = mid;
+        }
+        lo = p.off[a];
+        hi = p.off[a + 1] - 1;
+    }
+    const int L = p.trap_len, nb = p.nbanks;
+    auto at = [&](int band, int tap) { return p.mel[(size_t)max(lo, min(hi, r - p.back + tap)) * nb + band]; };
+    if (p.mode == 0) {
+        float *o = p.out + ((size_t)b * p.n_rows + r) * L;
+        for (int tap = 0; tap < L; tap++) {
+            float v = at(b, tap);
+            if (p.use_hamming) v = v * p.hamming[tap];            // sMultVect, traps.cpp:236-243
+            o[tap] = v;
+        }
+        return;
+    }
+    const int c0 = p.add_c0 ? 1 : 0, n_dct = p.shift - c0;
+    if (p.mode == 1) {
+        float *o = p.out + (size_t)r * ((size_t)p.trap_bands * p.shift) + (size_t)b * p.shift;
+        auto x = [&](int j) { const float v = at(b, j); return p.use_hamming ? v * p.hamming[j] : v; };
+        if (c0) {                                // CalcC0 dspc.h:223-233
+            float sum = 0.0f;
+            for (int j = 0; j < L; j++) sum += x(j);
+            sum *= p.normc;
+            *o++ = sum;
+        }
+        for (int k = 0; k < n_dct; k++) {        // sDCT dspc.h:206-221: sequential f32 sum, then the scale
+            float acc = 0.0f;
+            const float *ct = p.costab + (size_t)k * L;
+            for (int j = 0; j < L; j++) acc += x(j) * ct[j];
+            acc *= p.normc;
+            o[k] = acc;
+        }
+        return;
+    }
+    const int H = p.half, K = p.trap_bands * p.shift;
+    for (int n = 0; n < 2; n++) {
+        float *o = p.out + ((size_t)n * p.n_rows + r) * K + (size_t)b * p.shift;
+        const float *w = p.win + n * H;
+        auto x = [&](int j) {
+            const int q = b * (2 * H - 1) + n * (H - 1) + j;
+            float v = at(q / L, q % L);
+            v = v * w[j];                                        // sMultVect, traps.cpp:312-313
+            return v;
+        };
+        if (c0) {
+            float sum = 0.0f;
+            for (int j = 0; j < H; j++) sum += x(j);
+            sum *= p.normc;
+            *o++ = sum;
+        }
+        for (int k = 0; k < n_dct; k++) {
+            float acc = 0.0f;
+            const float *ct = p.costab + (size_t)k * H;
+            for (int j = 0; j < H; j++) acc += x(j) * ct[j];
+            acc *= p.normc;
+            o[k] = acc;
+        }
+    }
+}
+
 // LDS: [mean | dev] (2 * 16 * nkq floats), B image [ft][nkq][64] float4, four slabs [n_ot][ft][64] float4, and
 // for the fused 1BT_DCT input: mel tile [(16 ft + 30)][nbanks], row bounds [2][16 ft], DCT basis [shift][31],
 // Hamming window [32]
@@ -300,7 +379,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_kernel(const MlpParams p)
     const bool transform = (p.out_func[0] | p.out_func[1] | p.out_be) != 0;
     auto epi = [&](int, int i, int o, float q, bool valid) {
         if (p.neg_log) {
-            q = (q > 0.0f ? logf(q) : 0.0f) * -1.0f;
+            q = q > 0.0f ? logf(q) : 0.0f;                       // sLn dspc.h:155-160
+            if (p.neg_log == 1) q = q * -1.0f;                   // 1BT / 3BT: sMultiplication(.., -1), traps.cpp:425
         } else if (transform) {
             q = soften(p.out_func[0], p.out_c[0], p.out_l[0], q);
             q = soften(p.out_func[1], p.out_c[1], p.out_l[1], q);
@@ -544,7 +624,10 @@ hipError_t traps_features_launch(const TrapsFeatParams &p, hipStream_t stream)
 {
     if (p.n_rows <= 0) return hipSuccess;
     const long n = (long)p.n_rows * p.trap_bands;
-    traps_features_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(p);
+    if (p.trap_len == kTrapLen && p.mode < 2)
+        traps_features_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(p);
+    else
+        traps_features_general_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(p);
     return hipGetLastError();
 }
 

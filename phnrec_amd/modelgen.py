@@ -41,10 +41,10 @@ def pad4(n):
     return (n + 3) & ~3
 
 
-def half_windows():
-    """The two 16-tap half-Hamming windows every shipped system uses."""
-    j = np.arange(HALF, dtype=np.float64)
-    w0 = 0.54 - 0.46 * np.cos(2.0 * np.pi * j / 30.0)
+def half_windows(half=HALF):
+    """The two half-Hamming windows (16 taps in every shipped system; `half` taps for other posteriors/length values)."""
+    j = np.arange(half, dtype=np.float64)
+    w0 = 0.54 - 0.46 * np.cos(2.0 * np.pi * j / (2.0 * (half - 1)))
     return w0.astype(np.float32), w0[::-1].astype(np.float32).copy()
 
 
@@ -110,7 +110,7 @@ def write_ascii(weights_path, norms_path, net):
 
 def config_text(nbanks, sample_freq=8000, vector_size=200, vector_step=80, lower=64, higher=4000,
                 sent_mean_norm=True, wpenalty=-4.6875, fmt="lin16", suffix="mel", bunch_size=5,
-                system="LCRC", add_c0=True, hamming=False, **_unused):
+                system="LCRC", add_c0=True, hamming=False, trap_len=TRAP_LEN, **_unused):
     b = "true" if sent_mean_norm else "false"
     c0, hm = ("true" if add_c0 else "false"), ("true" if hamming else "false")
     return f"""[source]
@@ -119,7 +119,7 @@ sample_freq={sample_freq}
 
 [posteriors]
 system={system}
-length=31
+length={trap_len}
 add_c0={c0}
 hamming={hm}
 suffix=lop
@@ -184,10 +184,11 @@ thresholds_file=none
 
 
 def write_model_dir(path, nbanks, hidden, n_out, seed=0, ascii_too=False, nbin=True,
-                    hidden_merger=None, **cfg):
-    """Write a loadable LCRC model directory; returns the dict of nets."""
+                    hidden_merger=None, coefs=N_COEF, **cfg):
+    """Write a loadable LCRC model directory; returns the dict of nets.  The shipped geometry unless told otherwise:
+    `coefs` inputs per band of the band nets (C0 included when add_c0), trap_len / add_c0 through the config."""
     rng = np.random.default_rng(seed)
-    k = nbanks * N_COEF
+    k = nbanks * coefs
     nets = {
         "band0": random_net(rng, k, hidden, n_out, "band"),
         "band1": random_net(rng, k, hidden, n_out, "band"),
@@ -201,7 +202,7 @@ def write_model_dir(path, nbanks, hidden, n_out, seed=0, ascii_too=False, nbin=T
         if ascii_too or not nbin:
             write_ascii(os.path.join(path, "weights", name + ".weights"),
                         os.path.join(path, "norms", name + ".norms"), net)
-    for i, w in enumerate(half_windows()):
+    for i, w in enumerate(half_windows((cfg.get("trap_len", TRAP_LEN) - 1) // 2 + 1)):
         with open(os.path.join(path, "windows", "band%d.window" % i), "w") as f:
             f.write(" ".join("%.7e" % v for v in w) + "\n")
     n_phn = n_out // 3 - 1
@@ -213,7 +214,7 @@ def write_model_dir(path, nbanks, hidden, n_out, seed=0, ascii_too=False, nbin=T
 
 
 def write_traps_dir(path, system, nbanks, hidden, n_out, seed=0, band_out=12, band_hidden=40, coefs=6,
-                    add_c0=True, hamming=False, **cfg):
+                    add_c0=True, hamming=False, trap_len=TRAP_LEN, **cfg):
     """Write a loadable model directory for the non-LCRC `posteriors/system` variants (traps.cpp:88-171):
     "1BT_DCT": merger over nbanks * coefs DCT features (coefs counts C0 when add_c0);
     "1BT" / "3BT": nbanks (nbanks - 2) band nets 31 -> band_hidden -> band_out and a merger over their outputs."""
@@ -224,7 +225,7 @@ def write_traps_dir(path, system, nbanks, hidden, n_out, seed=0, band_out=12, ba
     else:
         tb = nbanks - 2 if system == "3BT" else nbanks
         for i in range(tb):
-            nets["band%d" % i] = random_net(rng, TRAP_LEN, band_hidden + i, band_out, "band")
+            nets["band%d" % i] = random_net(rng, trap_len, band_hidden + i, band_out, "band")
         nets["merger"] = random_net(rng, tb * band_out, hidden, n_out, "neglog")
     for sub in ("weights", "norms", "windows", "dicts", "tmp", "net"):
         os.makedirs(os.path.join(path, sub), exist_ok=True)
@@ -234,7 +235,7 @@ def write_traps_dir(path, system, nbanks, hidden, n_out, seed=0, band_out=12, ba
     with open(os.path.join(path, "dicts", "phonemes"), "w") as f:
         f.write("".join("p%02d\n" % i for i in range(n_phn)))
     with open(os.path.join(path, "config"), "w") as f:
-        f.write(config_text(nbanks, system=system, add_c0=add_c0, hamming=hamming, **cfg))
+        f.write(config_text(nbanks, system=system, add_c0=add_c0, hamming=hamming, trap_len=trap_len, **cfg))
     return nets
 
 

@@ -188,6 +188,34 @@ def test_default_system_1bt_dct_end_to_end(tmp_path):
     _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))
 
 
+def test_lcrc_at_another_length_end_to_end(tmp_path):
+    """posteriors/length=21, add_c0=false (a geometry the reference accepts but no shipped model uses) through the CLI on
+    the bundled utterance, against the posterior dump the reference CLI wrote for the same synthetic model; the list
+    form and the GPU front-end feed the general kernels as well"""
+    from phnrec_amd import modelgen
+    from tools.make_golden_systems import GEOM_CLI_CASE
+    c = dict(GEOM_CLI_CASE)
+    d = str(tmp_path / "model")
+    modelgen.write_model_dir(d, c.pop("nbanks"), c.pop("hidden"), c.pop("n_out"), seed=c.pop("seed"), **c)
+    raw = os.path.join(GOLD, "test.raw")
+    want = read_htk(os.path.join(GOLD, "systems", "lcrc_len21.lop"))
+    for k, extra in enumerate(((), ("-F",))):
+        lop = tmp_path / ("t%d.lop" % k)
+        run("-c", d, "-i", raw, "-t", "post", "-o", lop, *extra)
+        got = read_htk(str(lop))
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+    data = tmp_path / "data"
+    data.mkdir()
+    blob = open(raw, "rb").read()
+    for n, b in (("a", blob), ("b", blob[:9000])):
+        (data / (n + ".raw")).write_bytes(b)
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join("%s\n" % (data / (n + ".raw")) for n in ("a", "b")))
+    run("-c", d, "-l", lst, "-t", "post")
+    assert np.abs(read_htk(str(data / "a.lop")) - want).max() < 1e-4
+    assert read_htk(str(data / "b.lop")).shape == ((9000 // 2 - 200) // 80 + 1, want.shape[1])
+
+
 @pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_decoder_on_the_gpu_flag(system, tmp_path):
     """-D: PhnDec runs on the device behind the posterior kernel; same label files as the reference's, for

@@ -283,9 +283,9 @@ def test_api_errors(capi, tmp_path):
     with pytest.raises(capi.LcrcError) as e:
         capi.Lcrc(d, 23)                     # wrong nbanks for these nets
     assert e.value.code == capi.LCRC_E_MODEL
-    with pytest.raises(capi.LcrcError) as e:
-        capi.Lcrc(d, 15, trap_len=21)
-    assert e.value.code == capi.LCRC_E_UNSUPPORTED
+    other = capi.Lcrc(d, 15, trap_len=21)    # another length: the general kernels (test_general_geometry)
+    assert other.kernel_name == "lcrc_general"
+    other.close()
     ctx = capi.Lcrc(d, 15)
     assert ctx.posteriors(np.zeros((0, 15), np.float32)).shape == (0, 12)
     with pytest.raises(capi.LcrcError):
@@ -659,6 +659,68 @@ def test_both_workgroup_tile_sizes(capi, oracle_mod, tmp_path):
         with pytest.raises(capi.LcrcError):
             ctx.set_tile_frames(24)
         ctx.close()
+
+
+def test_general_geometry(capi, oracle_mod, tmp_path):
+    """Geometries the reference's Traps accepts but no shipped model uses (missing #4): posteriors/length other
+    than 31 -- odd and even --, LCRC without C0 or with another number of coefficients per band, and the other systems
+    at other lengths.  They run on the general features kernel + the MLP kernels (three launches), checked against the
+    reference's own outputs (tests/golden/geometry.npz) and the run-time-geometry oracle, on ragged batches with empty
+    utterances, through the staged entry, a clone, the streaming form and the device-side writer path."""
+    from tools.make_golden_systems import GEOM_CASES, write_geometry_model
+    gold = np.load(os.path.join(GOLD, "geometry.npz"))
+    for name, system, nb, hid, nout, seed, kw, lens, trap_len in GEOM_CASES:
+        d = str(tmp_path / name)
+        write_geometry_model(d, system, nb, hid, nout, seed, kw, trap_len)
+        add_c0, hamming = kw.get("add_c0", True), kw.get("hamming", False)
+        ctx = capi.Lcrc(d, nb, system=system, add_c0=add_c0, hamming=hamming, trap_len=trap_len)
+        assert ctx.kernel_name == ("lcrc_general" if system == "LCRC" else "traps_" + system.lower()) and ctx.n_out == nout
+        assert ctx.L.lcrc_trap_shift(ctx.h) == (trap_len - 1) // 2
+        mel, off = gold[name + "/mel"], gold[name + "/off"]
+        got = ctx.posteriors_batch(mel, off)
+        assert np.abs(got - gold[name + "/post"]).max() < TOL, (name, np.abs(got - gold[name + "/post"]).max())
+        o = oracle_mod.TrapsOracle(d, system, nb, add_c0, hamming, trap_len=trap_len)
+        lens2 = [0, 5, 300, 0, 64, 1]
+        off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+        mel2 = modelgen.synth_mel(int(off2[-1]), nb, seed=seed)
+        got2 = ctx.posteriors_batch(mel2, off2)
+        assert np.abs(got2 - o.posteriors_batch(mel2, off2)).max() < TOL, name
+        assert np.abs(got2.sum(axis=1) - 1).max() < 1e-5
+        assert np.array_equal(ctx.posteriors_batch(mel2, off2), got2)                  # deterministic
+        assert np.array_equal(ctx.posteriors_staged(mel2, off2), got2)
+        twin = ctx.clone()
+        assert np.array_equal(twin.posteriors_batch(mel2, off2), got2)
+        twin.close()
+        # streaming form == whole-utterance form: the estimate of frame r appears when frame r + (L - 1) / 2 is pushed
+        shift = (trap_len - 1) // 2
+        u = mel2[int(off2[2]):int(off2[3])][:60]
+        whole = ctx.posteriors(u)
+        ctx.reset()
+        pushed = np.concatenate([ctx.push(u[i:i + 7]) for i in range(0, len(u), 7)])
+        tail = ctx.push(np.repeat(u[-1:], shift, axis=0))
+        assert np.abs(np.concatenate([pushed, tail])[shift:] - whole).max() < 1e-6, name
+        ctx.configure_output(("log",), big_endian=True)
+        with np.errstate(divide="ignore"):
+            want = np.log(got2)
+        be = ctx.posteriors_batch(mel2, off2).view(">f4").astype(np.float32)
+        ok = np.isfinite(want)
+        assert np.abs(be[ok] - want[ok]).max() <= 2e-6 * max(1.0, np.abs(want[ok]).max())
+        ctx.configure_output(())
+        # what exists for the fused LCRC kernel only
+        with pytest.raises(capi.LcrcError) as e:
+            ctx.posteriors_rows(mel2[:40], 5, 10)
+        assert e.value.code == capi.LCRC_E_UNSUPPORTED
+        ctx.close()
+    # lengths outside 2 .. 255, and band nets whose inputs nbanks does not divide
+    d = str(tmp_path / "bad")
+    modelgen.write_model_dir(d, 15, 32, 21, seed=1)
+    for L in (1, 0, 256):
+        with pytest.raises(capi.LcrcError) as e:
+            capi.Lcrc(d, 15, trap_len=L)
+        assert e.value.code == capi.LCRC_E_ARG
+    with pytest.raises(capi.LcrcError) as e:
+        capi.Lcrc(d, 14)
+    assert e.value.code == capi.LCRC_E_MODEL
 
 
 def test_other_posterior_systems(capi, oracle_mod, tmp_path):

@@ -244,6 +244,34 @@ def test_other_posterior_systems_vs_reference_goldens(oracle_mod, tmp_path):
             assert np.array_equal(t.process_offline(mel[a:b]), got[a:b])
 
 
+def test_general_geometry_vs_reference_goldens(oracle_mod, tmp_path):
+    """The geometries the reference's Traps accepts but no shipped model uses -- posteriors/length other than 31 (odd and
+    even: for even lengths the reference's LCRC walk over be_mat drifts across the band rows, traps.cpp:296-306, and so
+    does the restatement), LCRC without C0 or with another number of coefficients per band -- traps_oracle.c against
+    what the reference's own class produced (tests/golden/geometry.npz): bit-exact, and in-process when oracle/_ref is
+    present.  At the shipped geometry the run-time-geometry restatement equals lcrc_oracle.c bit for bit."""
+    from tools.make_golden_systems import GEOM_CASES, write_geometry_model
+    gold = np.load(os.path.join(GOLD, "geometry.npz"))
+    for name, system, nb, hid, nout, seed, kw, lens, trap_len in GEOM_CASES:
+        d = str(tmp_path / name)
+        write_geometry_model(d, system, nb, hid, nout, seed, kw, trap_len)
+        o = oracle_mod.TrapsOracle(d, system, nb, kw.get("add_c0", True), kw.get("hamming", False), trap_len=trap_len)
+        assert o.n_out == nout
+        mel, off = gold[name + "/mel"], gold[name + "/off"]
+        assert np.array_equal(mel, np.concatenate([modelgen.synth_mel(n, nb, seed=1000 * seed + i)
+                                                   for i, n in enumerate(lens)]))
+        got = o.posteriors_batch(mel, off)
+        assert np.array_equal(got, gold[name + "/post"]), name
+        if oracle_mod.ref_lib_path(False):
+            t = oracle_mod.RefTraps(d, nb, bunch=3, system=system, add_c0=kw.get("add_c0", True),
+                                    hamming=kw.get("hamming", False), trap_len=trap_len)
+            a, b = int(off[0]), int(off[1])
+            assert np.array_equal(t.process_offline(mel[a:b]), got[a:b])
+    d = model_dir("PHN_CZ_SPDAT_LCRC_N1500")
+    mel = modelgen.synth_mel(70, 15, seed=9)
+    assert np.array_equal(oracle_mod.TrapsOracle(d, "LCRC", 15).posteriors(mel), oracle_mod.Oracle(d, 15).posteriors(mel))
+
+
 @pytest.mark.parametrize("system", list(modelgen.SYSTEMS))
 def test_phndec_oracle_reproduces_reference_label_files(oracle_mod, system):
     """phndec_oracle.c on the logarithm of the reference's posterior dump == the reference's .rec
