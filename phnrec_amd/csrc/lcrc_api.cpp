@@ -89,7 +89,7 @@ struct lcrc_ctx {
     int *d_off = nullptr;
     float *h_mel = nullptr, *h_post = nullptr;
     int *h_off = nullptr;
-    size_t cap_rows = 0, cap_utts = 0;
+    size_t cap_rows = 0, cap_utts = 0, cap_host_post = 0;
     float *d_dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_dbg = 0;
     // GPU front-end ("next" row f1): configuration, device tables, staging for raw bytes
@@ -406,7 +406,7 @@ void free_frame_staging(lcrc_ctx *c)
     if (c->h_mel) (void)hipHostFree(c->h_mel);
     if (c->h_post) (void)hipHostFree(c->h_post);
     c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
-    c->cap_rows = 0;
+    c->cap_rows = c->cap_host_post = 0;
 }
 
 void free_offset_staging(lcrc_ctx *c)
@@ -425,10 +425,12 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
         const size_t cap = rows + rows / 4 + 64;
         free_frame_staging(c);
         const size_t O = c->nets[2].n_out;
+        // (the pinned posterior buffer -- the largest: 744 B per HU frame, ~8 ms of page pinning per 32 768 frames --
+        //  follows in ensure_host_post, when a call actually copies posteriors back: with the decoder on the device
+        //  and no read-back nothing ever does)
         if (dev_alloc((void **)&c->d_mel, cap * c->nbanks * sizeof(float)) != hipSuccess ||
             dev_alloc((void **)&c->d_post, cap * O * sizeof(float)) != hipSuccess ||
-            pinned_alloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float)) != hipSuccess ||
-            pinned_alloc((void **)&c->h_post, cap * O * sizeof(float)) != hipSuccess) {
+            pinned_alloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float)) != hipSuccess) {
             free_frame_staging(c);
             (void)hipGetLastError();
             return fail(c, LCRC_E_NOMEM, "cannot allocate staging buffers for " + std::to_string(cap) + " frames");
@@ -446,6 +448,22 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
         }
         c->cap_utts = cap;
     }
+    return LCRC_OK;
+}
+
+// The pinned posterior buffer for as many rows as the device buffers hold (after ensure_staging).
+int ensure_host_post(lcrc_ctx *c)
+{
+    if (c->h_post && c->cap_host_post >= c->cap_rows) return LCRC_OK;
+    if (c->h_post) (void)hipHostFree(c->h_post);
+    c->h_post = nullptr; c->cap_host_post = 0;
+    const size_t O = c->nets[2].n_out;
+    if (pinned_alloc((void **)&c->h_post, c->cap_rows * O * sizeof(float)) != hipSuccess) {
+        c->h_post = nullptr;
+        (void)hipGetLastError();
+        return fail(c, LCRC_E_NOMEM, "cannot allocate the pinned posterior buffer for " + std::to_string(c->cap_rows) + " frames");
+    }
+    c->cap_host_post = c->cap_rows;
     return LCRC_OK;
 }
 
@@ -687,7 +705,11 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
         if (rc) return rc;
     }
     const bool copy_post = c->readback || !decoding;
-    if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (copy_post) {
+        rc = ensure_host_post(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (copy_post && post) memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
     if (any)
@@ -1162,6 +1184,8 @@ int lcrc_stage_buffers(lcrc_ctx *c, int rows, float **mel, float **post)
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_staging(c, rows > 0 ? rows : 1, 1);
     if (rc) return rc;
+    rc = ensure_host_post(c);
+    if (rc) return rc;
     *mel = c->h_mel;
     *post = c->h_post;
     return LCRC_OK;
@@ -1191,8 +1215,11 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
     if (rc) return rc;
     rc = decode_after(c, c->d_off, c->h_off, n_utts, n, c->d_post, c->stream);
     if (rc) return rc;
-    if (c->readback || c->dec_P <= 0)
+    if (c->readback || c->dec_P <= 0) {
+        rc = ensure_host_post(c);                // (lcrc_stage_buffers allocated it: a no-op)
+        if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return LCRC_OK;
 }
@@ -1398,7 +1425,11 @@ static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
     rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
     if (rc) return rc;
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
-    if (copy_post) HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
+    if (copy_post) {
+        rc = ensure_host_post(c);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (copy_post && post) memcpy(post, c->h_post, nbytes);   // post == NULL: read them in place (lcrc_staged_posteriors)
     return LCRC_OK;
@@ -1573,6 +1604,8 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
         HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (H + (size_t)n) * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
         rc = launch(c, c->d_mel, nullptr, 1, (int)(H + n), c->d_post, c->stream, nullptr, kShift, n, false);
         if (rc) return rc;
+        rc = ensure_host_post(c);
+        if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         // the new history while the copies and the kernel run: the last 30 pushed frames
         memcpy(c->h_ring, mel + ((size_t)n - H) * nb, H * nb * sizeof(float));
@@ -1630,6 +1663,8 @@ int lcrc_posteriors_rows(lcrc_ctx *c, const float *mel, int n_rows, int row_firs
     memcpy(c->h_mel, mel, (size_t)n_rows * nb * sizeof(float));
     HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n_rows * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
     rc = launch(c, c->d_mel, nullptr, 1, n_rows, c->d_post, c->stream, nullptr, row_first, row_count);
+    if (rc) return rc;
+    rc = ensure_host_post(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)row_count * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
