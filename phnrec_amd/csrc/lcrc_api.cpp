@@ -393,8 +393,11 @@ hipError_t dev_alloc(void **p, size_t bytes)
     *p = nullptr;
     return inject_alloc_failure() ? hipErrorOutOfMemory : hipMalloc(p, bytes);
 }
-hipError_t pinned_alloc(void **p, size_t bytes)
+// device_reads: a buffer that kernels read in place (mapped into the device, coherent: never cached on the device side)
+hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false)
 {
+    if (device_reads)
+        return inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
     *p = nullptr;
     return inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, hipHostMallocDefault);
 }
@@ -430,7 +433,7 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
         //  and no read-back nothing ever does)
         if (dev_alloc((void **)&c->d_mel, cap * c->nbanks * sizeof(float)) != hipSuccess ||
             dev_alloc((void **)&c->d_post, cap * O * sizeof(float)) != hipSuccess ||
-            pinned_alloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float)) != hipSuccess) {
+            pinned_alloc((void **)&c->h_mel, cap * c->nbanks * sizeof(float), true) != hipSuccess) {
             free_frame_staging(c);
             (void)hipGetLastError();
             return fail(c, LCRC_E_NOMEM, "cannot allocate staging buffers for " + std::to_string(cap) + " frames");
@@ -1210,8 +1213,17 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
         return fail(c, LCRC_E_NOMEM, "lcrc_stage_run: staging buffers moved");
     memcpy(c->h_off, off, (size_t)(n_utts + 1) * sizeof(int));
     HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    rc = launch(c, c->d_mel, c->d_off, n_utts, n, c->d_post, c->stream, nullptr);
+    // The kernel reads the features where they lie, in the pinned buffer (60-92 B per frame over PCIe, each row by two
+    // workgroups): no copy command.  A copy would be cheap by itself, but copies of all contexts share the device's copy
+    // queue, in order: this context's 2 MB would wait behind another context's 24 MB of posteriors on their way back,
+    // which in turn wait for that context's kernel -- with three contexts in flight the launches ran strictly one after
+    // the other, kernel / copy-back / kernel / ... (profiles/r03_ab_runs.txt 15: 20 -> 24-27 M frames/s for the CLI).
+    // (the fused LCRC kernels stage a workgroup's rows once; the composed kernels of the other systems re-read theirs and
+    //  get the copy)
+    float *mel_in = c->d_mel;
+    if (c->system == SYS_LCRC) HIP_TRY(c, hipHostGetDevicePointer((void **)&mel_in, c->h_mel, 0));
+    else HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, (size_t)n * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = launch(c, mel_in, c->d_off, n_utts, n, c->d_post, c->stream, nullptr);
     if (rc) return rc;
     rc = decode_after(c, c->d_off, c->h_off, n_utts, n, c->d_post, c->stream);
     if (rc) return rc;
