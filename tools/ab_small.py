@@ -73,6 +73,25 @@ def main():
                 t[k].append((time.perf_counter() - t0) / 600)
         a, b = np.median(t[0][1:]), np.median(t[1][1:])
         print("  push bunch 5: A %.1f us  B %.1f us per call  B/A %.3f" % (a * 1e6, b * 1e6, b / a))
+        # the host-pointer entry (lcrc_posteriors: one utterance in host memory, posteriors back in host memory)
+        for L in libs:
+            L.lcrc_posteriors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        for n in (50, 300, 2000, 8192):
+            hm = np.ascontiguousarray(modelgen.synth_mel(n, nb, seed=3))
+            outs = [np.empty((n, n_out), np.float32) for _ in libs]
+            t = [[], []]
+            reps = 300 if n <= 300 else 60
+            for rnd in range(7):
+                for k in ((0, 1) if rnd % 2 == 0 else (1, 0)):
+                    for _ in range(20):
+                        libs[k].lcrc_posteriors(hs[k], hm.ctypes.data, n, outs[k].ctypes.data)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        libs[k].lcrc_posteriors(hs[k], hm.ctypes.data, n, outs[k].ctypes.data)
+                    t[k].append((time.perf_counter() - t0) / reps)
+            a, b = np.median(t[0][1:]), np.median(t[1][1:])
+            print("  lcrc_posteriors %5d frames (host buffers): A %.1f us  B %.1f us per call  B/A %.3f  identical: %s"
+                  % (n, a * 1e6, b * 1e6, b / a, bool(np.array_equal(outs[0], outs[1]))))
 
 
 if __name__ == "__main__":
