@@ -396,10 +396,9 @@ hipError_t dev_alloc(void **p, size_t bytes)
 // device_reads: a buffer that kernels read in place (mapped into the device, coherent: never cached on the device side)
 hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false)
 {
-    if (device_reads)
-        return inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent);
     *p = nullptr;
-    return inject_alloc_failure() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (inject_alloc_failure()) return hipErrorOutOfMemory;
+    return hipHostMalloc(p, bytes, device_reads ? hipHostMallocMapped | hipHostMallocCoherent : hipHostMallocDefault);
 }
 
 void free_frame_staging(lcrc_ctx *c)
