@@ -620,8 +620,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
         // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the
-        // kernel itself at 186 outputs per frame) and the third's utterances are decoded (profiles/r03_cli_contexts.txt)
-        if (!EnsureGpus(single_file ? 1 : 3)) return false;
+        // kernel itself at 186 outputs per frame) and the third's utterances are decoded (profiles/r03_cli_contexts.txt).
+        // From four GPUs on: two -- on one GPU the third is worth 0-2 %, while every context costs ~10 ms of start-up that
+        // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
+        // list that eight GPUs finish in a tenth of a second are a loss.
+        if (!EnsureGpus(single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3)) return false;
     }
     const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
     std::vector<std::string> phn_names;
