@@ -270,6 +270,12 @@ int lcrc_delay(const lcrc_ctx *ctx);
 int lcrc_last_kernel_ms(lcrc_ctx *ctx, float *ms);
 /* Enable/disable the event pair (default on; costs two hipEventRecord per launch) */
 int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
+/* How the host-pointer entry points wait for the device at the end of a call.  0 (default): hipStreamSynchronize -- the
+ * calling thread spins on the completion signal: lowest latency, one busy core per waiting thread.  n > 0: an event
+ * behind the work is queried every n microseconds with the thread asleep in between: next to no CPU time, the completion
+ * noticed up to n (plus the timer's slack) late.  For callers that keep more contexts in flight -- a thread each -- than
+ * they have cores to burn: the CLI switches to it when its contexts outnumber a quarter of the usable cores. */
+int lcrc_set_wait_mode(lcrc_ctx *ctx, int poll_interval_us);
 /* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
  * (tuning and test hook; results are bit-identical either way) */
 int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
@@ -144,6 +144,7 @@ def load():
                                   C.POINTER(C.c_uint)]
     L.lcrc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.lcrc_set_timing.argtypes = [vp, C.c_int]
+    L.lcrc_set_wait_mode.argtypes = [vp, C.c_int]
     L.lcrc_set_tile_frames.argtypes = [vp, C.c_int]
     L.lcrc_set_hidden_split.argtypes = [vp, C.c_int]
     L.lcrc_set_mean_order.argtypes = [vp, C.c_int]
@@ -376,6 +377,9 @@ class Lcrc:
     def set_arithmetic(self, arithmetic):
         """ARITH_F32 (default) or ARITH_SPLIT_F16 (f32 products as three exact f16 MFMA products; shipped LCRC shapes)"""
         self._check(self.L.lcrc_set_arithmetic(self.h, arithmetic))
+
+    def set_wait_mode(self, poll_interval_us):
+        self._check(self.L.lcrc_set_wait_mode(self.h, int(poll_interval_us)))
 
     def set_timing(self, on):
         self._check(self.L.lcrc_set_timing(self.h, int(on)))

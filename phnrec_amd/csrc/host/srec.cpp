@@ -639,6 +639,14 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         for (auto &g : gpus_)
             if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
                 return Fail(g->LastError() + "\n");
+        // Every context has a thread waiting for it.  Spinning (the default) is the fastest way to notice a finished
+        // launch and costs a core each: fine for one GPU's three on 16 cores (sleeping waits lose 15 % with -F there,
+        // profiles/r03_ab_runs.txt 14), not when the waiting threads of many GPUs would take more than half of the cores
+        // the front-end and the decoder of the same run need (16 contexts on 16 cores: +10-20 % with sleeping waits,
+        // item 18).  PHNREC_WAIT_POLL_US overrides (0 = spin).
+        int poll_us = (int)gpus_.size() * 2 > UsableCpus() ? 50 : 0;
+        if (const char *e = getenv("PHNREC_WAIT_POLL_US")) poll_us = std::max(0, atoi(e));
+        for (auto &g : gpus_) g->SetWaitMode(poll_us);
     }
     const auto t1 = clock::now();
     stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();

@@ -63,6 +63,8 @@ public:
     // lcrc_set_hidden_split: 0 = small launches spread a tile's hidden units over several workgroups (default),
     // 1 = fused kernel only (a frame's output never depends on what else shares its launch)
     void SetHiddenSplit(int v) { hidden_split_ = v; if (ctx_) lcrc_set_hidden_split(ctx_, v); }
+    // 0: the calling thread spins while the device works; n: it sleeps, looking every n microseconds (lcrc_set_wait_mode)
+    void SetWaitMode(int poll_us) { if (ctx_) lcrc_set_wait_mode(ctx_, poll_us); }
     // lcrc_set_arithmetic: false when the model has no split-f16 form (LastError() says why)
     bool SetArithmetic(int a)
     {

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <time.h>
 #include <vector>
 
 #include "frontend_dev.h"
@@ -122,6 +123,8 @@ struct lcrc_ctx {
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = true, timed = false;
+    int poll_wait_us = 0;                // lcrc_set_wait_mode: 0 = spin in hipStreamSynchronize, > 0 = sleep between completion queries
+    hipEvent_t ev_wait = nullptr;
     // posterior writer path
     lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     int out_be = 0;
@@ -419,6 +422,25 @@ void free_offset_staging(lcrc_ctx *c)
     c->cap_utts = 0;
 }
 
+// The end of a host-pointer call's work on the context's stream.  Default: hipStreamSynchronize, which spins on the
+// completion signal (lowest latency; a core per waiting thread).  Polling mode (lcrc_set_wait_mode): an event behind the
+// work, queried between short sleeps -- the waiting thread uses next to no CPU time and learns of the completion some tens
+// of microseconds late.  For callers with more contexts in flight than cores to spare (the CLI with many GPUs).
+hipError_t wait_stream(lcrc_ctx *c)
+{
+    if (c->poll_wait_us <= 0) return hipStreamSynchronize(c->stream);
+    hipError_t e = hipSuccess;
+    if (!c->ev_wait) e = hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_wait, c->stream);
+    if (e != hipSuccess) return e;
+    const timespec nap = {0, (long)c->poll_wait_us * 1000L};
+    for (;;) {
+        e = hipEventQuery(c->ev_wait);
+        if (e != hipErrorNotReady) return e;
+        nanosleep(&nap, nullptr);
+    }
+}
+
 // Staging buffers of the host-pointer entry points.  A failed allocation leaves the group it belongs to
 // EMPTY (nothing half-allocated, capacity 0): the call fails with LCRC_E_NOMEM and a later call starts over.
 int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
@@ -712,7 +734,7 @@ int run_host(lcrc_ctx *c, const float *mel, const int *off, int n_utts, int n, f
         if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     if (copy_post && post) memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
     if (any)
         for (int i = 0; i < 5; i++)
@@ -1121,6 +1143,7 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->h_pushout) (void)hipHostFree(c->h_pushout);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1231,7 +1254,7 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
         if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)n * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     return LCRC_OK;
 }
 
@@ -1419,7 +1442,7 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
     if (!mel) return fail(c, LCRC_E_ARG, "lcrc_wave_to_mel: NULL output");
     const size_t nbytes = (size_t)rows * c->nbanks * sizeof(float);
     HIP_TRY(c, hipMemcpyAsync(c->h_mel, c->d_mel, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     memcpy(mel, c->h_mel, nbytes);
     return LCRC_OK;
 }
@@ -1441,7 +1464,7 @@ static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
         if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, nbytes, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     if (copy_post && post) memcpy(post, c->h_post, nbytes);   // post == NULL: read them in place (lcrc_staged_posteriors)
     return LCRC_OK;
 }
@@ -1621,7 +1644,7 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
         // the new history while the copies and the kernel run: the last 30 pushed frames
         memcpy(c->h_ring, mel + ((size_t)n - H) * nb, H * nb * sizeof(float));
         c->ring_rows = H;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, wait_stream(c));
         memcpy(post, c->h_post, (size_t)n * O * sizeof(float));
         c->delay += n;
         if (c->delay > 9999) c->delay = 9999;
@@ -1641,7 +1664,7 @@ int lcrc_push(lcrc_ctx *c, const float *mel, int n, float *post, int needed)
         if (c->system == SYS_LCRC) {
             rc = launch(c, c->d_ring + first * nb, nullptr, 1, (int)(H + n), c->d_pushout, c->stream, nullptr, kShift, n, false);
             if (rc) return rc;
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, wait_stream(c));
             memcpy(post, c->h_pushout, (size_t)n * O * sizeof(float));
         } else {                             // the unfused systems compute the whole strip
             rc = run_host(c, c->h_ring + first * nb, nullptr, 1, (int)(H + n), nullptr, nullptr, false);
@@ -1678,7 +1701,7 @@ int lcrc_posteriors_rows(lcrc_ctx *c, const float *mel, int n_rows, int row_firs
     rc = ensure_host_post(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->h_post, c->d_post, (size_t)row_count * O * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, wait_stream(c));
     memcpy(post, c->h_post, (size_t)row_count * O * sizeof(float));
     return LCRC_OK;
 }
@@ -1733,6 +1756,13 @@ int lcrc_debug_set_stamps(lcrc_ctx *c, void *d_buf)
     return LCRC_OK;
 }
 #endif
+
+int lcrc_set_wait_mode(lcrc_ctx *c, int poll_interval_us)
+{
+    if (!c || poll_interval_us < 0 || poll_interval_us > 100000) return fail(c, LCRC_E_ARG, "lcrc_set_wait_mode: 0 (spin) or a polling interval of 1..100000 us");
+    c->poll_wait_us = poll_interval_us;
+    return LCRC_OK;
+}
 
 int lcrc_set_timing(lcrc_ctx *c, int enabled)
 {
