@@ -531,6 +531,31 @@ def test_large_launch(capi):
     assert np.array_equal(post[1000 + 15:2000 - 15], post[150000 + 15:151000 - 15])
 
 
+def test_sleeping_waits_change_nothing(capi, tmp_path):
+    """lcrc_set_wait_mode: the host-pointer entries wait for the device by querying an event between short sleeps instead of
+    spinning in hipStreamSynchronize -- same results on every entry point, bad intervals refused"""
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 96, 30, seed=4)
+    ctx = capi.Lcrc(d, 15)
+    lens = [40, 0, 300, 7]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    mel = modelgen.synth_mel(int(off[-1]), 15, seed=2)
+    want = ctx.posteriors_batch(mel, off)
+    ctx.reset()
+    pushed = ctx.push(mel[:20])
+    for us in (1, 50, 1000, 0):
+        ctx.set_wait_mode(us)
+        assert np.array_equal(ctx.posteriors_batch(mel, off), want)
+        assert np.array_equal(ctx.posteriors_staged(mel, off), want)
+        assert np.array_equal(ctx.posteriors(mel[:40]), want[:40])
+        ctx.reset()
+        assert np.array_equal(ctx.push(mel[:20]), pushed)
+    for bad in (-1, 100001):
+        with pytest.raises(capi.LcrcError):
+            ctx.set_wait_mode(bad)
+    ctx.close()
+
+
 def test_staged_zero_copy_entry_equals_batch(capi, tmp_path):
     """lcrc_stage_buffers / lcrc_stage_run (what the CLI uses) vs lcrc_posteriors_batch, incl. buffer regrowth"""
     d = str(tmp_path / "m")
