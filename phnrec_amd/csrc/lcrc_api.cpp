@@ -565,14 +565,28 @@ int launch_traps(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, 
     if (!fused_dct) HIP_TRY(c, traps_features_launch(f, s));
     const float *merger_in = c->d_feat;
     if (c->system != SYS_1BT_DCT) {
-        m.net = c->band_max;                 // one launch, grid.y = band net
-        const long in_ld = c->system == SYS_LCRC_GEN ? c->band_nets[0].n_inp : c->trap_len;
-        m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = (int)c->band_nets.size();
-        m.in = c->d_feat; m.in_ld = in_ld; m.in_net_stride = (long)n_rows * in_ld;
-        m.out = c->d_minp; m.out_ld = (long)Km;
-        m.neg_log = c->system == SYS_LCRC_GEN ? 2 : 1;
-        HIP_TRY(c, mlp_launch(m, s));
-        m.nets_dev = nullptr; m.out_col = nullptr; m.n_nets = 0;
+        if (c->system == SYS_LCRC_GEN) {
+            // the two band nets one after the other (their inputs may be wider than the many-nets kernels' 256): each
+            // writes ln(p) into its columns of the merger's input rows
+            const long in_ld = c->band_nets[0].n_inp;
+            int col = 0;
+            for (int i = 0; i < 2; i++) {
+                m.net = c->band_nets[i];
+                m.in = c->d_feat + (size_t)i * n_rows * in_ld; m.in_ld = in_ld;
+                m.out = c->d_minp + col; m.out_ld = (long)Km;
+                m.neg_log = 2;
+                HIP_TRY(c, mlp_launch(m, s));
+                col += c->band_nets[i].n_out;
+            }
+        } else {
+            m.net = c->band_max;                 // one launch, grid.y = band net
+            m.nets_dev = c->d_band_nets; m.out_col = c->d_band_col; m.n_nets = (int)c->band_nets.size();
+            m.in = c->d_feat; m.in_ld = c->trap_len; m.in_net_stride = (long)n_rows * c->trap_len;
+            m.out = c->d_minp; m.out_ld = (long)Km;
+            m.neg_log = 1;
+            HIP_TRY(c, mlp_launch(m, s));
+            m.nets_dev = nullptr; m.out_col = nullptr; m.n_nets = 0;
+        }
         merger_in = c->d_minp;
     }
     m.net = c->nets[2];

@@ -44,7 +44,7 @@ def pad4(n):
 def half_windows(half=HALF):
     """The two half-Hamming windows (16 taps in every shipped system; `half` taps for other posteriors/length values)."""
     j = np.arange(half, dtype=np.float64)
-    w0 = 0.54 - 0.46 * np.cos(2.0 * np.pi * j / (2.0 * (half - 1)))
+    w0 = 0.54 - 0.46 * np.cos(2.0 * np.pi * j / (2.0 * max(half - 1, 1)))
     return w0.astype(np.float32), w0[::-1].astype(np.float32).copy()
 
 

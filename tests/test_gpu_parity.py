@@ -494,6 +494,9 @@ def test_fuzzed_models(capi, oracle_mod):
     from tools import fuzz_parity
     ran, worst, worst_s, worst_d = fuzz_parity.fuzz(seed=20261004, n_models=30, n_h2=12, log=lambda *a: None)
     assert ran >= 20 and worst < TOL and worst_s < TOL and worst_d < 5e-5
+    # ... and 25 random geometries of the general kernels (any length 2..64, C0 on / off, 1..16 values per band, all four
+    # systems) against the run-time-geometry oracle
+    assert fuzz_parity.fuzz_geometry(seed=20261004, n_models=25, log=lambda *a: None) < TOL
 
 
 def test_sharded_file_list_shape(capi, oracle_mod, tmp_path):
@@ -735,6 +738,16 @@ def test_general_geometry(capi, oracle_mod, tmp_path):
         with pytest.raises(capi.LcrcError) as e:
             ctx.posteriors_rows(mel2[:40], 5, 10)
         assert e.value.code == capi.LCRC_E_UNSUPPORTED
+        ctx.close()
+    # band nets wider than the many-nets kernels' 256 inputs (23 banks x 16 values), and the shortest length there is
+    for nb, coefs, L, c0 in ((23, 16, 31, False), (9, 2, 2, True)):
+        d = str(tmp_path / ("wide%d" % L))
+        modelgen.write_model_dir(d, nb, 70, 33, seed=60 + L, coefs=coefs, trap_len=L, add_c0=c0)
+        ctx = capi.Lcrc(d, nb, trap_len=L, add_c0=c0)
+        o = oracle_mod.TrapsOracle(d, "LCRC", nb, c0, False, trap_len=L)
+        mel = modelgen.synth_mel(90, nb, seed=L)
+        off = np.array([0, 50, 50, 90], np.int32)
+        assert np.abs(ctx.posteriors_batch(mel, off) - o.posteriors_batch(mel, off)).max() < TOL
         ctx.close()
     # lengths outside 2 .. 255, and band nets whose inputs nbanks does not divide
     d = str(tmp_path / "bad")

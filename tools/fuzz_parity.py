@@ -3,7 +3,7 @@
 hidden size) on ragged batches, 16- and 32-frame workgroups and forced hidden splits, each against the oracle at the
 1e-4 bar; then models of the shipped shape classes (random hidden sizes, weight scales and input scales) in the split-f16
 arithmetic, against the oracle and against the f32 kernels.
-usage: fuzz_parity.py [seed [models [split_f16_models]]]      (also tests/test_gpu_parity.py::test_fuzzed_models)"""
+usage: fuzz_parity.py [seed [models [split_f16_models [geometry_models]]]]      (also tests/test_gpu_parity.py::test_fuzzed_models)"""
 import os
 import sys
 import tempfile
@@ -78,6 +78,48 @@ def fuzz(seed=0, n_models=60, n_h2=24, log=print):
     return ran, worst, worst_s, worst_d
 
 
+def fuzz_geometry(seed=0, n_models=40, log=print):
+    """Random geometries of the general kernels: any posteriors/length 2..64 (odd and even), add_c0 on / off, 1..16 values
+    per band, all four systems, Hamming window on / off -- against the run-time-geometry oracle."""
+    from oracle import binding as ob
+    from phnrec_amd import capi, modelgen
+    capi.load()
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for it in range(n_models):
+        system = ["LCRC", "LCRC", "1BT_DCT", "1BT", "3BT"][int(rng.integers(0, 5))]
+        L = int(rng.integers(2, 65))
+        nb = int(rng.integers(3, 24))
+        c0 = bool(rng.integers(0, 2))
+        hamm = bool(rng.integers(0, 2)) and system != "LCRC"
+        coefs = int(rng.integers(1, 17))
+        if system == "1BT_DCT":
+            coefs = min(coefs, L + (1 if c0 else 0))          # at most L cosine rows (+ C0)
+        hid, nout = int(rng.integers(1, 200)), int(rng.integers(2, 100))
+        with tempfile.TemporaryDirectory() as d:
+            if system == "LCRC":
+                if L == 31 and c0 and coefs == 11:
+                    coefs = 10
+                modelgen.write_model_dir(d, nb, hid, nout, seed=int(rng.integers(1 << 30)), coefs=coefs, trap_len=L, add_c0=c0)
+            else:
+                modelgen.write_traps_dir(d, system, nb, hid, nout, seed=int(rng.integers(1 << 30)), coefs=coefs, add_c0=c0,
+                                         hamming=hamm, trap_len=L, band_out=int(rng.integers(2, 30)), band_hidden=int(rng.integers(1, 60)))
+            ctx = capi.Lcrc(d, nb, system=system, add_c0=c0, hamming=hamm, trap_len=L)
+            o = ob.TrapsOracle(d, system, nb, c0, hamm, trap_len=L)
+            lens = [int(v) for v in rng.integers(0, 90, size=int(rng.integers(1, 6)))]
+            if sum(lens) == 0:
+                lens.append(3)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+            mel = modelgen.synth_mel(int(off[-1]), nb, seed=it)
+            err = float(np.abs(ctx.posteriors_batch(mel, off) - o.posteriors_batch(mel, off)).max())
+            worst = max(worst, err)
+            assert err < 1e-4, (system, L, nb, c0, hamm, coefs, err)
+            ctx.close()
+    log("geometry fuzz ok: %d models, worst max-abs %g" % (n_models, worst))
+    return worst
+
+
 if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:]]
-    fuzz(*a)
+    fuzz(*a[:3])
+    fuzz_geometry(a[0] if a else 0, a[3] if len(a) > 3 else 40)
