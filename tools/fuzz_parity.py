@@ -111,9 +111,22 @@ def fuzz_geometry(seed=0, n_models=40, log=print):
                 lens.append(3)
             off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
             mel = modelgen.synth_mel(int(off[-1]), nb, seed=it)
-            err = float(np.abs(ctx.posteriors_batch(mel, off) - o.posteriors_batch(mel, off)).max())
+            got = ctx.posteriors_batch(mel, off)
+            err = float(np.abs(got - o.posteriors_batch(mel, off)).max())
             worst = max(worst, err)
             assert err < 1e-4, (system, L, nb, c0, hamm, coefs, err)
+            assert np.array_equal(ctx.posteriors_staged(mel, off), got), (system, L)
+            # the streaming form: frame r's estimate appears when frame r + (L - 1) / 2 has been pushed
+            u = mel[int(off[-2]):int(off[-1])] if off[-1] > off[-2] else mel[:int(off[1])]
+            if len(u):
+                shift = (L - 1) // 2
+                whole = ctx.posteriors(u)
+                ctx.reset()
+                parts = [ctx.push(u[i:i + 5]) for i in range(0, len(u), 5)]
+                if shift:
+                    parts.append(ctx.push(np.repeat(u[-1:], shift, axis=0)))
+                pushed = np.concatenate(parts)[shift:]
+                assert np.abs(pushed - whole).max() < 1e-6, (system, L, nb, len(u), float(np.abs(pushed - whole).max()))
             ctx.close()
     log("geometry fuzz ok: %d models, worst max-abs %g" % (n_models, worst))
     return worst
