@@ -188,6 +188,14 @@ def test_default_system_1bt_dct_end_to_end(tmp_path):
     _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))
 
 
+def test_fuzzed_lists_and_pipeline_settings():
+    """tools/fuzz_cli.py with a fixed seed: random lists (empty files, files shorter than a frame, exactly one frame, up to
+    20 s, sometimes an unreadable name) through random batch sizes, logical GPU counts, host thread counts and the three
+    modes -- every configuration writes the MLF (or fails where) its mode's plain run does, within the time limit"""
+    from tools import fuzz_cli
+    assert fuzz_cli.fuzz(seed=20261004, n_lists=3, log=lambda *a: None) == 27
+
+
 def test_lcrc_at_another_length_end_to_end(tmp_path):
     """posteriors/length=21, add_c0=false (a geometry the reference accepts but no shipped model uses) through the CLI on
     the bundled utterance, against the posterior dump the reference CLI wrote for the same synthetic model; the list

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised run of the CLI's list pipeline (GPU): random lists -- files of 0 bytes, less than a frame, exactly a frame, up to
+20 s, optionally one unreadable name --, random batch sizes (-b), logical GPU counts (-g N on the one device), host threads
+(-j) and modes (host front-end, -F, -F -D): every configuration must write the MLF its mode's plain run writes (or fail the
+same way), and none may hang (each run has a time limit).     usage: fuzz_cli.py [seed [lists]]"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+EXE = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+MODEL = os.path.join(ROOT, "tests", "golden", "models", "PHN_CZ_SPDAT_LCRC_N1500")
+
+
+def run(args, env=None, limit=120):
+    p = subprocess.run([EXE] + [str(a) for a in args], capture_output=True, text=True, timeout=limit,
+                       env=dict(os.environ, **(env or {})))
+    return p.returncode, p.stderr
+
+
+def fuzz(seed=0, n_lists=12, log=print):
+    rng = np.random.default_rng(seed)
+    runs = 0
+    for it in range(n_lists):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            n_files = int(rng.integers(1, 70))
+            names = []
+            for i in range(n_files):
+                kind = int(rng.integers(0, 10))
+                n = 0 if kind == 0 else int(rng.integers(1, 200)) if kind == 1 else 200 if kind == 2 else int(rng.integers(201, 160000))
+                p = os.path.join(td, "f%03d.raw" % i)
+                (rng.normal(0, 2500, n).clip(-32768, 32767).astype("<i2")).tofile(p)
+                names.append(p)
+            bad = int(rng.integers(0, 4)) == 0
+            if bad:
+                names.insert(int(rng.integers(0, len(names) + 1)), os.path.join(td, "missing.raw"))
+            lst = os.path.join(td, "list.scp")
+            open(lst, "w").write("".join(n + "\n" for n in names))
+            for mode in ([], ["-F"], ["-F", "-D"]):
+                ref_mlf = os.path.join(td, "ref.mlf")
+                rc0, err0 = run(["-c", MODEL, "-l", lst, "-m", ref_mlf] + mode)
+                assert (rc0 != 0) == bad, (seed, it, mode, rc0, err0[-300:])
+                want = open(ref_mlf).read() if os.path.exists(ref_mlf) else None
+                for _ in range(3):
+                    g = int(rng.choice([1, 1, 2, 3, 4]))
+                    b = int(rng.choice([64, 700, 5000, 32768, 200000]))
+                    j = int(rng.choice([1, 2, 5, 16]))
+                    out = os.path.join(td, "o.mlf")
+                    if os.path.exists(out):
+                        os.remove(out)
+                    rc, err = run(["-c", MODEL, "-l", lst, "-m", out, "-g", g, "-b", b, "-j", j] + mode,
+                                  env={"PHNREC_DEVICE_MAP": ",".join(["0"] * g)})
+                    got = open(out).read() if os.path.exists(out) else None
+                    assert rc == rc0 and got == want, (seed, it, mode, g, b, j, rc, err[-300:])
+                    runs += 1
+    log("cli fuzz ok: %d lists, %d configurations" % (n_lists, runs))
+    return runs
+
+
+if __name__ == "__main__":
+    a = [int(v) for v in sys.argv[1:]]
+    fuzz(*a)
