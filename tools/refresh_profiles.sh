@@ -18,7 +18,7 @@ PHNREC_DEVICE_MAP=0,0 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu -
 echo "bench done"
 # per-kernel summary: rocprofv3's own (every launch of the process) and the steady-state one (the 200 timed launches)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 200 --warmup 100 --no-cpu --no-extras --list-files 0 > $OUT/bench_profiled.json 2> $OUT/stats.log
-python3 tools/steady_kernel_stats.py $OUT/stats 200 $OUT/steady_kernel_stats.csv
+python3 tools/steady_kernel_stats.py $OUT/stats 200 $OUT/steady_kernel_stats.csv $OUT/bench_profiled.json
 # the fused kernel's own dispatch rows (grid, workgroup, LDS, registers)
 for f in $OUT/stats/*/*kernel_trace.csv; do head -1 $f > $OUT/kernel_trace_head.csv; grep -m 3 lcrc_fused_kernel $f >> $OUT/kernel_trace_head.csv; done
 i=0

@@ -3,10 +3,14 @@
 
 rocprofv3's own --stats averages every launch of the process, including the first ones (code-object load, clock
 ramp after idling: ~0.29 ms against 0.195 ms for the bench's kernel), so its average sits above the bench's own
-figure for the timed launches.  This tool reads the same run's kernel trace and summarises, per kernel, only the last
-N launches (N = the timed steps of the traced command), in the column layout of rocprofv3's *_kernel_stats.csv.
+figure for the timed launches.  This tool reads the same run's kernel trace and summarises, per kernel, only the N
+launches of the traced command's timed region, in the column layout of rocprofv3's *_kernel_stats.csv.  Which launches
+those are: BENCH.json (the traced run's own line) says how many pre-heat and warm-up launches precede them
+("roofline.launches_timed": "200 launches after 320 pre-heat + 100 warm-up launches") -- the bench's check launches
+BEHIND the timed region (parity, cold-clock figure: ~46, after host-side pauses) must not be counted either.  Without
+BENCH.json: the last N launches of every kernel.  Kernels other than the timed one: their last N.
 
-usage: steady_kernel_stats.py TRACE_DIR N [OUT.csv]        (TRACE_DIR holds <pid>_kernel_trace.csv)"""
+usage: steady_kernel_stats.py TRACE_DIR N [OUT.csv [BENCH.json]]        (TRACE_DIR holds <pid>_kernel_trace.csv)"""
 import csv
 import glob
 import math
@@ -17,6 +21,14 @@ import sys
 def main():
     trace_dir, n = sys.argv[1], int(sys.argv[2])
     out = sys.argv[3] if len(sys.argv) > 3 else None
+    first = None
+    if len(sys.argv) > 4:
+        import json
+        import re
+        line = [ln for ln in open(sys.argv[4]).read().splitlines() if ln.startswith("{")][-1]
+        nums = [int(v) for v in re.findall(r"\d+", json.loads(line)["roofline"]["launches_timed"])]
+        assert nums[0] == n, (nums, n)
+        first = sum(nums[1:])                       # launches before the timed region
     files = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + trace_dir)
@@ -28,14 +40,16 @@ def main():
     stats = []
     for name, v in by.items():
         v.sort()
-        d = [x[1] for x in v[-n:]] if len(v) > n else [x[1] for x in v]
+        timed = first is not None and len(v) >= first + n and "lcrc_fused_kernel" in name
+        d = [x[1] for x in v[first:first + n]] if timed else [x[1] for x in v[-n:]] if len(v) > n else [x[1] for x in v]
+        window = ("launches %d..%d of %d (the timed region)" % (first + 1, first + n, len(v))) if timed else "last %d launches of %d" % (len(d), len(v))
         avg = sum(d) / len(d)
         sd = math.sqrt(sum((x - avg) ** 2 for x in d) / len(d))
-        stats.append((name, len(d), sum(d), avg, min(d), max(d), sd, len(v)))
+        stats.append((name, len(d), sum(d), avg, min(d), max(d), sd, len(v), window))
     total = sum(s[2] for s in stats) or 1
     for s in sorted(stats, key=lambda s: -s[2]):
         lines.append([s[0], s[1], s[2], "%.3f" % s[3], "%.2f" % (100.0 * s[2] / total), s[4], s[5], "%.3f" % s[6], s[7],
-                      "last %d launches of %d" % (s[1], s[7])])
+                      s[8]])
     w = csv.writer(open(out, "w", newline="") if out else sys.stdout, quoting=csv.QUOTE_NONNUMERIC)
     w.writerows(lines)
 
