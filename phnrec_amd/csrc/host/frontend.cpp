@@ -407,4 +407,28 @@ void SentenceMeanNorm(float *mel, int rows, int cols)
     }
 }
 
+// offlinenorm/sent_max_norm and sent_chmax_norm (srec.cpp:1547-1587), after the mean normalisation: every column's
+// maximum over the utterance (from -9999.9, strict >) is subtracted from the column.  With sent_max_norm the reference
+// means the maximum over all columns, but its loop overwrites the whole row of maxima with the running value in EVERY
+// iteration (`max.set(global_max)` inside the loop, :1573-1580): what is subtracted everywhere is column 0's maximum.
+// Restated as it is.
+void SentenceMaxNorm(float *mel, int rows, int cols, bool global)
+{
+    std::vector<float> mx((size_t)cols, -9999.9f);
+    for (int c = 0; c < cols; c++)
+        for (int r = 0; r < rows; r++) {
+            const float v = mel[(size_t)r * cols + c];
+            if (v > mx[c]) mx[c] = v;
+        }
+    if (global) {
+        float g = -9999.9f;
+        for (int c = 0; c < cols; c++) {
+            if (mx[c] > g) g = mx[c];
+            for (int k = 0; k < cols; k++) mx[k] = g;
+        }
+    }
+    for (int c = 0; c < cols; c++)
+        for (int r = 0; r < rows; r++) mel[(size_t)r * cols + c] = mel[(size_t)r * cols + c] - mx[c];
+}
+
 }  // namespace phnrec

@@ -60,6 +60,8 @@ private:
 // offlinenorm/sent_mean_norm (srec.cpp:1500-1511): column sums are sequential f32,
 // mean = sum * (1.0f / rows), x += -mean.
 void SentenceMeanNorm(float *mel, int rows, int cols);
+// offlinenorm/sent_chmax_norm (global = false) and sent_max_norm (global = true) as the reference computes them
+void SentenceMaxNorm(float *mel, int rows, int cols, bool global);
 
 }  // namespace phnrec
 #endif

@@ -234,6 +234,8 @@ bool SpeechRec::Init(const std::string &config_file)
                         C.GetFloat("melbanks", "lower_freq"), C.GetFloat("melbanks", "higher_freq"));
     Log("  - online normalization ...\n");
     sent_mean_norm_ = C.GetBool("offlinenorm", "sent_mean_norm");
+    sent_max_norm_ = C.GetBool("offlinenorm", "sent_max_norm");
+    sent_chmax_norm_ = C.GetBool("offlinenorm", "sent_chmax_norm");
     if (C.GetBool("offlinenorm", "sent_var_norm"))
         return Fail("offlinenorm/sent_var_norm=true is not supported (the reference aborts on it: srec.cpp:1531 reads a variable that is not in its schema)\n");
 
@@ -352,6 +354,7 @@ std::string SpeechRec::SetUpContext(Traps &t)
         fe.sent_mean_norm = sent_mean_norm_ ? 1 : 0;
         if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
             return "framenorm/* needs the host front-end; drop -F\n";
+        if (sent_max_norm_ || sent_chmax_norm_) return "offlinenorm/sent_max_norm and sent_chmax_norm need the host front-end; drop -F\n";
         if (!t.ConfigureFrontend(fe)) return t.LastError() + "\n";
     }
     return std::string();
@@ -486,8 +489,10 @@ void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
         }
     }
     // sentence normalisation happens after the `-t par` exit (srec.cpp:973-974,999)
-    if ((in == dfWaveform || in == dfParams) && out != dfParams && sent_mean_norm_ && job.frames > 0)
-        SentenceMeanNorm(job.mel.data(), job.frames, nbanks_);
+    if ((in == dfWaveform || in == dfParams) && out != dfParams && job.frames > 0) {
+        if (sent_mean_norm_) SentenceMeanNorm(job.mel.data(), job.frames, nbanks_);
+        if (sent_max_norm_ || sent_chmax_norm_) SentenceMaxNorm(job.mel.data(), job.frames, nbanks_, sent_max_norm_);
+    }
 }
 
 static lcrc_softening DeviceSoftening(const std::string &f, const float *a)

@@ -120,6 +120,7 @@ private:
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
 
     std::string config_dir_, err_;
+    bool sent_max_norm_ = false, sent_chmax_norm_ = false;
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false, split_f16_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;

@@ -110,8 +110,10 @@ def write_ascii(weights_path, norms_path, net):
 
 def config_text(nbanks, sample_freq=8000, vector_size=200, vector_step=80, lower=64, higher=4000,
                 sent_mean_norm=True, wpenalty=-4.6875, fmt="lin16", suffix="mel", bunch_size=5,
-                system="LCRC", add_c0=True, hamming=False, trap_len=TRAP_LEN, **_unused):
+                system="LCRC", add_c0=True, hamming=False, trap_len=TRAP_LEN, sent_max_norm=False, sent_chmax_norm=False,
+                **_unused):
     b = "true" if sent_mean_norm else "false"
+    mx, cmx = ("true" if sent_max_norm else "false"), ("true" if sent_chmax_norm else "false")
     c0, hm = ("true" if add_c0 else "false"), ("true" if hamming else "false")
     return f"""[source]
 format={fmt}
@@ -150,6 +152,8 @@ mode=decode
 [offlinenorm]
 sent_mean_norm={b}
 sent_var_norm=false
+sent_max_norm={mx}
+sent_chmax_norm={cmx}
 
 [dirs]
 tmp=$C/tmp

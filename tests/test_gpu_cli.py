@@ -188,6 +188,29 @@ def test_default_system_1bt_dct_end_to_end(tmp_path):
     _labels_match(rec2, os.path.join(GOLD, "systems", "1bt_dct.rec"))
 
 
+def test_sentence_maximum_normalisations(tmp_path):
+    """offlinenorm/sent_max_norm and sent_chmax_norm (srec.cpp:1547-1587; no shipped config sets them) against the
+    posterior dumps the reference CLI wrote with them -- sent_max_norm as the reference computes it: its loop ends up
+    subtracting column 0's maximum everywhere.  With -F they are refused (host front-end only)."""
+    from phnrec_amd import modelgen
+    from tools.make_golden_systems import NORM_CLI_MODEL, NORM_CLI_CASES
+    raw = os.path.join(GOLD, "test.raw")
+    dumps = {}
+    for name, cfg in NORM_CLI_CASES:
+        c = dict(NORM_CLI_MODEL)
+        d = str(tmp_path / name)
+        modelgen.write_model_dir(d, c.pop("nbanks"), c.pop("hidden"), c.pop("n_out"), seed=c.pop("seed"), **cfg)
+        lop = tmp_path / (name + ".lop")
+        run("-c", d, "-i", raw, "-t", "post", "-o", lop)
+        got, want = read_htk(str(lop)), read_htk(os.path.join(GOLD, "systems", "lcrc_%s.lop" % name))
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4, name
+        dumps[name] = got
+        p = subprocess.run([BIN, "-c", d, "-i", raw, "-t", "post", "-o", str(lop), "-F"], capture_output=True, text=True)
+        assert p.returncode != 0 and "host front-end" in p.stderr
+    assert np.abs(dumps["maxnorm"] - dumps["chmaxnorm"]).max() > 1e-3        # (they do differ)
+    assert np.array_equal(dumps["maxnorm"], dumps["bothmax"])                # the global form overrides the per-channel one
+
+
 def test_fuzzed_lists_and_pipeline_settings():
     """tools/fuzz_cli.py with a fixed seed: random lists (empty files, files shorter than a frame, exactly one frame, up to
     20 s, sometimes an unreadable name) through random batch sizes, logical GPU counts, host thread counts and the three

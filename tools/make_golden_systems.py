@@ -48,6 +48,11 @@ GEOM_CASES = [
     ("dct_12_even", "1BT_DCT", 23, 64, 30, 50, dict(coefs=5), [33, 20], 12),
 ]
 GEOM_CLI_CASE = dict(nbanks=15, hidden=100, n_out=45, seed=51, coefs=5, add_c0=False, trap_len=21)
+# offlinenorm/sent_max_norm and sent_chmax_norm (srec.cpp:1547-1587; no shipped config sets them): the reference CLI's
+# posterior dumps on test.raw for a synthetic LCRC model of the usual geometry -> tests/golden/systems/lcrc_<name>.lop
+NORM_CLI_MODEL = dict(nbanks=15, hidden=100, n_out=45, seed=52)
+NORM_CLI_CASES = [("maxnorm", dict(sent_max_norm=True)), ("chmaxnorm", dict(sent_chmax_norm=True, sent_mean_norm=False)),
+                  ("bothmax", dict(sent_max_norm=True, sent_chmax_norm=True))]
 
 
 def write_geometry_model(path, system, nb, hid, nout, seed, kw, trap_len):
@@ -95,6 +100,14 @@ def main():
         subprocess.run([cli, "-c", td, "-i", os.path.join(GOLD, "test.raw"), "-t", "post", "-o", dst], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         shutil.copyfile(dst, os.path.join(sub, "lcrc_len21.lop"))
+    for name, cfg in NORM_CLI_CASES:
+        with tempfile.TemporaryDirectory() as td:
+            c = dict(NORM_CLI_MODEL)
+            modelgen.write_model_dir(td, c.pop("nbanks"), c.pop("hidden"), c.pop("n_out"), seed=c.pop("seed"), **cfg)
+            dst = os.path.join(td, "out.lop")
+            subprocess.run([cli, "-c", td, "-i", os.path.join(GOLD, "test.raw"), "-t", "post", "-o", dst], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            shutil.copyfile(dst, os.path.join(sub, "lcrc_%s.lop" % name))
     with tempfile.TemporaryDirectory() as td:
         c = dict(CLI_CASE)
         modelgen.write_traps_dir(td, c.pop("system"), c.pop("nbanks"), c.pop("hidden"), c.pop("n_out"),
