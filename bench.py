@@ -842,7 +842,7 @@ def main():
                 dt = (time.perf_counter() - t0) / reps
                 line["host_path_zero_copy"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
                                                "ms_per_call": round(dt * 1e3, 4),
-                                               "what": "lcrc_stage_run() on the context's pinned buffers: H2D + kernel + D2H, "
+                                               "what": "lcrc_stage_run() on the context's pinned buffers: kernel on the features in place (mapped) + D2H, "
                                                        "synchronous"}
             if ranks.world == 1 and not args.no_extras:
                 en_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_EN_TIMIT_LCRC_N500")
