@@ -68,6 +68,50 @@ def test_decoder_reproduces_reference_labels(system, tmp_path):
     assert mine[0][0] == "000000"            # "%d00000" of frame 0, as the reference prints it
 
 
+def _es_model(tmp_path):
+    """the reference's test/PHN_ES = the HU model under another config (source/format=lin16) and phoneme list"""
+    d = tmp_path / "PHN_ES"
+    shutil.copytree(model_dir("PHN_HU_SPDAT_LCRC_N1500"), d)
+    shutil.copy(os.path.join(GOLD, "ref", "PHN_ES", "config"), d / "config")
+    shutil.copy(os.path.join(GOLD, "ref", "PHN_ES", "dicts", "phonemes"), d / "dicts" / "phonemes")
+    return d
+
+
+def test_reference_fixture_8580_host_legs(tmp_path):
+    """/root/reference/test (8580.wav, lsit.txt, the MLF `test`): the host legs of that fixture.  The .wav's 44-byte
+    RIFF header is read as 22 samples like the reference does (srec.cpp:1384-1422 loads the whole file): `-t par`
+    must equal the reference CLI's dump bit for bit; decoding the reference's posterior dump through the list mode
+    (`-s post -l`, one-column line with a bare name -> MLF entry "8580.rec", srec.cpp:1424-1436) must give the
+    reference's MLF: names, labels, times exact, scores within 1e-2 of the SHIPPED file."""
+    ref = os.path.join(GOLD, "ref")
+    es = _es_model(tmp_path)
+    mel = tmp_path / "8580.mel"
+    run("-c", es, "-i", os.path.join(ref, "8580.wav"), "-t", "par", "-o", mel)
+    assert open(mel, "rb").read() == open(os.path.join(ref, "8580.mel"), "rb").read()
+    work = tmp_path / "work"
+    work.mkdir()
+    shutil.copy(os.path.join(ref, "8580.lop"), work / "8580.lop")
+    (work / "l.txt").write_text("8580.lop\n")
+    p = subprocess.run([BIN, "-c", str(es), "-s", "post", "-l", "l.txt", "-m", "out.mlf"], cwd=work,
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    mine = (work / "out.mlf").read_text().splitlines()
+    gold = open(os.path.join(ref, "8580.mlf")).read().splitlines()
+    assert len(mine) == len(gold)
+    for a, b in zip(mine, gold):
+        pa, pb = a.split(), b.split()
+        if len(pb) == 4:
+            assert pa[:3] == pb[:3] and abs(float(pa[3]) - float(pb[3])) < 1e-2, (a, b)
+        else:
+            assert a == b, (a, b)
+    out = tmp_path / "8580.rec"
+    run("-c", es, "-s", "post", "-i", work / "8580.lop", "-o", out)
+    mine = [l.split() for l in open(out)]
+    shipped = [l.split() for l in open(os.path.join(ref, "8580.rec"))]
+    assert [m[:3] for m in mine] == [s[:3] for s in shipped]
+    assert max(abs(float(m[3]) - float(s[3])) for m, s in zip(mine, shipped)) < 1e-2
+
+
 def test_list_mode_mlf_and_derived_names(tmp_path):
     data = tmp_path / "data"
     data.mkdir()

@@ -274,6 +274,69 @@ def test_decoder_on_the_gpu_flag(system, tmp_path):
     assert dev.read_text() == host.read_text()                            # same posteriors, same f32 additions
 
 
+# ---- the reference's own remaining goldens (tests/golden/ref: data copied from /root/reference) ---------------------
+REF = os.path.join(GOLD, "ref")
+
+
+def _es_model(tmp_path):
+    """test/PHN_ES of the reference = the HU weights, norms and windows under another phoneme list and config
+    (source/format=lin16): assembled here from the committed HU model and the two committed ES text files"""
+    import shutil
+    d = tmp_path / "PHN_ES"
+    shutil.copytree(model_dir(HU), d)
+    shutil.copy(os.path.join(REF, "PHN_ES", "config"), d / "config")
+    shutil.copy(os.path.join(REF, "PHN_ES", "dicts", "phonemes"), d / "dicts" / "phonemes")
+    return d
+
+
+@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D")])
+def test_reference_list_golden_8580(flags, tmp_path):
+    """/root/reference/test: `phnrec -c PHN_ES -l lsit.txt -m test` run inside that directory.  lsit.txt:1 is a
+    one-column line with a bare file name, so the MLF entry is "8580.rec" (no "*/": ChangeFilePath leaves a name
+    without separator alone, srec.cpp:1424-1436); 8580.wav's 44-byte RIFF header is consumed as 22 samples
+    (srec.cpp:1384-1422 reads the whole file).  Names, labels and times exact, scores within 1e-2 (SURVEY 8c);
+    also the single-file form against test/8580.rec."""
+    import shutil
+    es = _es_model(tmp_path)
+    work = tmp_path / "work"
+    work.mkdir()
+    shutil.copy(os.path.join(REF, "8580.wav"), work / "8580.wav")
+    shutil.copy(os.path.join(REF, "lsit.txt"), work / "lsit.txt")
+    e = dict(os.environ)
+    p = subprocess.run([BIN, "-c", str(es), "-l", "lsit.txt", "-m", "out.mlf"] + list(flags), cwd=work,
+                       capture_output=True, text=True, env=e)
+    assert p.returncode == 0, p.stderr
+    mine = (work / "out.mlf").read_text().splitlines()
+    gold = open(os.path.join(REF, "8580.mlf")).read().splitlines()
+    assert len(mine) == len(gold)
+    for a, b in zip(mine, gold):
+        pa, pb = a.split(), b.split()
+        if len(pb) == 4:
+            assert pa[:3] == pb[:3] and abs(float(pa[3]) - float(pb[3])) < 1e-2, (a, b)
+        else:
+            assert a == b, (a, b)                # "#!MLF!#", "8580.rec", "."
+    out = tmp_path / "8580.rec"
+    run("-c", es, "-i", work / "8580.wav", "-o", out, *flags)
+    _labels_match(out, os.path.join(REF, "8580.rec"))
+    if "-D" not in flags:                  # posteriors against the reference CLI's dump of the same file
+        lop = tmp_path / "8580.lop"
+        run("-c", es, "-i", work / "8580.wav", "-t", "post", "-o", lop, *flags)
+        got, want = read_htk(str(lop)), read_htk(os.path.join(REF, "8580.lop"))
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4
+    assert open(out).readline().split()[0] == "000000"      # a label file prints time zero as the reference does
+
+
+@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D")])
+@pytest.mark.parametrize("which", ["es", "hu"])
+def test_reference_golden_es_wav(which, flags, tmp_path):
+    """/root/reference/es.wav -> es.rec (19 s, lin16 with its header taken as samples): no phoneme the ES and HU lists
+    name differently occurs in it, so both model directories must reproduce it"""
+    d = _es_model(tmp_path) if which == "es" else model_dir(HU)
+    out = tmp_path / "es.rec"
+    run("-c", d, "-i", os.path.join(REF, "es.wav"), "-o", out, *flags)
+    _labels_match(out, os.path.join(REF, "es.rec"))
+
+
 # ---- the multi-GPU split (SURVEY 8e; BASELINE configs[3] / configs[4]) on a 1-GPU box -----------------------
 def _make_list(tmp_path, name, n_files, seed, fmt="lin16", rate=8000):
     """`n_files` synthetic waveform files of 0.2-2.5 s (5 sines + noise, as SURVEY 8d prescribes) + the list"""
