@@ -256,7 +256,10 @@ int lcrc_last_labels(lcrc_ctx *ctx, const lcrc_label **labels, const int **first
  * pushed frame i (i.e. centred 15 frames earlier); when !needed only the
  * history advances and `post` is not touched (may be NULL).  The frames are kept in a pinned strip
  * the kernel reads in place and only the n pushed rows are computed (no re-upload of the history,
- * no allocation per call).
+ * no allocation per call).  A push of >= 4096 frames goes through the context's staging buffers instead
+ * (explicit copies at PCIe rate) and may grow them: pointers handed out by lcrc_stage_buffers /
+ * lcrc_wave_stage_buffer are INVALID after such a push -- ask for them again (a caller that mixes the staged
+ * entry points with streaming on ONE context must do so anyway: both use the context's one set of buffers).
  * lcrc_delay == Traps::GetDelay (frames pushed since reset minus one, capped
  * at 9999, traps.cpp:199,215-217). */
 int lcrc_reset(lcrc_ctx *ctx);
@@ -274,7 +277,7 @@ int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
  * calling thread spins on the completion signal: lowest latency, one busy core per waiting thread.  n > 0: an event
  * behind the work is queried every n microseconds with the thread asleep in between: next to no CPU time, the completion
  * noticed up to n (plus the timer's slack) late.  For callers that keep more contexts in flight -- a thread each -- than
- * they have cores to burn: the CLI switches to it when its contexts outnumber a quarter of the usable cores. */
+ * they have cores to burn: the CLI switches to it when its contexts outnumber half of the usable cores. */
 int lcrc_set_wait_mode(lcrc_ctx *ctx, int poll_interval_us);
 /* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
  * (tuning and test hook; results are bit-identical either way) */

@@ -152,47 +152,117 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
 }
 
 // offlinenorm/sent_mean_norm (srec.cpp:1500-1511, matrix.h:194-199,245,2101-2116): the reference's column sums
-// are SEQUENTIAL f32 sums over the frames, mean = sum * (1.0f / rows), x += -mean.  That exact order is kept
-// as an option (lcrc_set_mean_order(ctx, 1)); the default is the tree below.  colmean_kernel: one workgroup per utterance streams the rows through LDS with coalesced
-// loads and lane b adds column b in frame order; submean_kernel: one thread per row subtracts.
-constexpr int kNormLdsFloats = 15360;           // 60 KiB of rows per LDS chunk (1024 rows of 15 banks)
+// are SEQUENTIAL f32 sums over the frames, mean = sum * (1.0f / rows), x += -mean.  That exact order is the DEFAULT
+// (lcrc_set_mean_order(ctx, 1), ABI 2); the fixed-shape tree further down is the opt-in (order 0).
+//
+// colmean_kernel: one workgroup per utterance; what bounds it is ONE dependent f32 add per frame and bank, so
+// everything else is kept off that chain.  Wave 0 is the ADDER: lane b owns column b and does nothing but the chain.
+// Waves 1-3 are LOADERS: they stream the utterance's rows (coalesced dword loads, 768 B per step) into a ring of
+// kMeanSlots LDS slots, TRANSPOSED -- slot[b][r], row pitch a multiple of 4 with an odd number of quads, so that the
+// adder fetches four consecutive frames of its column with one conflict-free ds_read_b128 (a [r][b] image costs one
+// LDS instruction per add and the LDS issue, not the add, set the pace: 13 ns per frame in round 3).  The loaders run
+// kMeanSlots - 1 chunks ahead; one barrier per chunk hands a slot over in each direction.  The adder requests the next
+// 16 frames from LDS before it adds the current 16.
+constexpr int kMeanSlots = 4;
+constexpr int kMeanSlotFloats = 4352;           // 17 KiB per slot: 272 rows of 15 banks (+ pad), 176 rows of 23
 __global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
                                                       float *means)
 {
-    extern __shared__ float chunk[];            // [chunk_rows][nbanks]
-    const int chunk_rows = kNormLdsFloats / nbanks;
+    extern __shared__ float ring[];             // [kMeanSlots][nbanks][RP]
     const int u = blockIdx.x;
     const int a = frame_off[u], rows = frame_off[u + 1] - a;
     if (rows <= 0) return;
+    const int R = min(((kMeanSlotFloats / nbanks) - 4) & ~15, 1024);    // frames per slot: a multiple of 16
+    const int RP = R + 4;                                               // pitch: RP / 4 odd -> 16 columns, 16 bank quads
+    const int slot_floats = nbanks * RP;
     const float *x = mel + (size_t)a * nbanks;
-    float sum = 0.0f;
-    for (int r0 = 0; r0 < rows; r0 += chunk_rows) {
-        const int n = min(chunk_rows, rows - r0) * nbanks;
-        const float *src = x + (size_t)r0 * nbanks;
-#pragma unroll 8
-        for (int i = threadIdx.x; i < n; i += 256) chunk[i] = src[i];
-        __syncthreads();
-        if ((int)threadIdx.x < nbanks) {
-            // 16 independent LDS reads in flight, then the 16 adds in frame order (the add chain is the
-            // only dependent part)
-            const int nr = n / nbanks;
-            int r = 0;
-            for (; r + 16 <= nr; r += 16) {
-                float v[16];
+    const int n_chunks = (rows + R - 1) / R;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    // loaders: thread t of 192 takes elements t, t + 192, ... of a chunk's [r][b] image; (r, b) advance without division
+    const int lt = (int)threadIdx.x - 64;
+    const int step_r = 192 / nbanks, step_b = 192 % nbanks;
+    auto load_chunk = [&](int c) {
+        if (c >= n_chunks) return;
+        const int nr = min(R, rows - c * R), n = nr * nbanks;
+        const float *src = x + (size_t)c * R * nbanks;
+        float *dst = ring + (size_t)(c % kMeanSlots) * slot_floats;
+        int r = lt / nbanks, b = lt % nbanks;
+        int i = lt;
+        for (; i + 3 * 192 < n; i += 4 * 192) {                         // four loads in flight per thread
+            float v[4]; int at[4];
 #pragma unroll
-                for (int q = 0; q < 16; q++) v[q] = chunk[(r + q) * nbanks + threadIdx.x];
-#pragma unroll
-                for (int q = 0; q < 16; q++) sum += v[q];
+            for (int k = 0; k < 4; k++) {
+                v[k] = src[i + k * 192];
+                at[k] = b * RP + r;
+                b += step_b; r += step_r;
+                if (b >= nbanks) { b -= nbanks; r++; }
             }
-            for (; r < nr; r++) sum += chunk[r * nbanks + threadIdx.x];
+#pragma unroll
+            for (int k = 0; k < 4; k++) dst[at[k]] = v[k];
+        }
+        for (; i < n; i += 192) {
+            dst[b * RP + r] = src[i];
+            b += step_b; r += step_r;
+            if (b >= nbanks) { b -= nbanks; r++; }
+        }
+    };
+    if (wave > 0)
+        for (int c = 0; c < kMeanSlots - 1; c++) load_chunk(c);
+    __syncthreads();
+
+    float sum = 0.0f;
+    for (int c = 0; c < n_chunks; c++) {
+        if (wave > 0) {
+            load_chunk(c + kMeanSlots - 1);     // into the slot the adder left at the last barrier
+        } else if (lane < nbanks) {
+            const int nr = min(R, rows - c * R);
+            const float *col = ring + (size_t)(c % kMeanSlots) * slot_floats + lane * RP;
+            const float4 *q = reinterpret_cast<const float4 *>(col);
+            int r = 0;
+            if (nr >= 16) {
+                // two register sets, no copies: while one set's 16 frames are added the other set's are on their way
+                // (the fences keep hipcc from sinking the requests behind the adds they are meant to overlap)
+                float4 ra[4], rb[4];
+                auto request = [&](float4 (&d)[4], int row) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) d[k] = q[(row >> 2) + k];
+                };
+                auto add16 = [&](const float4 (&d)[4]) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { sum += d[k].x; sum += d[k].y; sum += d[k].z; sum += d[k].w; }
+                };
+                request(ra, 0);
+                for (; r + 48 <= nr; r += 32) {
+                    request(rb, r + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add16(ra);
+                    __builtin_amdgcn_sched_barrier(0);
+                    request(ra, r + 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add16(rb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (r + 32 <= nr) {
+                    request(rb, r + 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add16(ra);
+                    add16(rb);
+                    r += 32;
+                } else {
+                    add16(ra);
+                    r += 16;
+                }
+            }
+            for (; r < nr; r++) sum += col[r];
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < nbanks) means[(size_t)u * nbanks + threadIdx.x] = sum * (1.0f / (float)rows);
+    if (wave == 0 && lane < nbanks) means[(size_t)u * nbanks + lane] = sum * (1.0f / (float)rows);
 }
 
-// The default order of the column sums: a FIXED-SHAPE TREE per utterance instead of the reference's dependent
-// chain (107 us for one 8192-frame utterance; the mean moves by ~1e-7 relative, posteriors by << 1e-4).  Rows
+// The OPT-IN order of the column sums (lcrc_set_mean_order(ctx, 0)): a FIXED-SHAPE TREE per utterance instead of the
+// reference's dependent chain (the mean moves by ~1e-7 relative, posteriors by << 1e-4; 4.6 us whatever the length).  Rows
 // are grouped in blocks of kMeanBlock rows counted from the utterance's first row; within a block, row lane q of
 // Q = 256 / B' (B' = nbanks rounded up to a power of two) adds rows q, q+Q, ... in order, the Q lane sums are
 // folded by halves (q += q + Q/2, ...), and submean_tree_kernel adds an utterance's block sums in block order.
@@ -318,7 +388,8 @@ hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_of
     if (n_utts <= 0 || n_rows <= 0) return hipSuccess;
     if (nbanks > 64) return hipErrorInvalidValue;
     if (block_off == nullptr) {                 // the reference's sequential sums (lcrc_set_mean_order)
-        const size_t lds = (size_t)(kNormLdsFloats / nbanks) * nbanks * sizeof(float);
+        const int R = std::min(((kMeanSlotFloats / nbanks) - 4) & ~15, 1024);
+        const size_t lds = (size_t)kMeanSlots * nbanks * (R + 4) * sizeof(float);
         colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
     } else {
         colmean_block_kernel<<<n_blocks, 256, 0, stream>>>(mel, frame_off, block_off, n_utts, nbanks, partial);

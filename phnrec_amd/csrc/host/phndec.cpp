@@ -13,6 +13,7 @@ namespace phnrec {
 
 namespace {
 const float kLogHalf = -0.69314718055994530941723212145818f;   // both transitions (phndec.cpp:9,14-15)
+bool UseAvx512();
 }
 
 bool PhnDec::LoadPhnList(const std::string &path)
@@ -42,6 +43,10 @@ void PhnDec::Init()
     halpha_.assign(prune_ + 1, -1.0f);
     hpos_ = 0;
     for (int i = 0; i < P; i++) alpha_[i] = wpen_;               // entry state carries the penalty
+    packed_ = S_ == 3 && UseAvx512();
+    if (packed_) pk_.assign((size_t)W * Pp_, 0);                 // (winner -1, length 0) everywhere
+    entry_a_ = wpen_;
+    entry_prev_ = -1;
     nframes_ = 0;
     prev_alpha_ = 0.0f;
     labels_.clear();
@@ -56,6 +61,13 @@ namespace {
 bool UseAvx2()
 {
     static const bool v = __builtin_cpu_supports("avx2") && !getenv("PHNREC_NO_AVX2");
+    return v;
+}
+// ... and a third time on AVX-512 (sixteen phonemes per instruction, the whole frame in one pass over the token slots):
+// PHNREC_NO_AVX512=1 keeps to AVX2, PHNREC_NO_AVX2=1 to the plain form.  Still the same IEEE operations.
+bool UseAvx512()
+{
+    static const bool v = UseAvx2() && __builtin_cpu_supports("avx512f") && !getenv("PHNREC_NO_AVX512");
     return v;
 }
 
@@ -162,10 +174,149 @@ void FillEntryAvx2(int n, float *a, int *pv, int *ln, float entry, int bi)
     }
 }
 
+// ---- AVX-512, three states per phoneme (every shipped system) --------------------------------------------------
+// One pass per group of sixteen phonemes: the group's 48 log-posteriors are loaded (masked at the end of the phoneme
+// list: never past what the list needs) and brought state-major by two permutes per state; the token slots of the
+// sixteen models are loaded once, updated last state first on the OLD values exactly as phndec.cpp:96-119 does, and
+// stored; the running maxima of the exit row and of all inner rows come out of the same pass (max is exact: any order).
+// Two things are kept differently from the other forms, to halve the loads and stores of a frame:
+//   * a token's (entry winner, length) pair travels as ONE word, (winner + 1) << 24 | length (kPackLenBits; the frame
+//     that would overflow the length field unpacks the slots and the utterance goes on in the AVX2 form);
+//   * the entry row is not stored at all: after PropagateInNetwork every phoneme's entry slot holds the same token
+//     (score best + penalty, winner bi, length 0; phndec.cpp:121-144), so it is three scalars that are broadcast.
+constexpr int kPackLenBits = 24;
+struct Frame512 {
+    __m512 exit_max, inner_max;
+};
+
+__attribute__((target("avx512f")))
+inline Frame512 UpdateFrame3Avx512(const float *f, int P, int Pp, float *alpha, int *pk, float entry, int entry_pk)
+{
+    const __m512 c = _mm512_set1_ps(kLogHalf);
+    const __m512i one = _mm512_set1_epi32(1);
+    // state s of phoneme p of the group is value 3p + s of its 48: values 0..31 come from (v0, v1), 32..47 from v2
+    const __m512i i0 = _mm512_setr_epi32(0, 3, 6, 9, 12, 15, 18, 21, 24, 27, 30, 0, 0, 0, 0, 0);
+    const __m512i i1 = _mm512_setr_epi32(1, 4, 7, 10, 13, 16, 19, 22, 25, 28, 31, 0, 0, 0, 0, 0);
+    const __m512i i2 = _mm512_setr_epi32(2, 5, 8, 11, 14, 17, 20, 23, 26, 29, 0, 0, 0, 0, 0, 0);
+    const __m512i t0 = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 4, 7, 10, 13);     // value 33.. -> v2[1..]
+    const __m512i t1 = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 5, 8, 11, 14);
+    const __m512i t2 = _mm512_setr_epi32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 6, 9, 12, 15);     // p = 10 is value 32 = v2[0]
+    Frame512 r;
+    r.exit_max = _mm512_set1_ps(-FLT_MAX);
+    r.inner_max = _mm512_set1_ps(-FLT_MAX);
+    float *a1 = alpha + Pp, *a2 = alpha + 2 * (size_t)Pp, *a3 = alpha + 3 * (size_t)Pp;
+    int *p1 = pk + Pp, *p2 = pk + 2 * (size_t)Pp, *p3 = pk + 3 * (size_t)Pp;
+    const __m512 ev = _mm512_set1_ps(entry), floor = _mm512_set1_ps(-FLT_MAX);
+    const __m512i P0 = _mm512_set1_epi32(entry_pk);
+    for (int i = 0; i < Pp; i += 16) {
+        const int nv = 3 * (P - i);                                  // values of this group that exist (>= 48: all)
+        const __mmask16 m0 = nv >= 16 ? 0xFFFF : (__mmask16)((1u << (nv > 0 ? nv : 0)) - 1);
+        const __mmask16 m1 = nv >= 32 ? 0xFFFF : (__mmask16)((1u << (nv > 16 ? nv - 16 : 0)) - 1);
+        const __mmask16 m2 = nv >= 48 ? 0xFFFF : (__mmask16)((1u << (nv > 32 ? nv - 32 : 0)) - 1);
+        const __m512 v0 = _mm512_maskz_loadu_ps(m0, f + 3 * i), v1 = _mm512_maskz_loadu_ps(m1, f + 3 * i + 16),
+                     v2 = _mm512_maskz_loadu_ps(m2, f + 3 * i + 32);
+        // state 0: p = 0..10 at 3p <= 30 in (v0, v1); p = 11..15 at 33..45 = v2[1, 4, 7, 10, 13]
+        const __m512 o0 = _mm512_mask_permutexvar_ps(_mm512_permutex2var_ps(v0, i0, v1), 0xF800, t0, v2);
+        // state 1: p = 0..10 at 3p + 1 <= 31; p = 11..15 at 34..46 = v2[2, 5, 8, 11, 14]
+        const __m512 o1 = _mm512_mask_permutexvar_ps(_mm512_permutex2var_ps(v0, i1, v1), 0xF800, t1, v2);
+        // state 2: p = 0..9 at 3p + 2 <= 29; p = 10 at 32 = v2[0]; p = 11..15 at 35..47 = v2[3, 6, 9, 12, 15]
+        const __m512 o2 = _mm512_mask_permutexvar_ps(_mm512_permutex2var_ps(v0, i2, v1), 0xFC00, t2, v2);
+
+        const int np = P - i;                                        // phonemes of this group that exist
+        const __mmask16 mp = np >= 16 ? 0xFFFF : (__mmask16)((1u << (np > 0 ? np : 0)) - 1);
+        const __m512 A0 = _mm512_mask_blend_ps(mp, floor, ev);       // pad slots keep -FLT_MAX (they never win)
+        const __m512 A1 = _mm512_loadu_ps(a1 + i), A2 = _mm512_loadu_ps(a2 + i), A3 = _mm512_loadu_ps(a3 + i);
+        const __m512 e0 = _mm512_add_ps(A0, c), e1 = _mm512_add_ps(A1, c), e2 = _mm512_add_ps(A2, c), e3 = _mm512_add_ps(A3, c);
+        // state 3: stays (e3) or takes state 2's token (e2); state 2: e2 vs e1; state 1: e1 vs e0 -- all on old values
+        const __mmask16 k3 = _mm512_cmp_ps_mask(e3, e2, _CMP_GT_OQ), k2 = _mm512_cmp_ps_mask(e2, e1, _CMP_GT_OQ),
+                        k1 = _mm512_cmp_ps_mask(e1, e0, _CMP_GT_OQ);
+        const __m512 n3 = _mm512_add_ps(_mm512_mask_blend_ps(k3, e2, e3), o2);
+        const __m512 n2 = _mm512_add_ps(_mm512_mask_blend_ps(k2, e1, e2), o1);
+        const __m512 n1 = _mm512_add_ps(_mm512_mask_blend_ps(k1, e0, e1), o0);
+        _mm512_storeu_ps(a3 + i, n3);
+        _mm512_storeu_ps(a2 + i, n2);
+        _mm512_storeu_ps(a1 + i, n1);
+        const __m512i P1 = _mm512_loadu_si512(p1 + i), P2 = _mm512_loadu_si512(p2 + i), P3 = _mm512_loadu_si512(p3 + i);
+        _mm512_storeu_si512(p3 + i, _mm512_add_epi32(_mm512_mask_blend_epi32(k3, P2, P3), one));      // length + 1
+        _mm512_storeu_si512(p2 + i, _mm512_add_epi32(_mm512_mask_blend_epi32(k2, P1, P2), one));
+        _mm512_storeu_si512(p1 + i, _mm512_add_epi32(_mm512_mask_blend_epi32(k1, P0, P1), one));
+        r.exit_max = _mm512_max_ps(r.exit_max, n3);
+        r.inner_max = _mm512_max_ps(r.inner_max, _mm512_max_ps(n3, _mm512_max_ps(n2, n1)));
+    }
+    return r;
+}
+
+__attribute__((target("avx512f")))
+inline int FirstEqualAvx512(const float *a, int n, float v)
+{
+    const __m512 vv = _mm512_set1_ps(v);
+    for (int i = 0; i < n; i += 16) {
+        const unsigned mask = _mm512_cmp_ps_mask(_mm512_loadu_ps(a + i), vv, _CMP_EQ_OQ);
+        if (mask) return i + __builtin_ctz(mask);
+    }
+    return n;
+}
+
+__attribute__((target("avx512f")))
+inline float HMax512(__m512 v) { return _mm512_reduce_max_ps(v); }
+
 }  // namespace
+
+// packed form <-> the (prev_, len_) arrays of the other forms
+void PhnDec::Unpack()
+{
+    const int P = (int)phn_.size(), Pp = Pp_, W = S_ + 1;
+    for (int j = 1; j < W; j++)
+        for (int i = 0; i < Pp; i++) {
+            const int w = pk_[(size_t)j * Pp + i];
+            prev_[(size_t)j * Pp + i] = (w >> kPackLenBits) - 1;
+            len_[(size_t)j * Pp + i] = w & ((1 << kPackLenBits) - 1);
+        }
+    for (int i = 0; i < P; i++) { alpha_[i] = entry_a_; prev_[i] = entry_prev_; len_[i] = 0; }
+    packed_ = false;
+}
+
+// the whole frame on AVX-512 (S == 3): the same steps as ProcessFrame below
+__attribute__((target("avx512f")))
+void PhnDec::ProcessFrame512(const float *f)
+{
+    const int P = (int)phn_.size(), Pp = Pp_;
+    const Frame512 fm = UpdateFrame3Avx512(f, P, Pp, alpha_.data(), pk_.data(), entry_a_, (entry_prev_ + 1) << kPackLenBits);
+    const float *exitv = &alpha_[(size_t)3 * Pp];
+    float best = -FLT_MAX;
+    int bi = 0;
+    const float m = HMax512(fm.exit_max);
+    if (m > best) { best = m; bi = FirstEqualAvx512(exitv, Pp, m); }
+    const int cols = (int)hphn_.size();
+    const int slot = hpos_;
+    hpos_ = hpos_ + 1 == cols ? 0 : hpos_ + 1;
+    const int w = pk_[(size_t)3 * Pp + bi];
+    hphn_[slot] = (w >> kPackLenBits) - 1;
+    hlen_[slot] = w & ((1 << kPackLenBits) - 1);
+    halpha_[slot] = best;
+    entry_a_ = best + wpen_;
+    entry_prev_ = bi;
+    nframes_++;
+    if (nframes_ < cols) return;
+    // TimePruning's best inner token (phndec.cpp:191-205): smallest phoneme index among equals, then smallest state
+    int ti = -1, tj = 0;
+    const float im = HMax512(fm.inner_max);
+    if (im > -FLT_MAX) {
+        ti = Pp;
+        for (int j = 1; j <= 3; j++) {
+            const int i = FirstEqualAvx512(&alpha_[(size_t)j * Pp], Pp, im);
+            if (i < ti) { ti = i; tj = j; }
+        }
+    }
+    PruneFrom(ti, tj);
+}
 
 void PhnDec::ProcessFrame(const float *f)
 {
+    if (packed_) {
+        if (nframes_ < (1 << kPackLenBits) - 2) { ProcessFrame512(f); return; }
+        Unpack();                            // an utterance of 2^24 frames: the length field is full, go on unpacked
+    }
     const int P = (int)phn_.size(), Pp = Pp_;
     const bool avx2 = UseAvx2();
     // this frame's observations state-major
@@ -239,8 +390,19 @@ void PhnDec::TimePruning()
                 if (a[i] > best || (a[i] == best && i < bi)) { best = a[i]; bi = i; bj = j; }
         }
     }
+    PruneFrom(bi, bj);
+}
+
+// the walk from the best inner token (state bj of phoneme bi; bi < 0: none beat -FLT_MAX) back to the horizon
+void PhnDec::PruneFrom(int bi, int bj)
+{
+    const int cols = (int)hlen_.size(), Pp = Pp_;
     int blen = 1, bprev = 0;
-    if (bi >= 0) {
+    if (bi >= 0 && packed_) {
+        const int w = pk_[(size_t)bj * Pp + bi];
+        blen = w & ((1 << kPackLenBits) - 1);
+        bprev = (w >> kPackLenBits) - 1;
+    } else if (bi >= 0) {
         blen = len_[(size_t)bj * Pp + bi];
         bprev = prev_[(size_t)bj * Pp + bi];
     }
@@ -265,7 +427,7 @@ void PhnDec::Done()
     const int cols = (int)hlen_.size();
     auto col = [&](int c) { const int k = hpos_ + c; return k >= cols ? k - cols : k; };
     int offs = cols - 1, end = nframes_;
-    int phn = prev_[0];                    // the winner that entered the loop last
+    int phn = packed_ ? entry_prev_ : prev_[0];     // the winner that entered the loop last
     std::vector<Label> tail;
     while (offs > 0 && phn != -1) {
         const int k = col(offs);

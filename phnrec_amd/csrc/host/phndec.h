@@ -6,10 +6,35 @@
 #ifndef PHNREC_HOST_PHNDEC_H
 #define PHNREC_HOST_PHNDEC_H
 
+#include <cstdint>
 #include <string>
 #include <vector>
 
 namespace phnrec {
+
+// std::vector-like array of PODs whose data() is 64-byte aligned: the vector forms of the decoder move whole cache
+// lines, and a line-crossing 64-byte access costs two
+template <typename T>
+class AlignedArray {
+public:
+    void assign(size_t n, T v)
+    {
+        store_.assign(n + 64 / sizeof(T), v);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(store_.data());
+        p_ = reinterpret_cast<T *>((a + 63) & ~uintptr_t(63));
+        n_ = n;
+    }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t size() const { return n_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+
+private:
+    std::vector<T> store_;
+    T *p_ = nullptr;
+    size_t n_ = 0;
+};
 
 struct Label {
     int start, end;          // frames
@@ -33,6 +58,14 @@ public:
 
 private:
     void TimePruning();
+    void PruneFrom(int bi, int bj);
+    void ProcessFrame512(const float *logpost);
+    void Unpack();
+    // AVX-512 form (phndec.cpp): (entry winner + 1) << 24 | length per token slot, the uniform entry row as scalars
+    bool packed_ = false;
+    AlignedArray<int> pk_;          // [S+1][Pp]
+    float entry_a_ = 0.0f;
+    int entry_prev_ = -1;
     std::vector<std::string> phn_;
     int S_ = 1, prune_ = 50, nframes_ = 0;
     float wpen_ = 0.0f, prev_alpha_ = 0.0f;
@@ -41,9 +74,9 @@ private:
     // vectorises), with the same f32 additions and the same tie rules as the reference's phoneme-major loops.
     // Pad slots hold -FLT_MAX and never win a strict comparison.
     int Pp_ = 0;
-    std::vector<float> alpha_;      // [S+1][Pp]
-    std::vector<int> prev_, len_;   // [S+1][Pp]
-    std::vector<float> obs_;        // [S][Pp] this frame's log-posteriors, state-major
+    AlignedArray<float> alpha_;     // [S+1][Pp]
+    AlignedArray<int> prev_, len_;  // [S+1][Pp]
+    AlignedArray<float> obs_;       // [S][Pp] this frame's log-posteriors, state-major
     // history of the network-level winners of the last prune+1 frames: a ring, slot of column c = (hpos_ + c) % cols
     std::vector<int> hphn_, hlen_;
     std::vector<float> halpha_;

@@ -180,8 +180,11 @@ int main(int argc, char **argv)
     // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.
     // (tools that live on exit handlers -- rocprofv3 and other preloaded profilers -- get the ordinary exit)
     SR.JoinWarmUp();
-    fflush(stdout);
-    fflush(stderr);
+    fflush(NULL);                            // every open output stream, not only stdout / stderr
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__) || defined(PHNREC_COVERAGE)
+    return 0;                                // sanitizer / coverage builds report from exit handlers
+#else
     if (getenv("LD_PRELOAD") || getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("PHNREC_CLEAN_EXIT")) return 0;
     _Exit(0);
+#endif
 }

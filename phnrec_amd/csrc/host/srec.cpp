@@ -1,10 +1,13 @@
 // srec.cpp -- see srec.h
 #include "srec.h"
 
+#include <fcntl.h>
 #include <sched.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -607,6 +610,23 @@ bool SpeechRec::ParseLine(const std::string &line, DataFormat out, bool mlf, Job
 // line stops the run THERE -- everything before it is computed and written, then the error is reported.
 namespace {
 
+// A whole file into `dst` (exactly `bytes` of it): one open, reads until done, close -- no stdio buffer in between
+// (a FILE's 4 KiB buffer would copy every byte twice; the files go straight into pinned memory)
+bool ReadWholeFile(const char *path, unsigned char *dst, long long bytes)
+{
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    long long got = 0;
+    while (got < bytes) {
+        const ssize_t r = read(fd, dst + got, (size_t)(bytes - got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+        got += r;
+    }
+    close(fd);
+    return got == bytes;
+}
+
 struct Slot {
     int state = 0;          // 0: stage 1 pending, 1: staged (waits for a launch), 2: in a launch, 3: done
 };
@@ -656,7 +676,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     const auto t1 = clock::now();
     stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
 
-    struct Item { Job job; Slot slot; };
+    struct Item { Job job; Slot slot; long long seq = 0; };
     std::mutex mu;
     std::condition_variable cv_feed, cv_work, cv_idle;
     std::deque<std::unique_ptr<Item>> win;     // jobs in flight, list order; win.front() has sequence number `base`
@@ -794,7 +814,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             return true;
         };
         while (take_launch(items)) {
-            const int cnt = (int)items.size();
+            int cnt = (int)items.size();
             off.assign(1, 0);
             for (int k = 0; k < cnt; k++) off.push_back(off.back() + items[k]->job.frames);
             const auto l0 = clock::now();
@@ -812,15 +832,35 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                 }
                 unsigned char *pinned = nullptr;
                 if (!tr.WaveStageBuffer(pos, &pinned)) { abort_run(tr.LastError()); return; }
-                std::atomic<int> bad(-1);
+                std::atomic<int> bad(cnt);     // lowest index whose read failed
                 pool_->ParallelFor(cnt, [&](int k) {
                     CpuTimer tm(read_us);
-                    FILE *f = fopen(items[k]->job.src.c_str(), "rb");
-                    const bool ok = f && (blen[k] == 0 || fread(pinned + bstart[k], 1, (size_t)blen[k], f) == (size_t)blen[k]);
-                    if (f) fclose(f);
-                    if (!ok) { int e = -1; bad.compare_exchange_strong(e, k); }
+                    if (!ReadWholeFile(items[k]->job.src.c_str(), pinned + bstart[k], blen[k])) {
+                        int e = bad.load();
+                        while (k < e && !bad.compare_exchange_weak(e, k)) {}
+                    }
                 });
-                if (bad >= 0) { abort_run("Can not open waveform file: " + items[bad]->job.src); return; }
+                if (bad < cnt) {
+                    // The file was there for stage 1's stat() and cannot be read now.  Same meaning as a stage-1
+                    // failure (srec.cpp:1246-1290 works file by file): the list stops AT this file -- the jobs in
+                    // front of it, in this launch and in the others' launches, are computed and written, then the
+                    // error is reported; nothing behind it is written.
+                    const int b = bad;
+                    {
+                        std::lock_guard<std::mutex> l(mu);
+                        Job &j = items[b]->job;
+                        j.ok = false;
+                        j.err = "Can not open waveform file: " + j.src + "\n";
+                        if (stop_seq < 0 || items[b]->seq < stop_seq) stop_seq = items[b]->seq;
+                        for (int k = b; k < cnt; k++) items[k]->slot.state = 3;
+                        cv_work.notify_all(); cv_feed.notify_all();
+                        if (b == 0) drain();
+                    }
+                    if (b == 0) continue;
+                    items.resize((size_t)b);
+                    cnt = b;
+                    off.resize((size_t)b + 1);
+                }
                 foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
                 if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
                 h_post = tr.StagedPosteriors();
@@ -887,6 +927,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         Item *raw = it.get();
         {
             std::lock_guard<std::mutex> l(mu);
+            raw->seq = base + (long long)win.size();
             win.push_back(std::move(it));
             pending1++;
         }

@@ -271,13 +271,15 @@ int ensure_split_f16(lcrc_ctx *c)
     SharedModel &m = *c->model;
     std::lock_guard<std::mutex> l(m.mu);
     if (m.h2_state == 0) {
-        m.h2_state = -1;
+        // -1 (no such form, for good) only when a net is not representable; a device error (allocation, upload) leaves
+        // the state at 0 so that a later call retries -- the images uploaded so far stay in the model's allocation list
+        // (freed with the model) and are simply re-made
         bool ok = true;
         for (int i = 0; i < 3 && ok; i++) {
             int rc = pack_net_h2(c, m.host[i], c->nets[i], m.h2[i], &ok);
             if (rc) return rc;
         }
-        if (ok) m.h2_state = 1;
+        m.h2_state = ok ? 1 : -1;
     }
     if (m.h2_state != 1) return LCRC_E_UNSUPPORTED;
     for (int i = 0; i < 3; i++) {
@@ -396,12 +398,19 @@ hipError_t dev_alloc(void **p, size_t bytes)
     *p = nullptr;
     return inject_alloc_failure() ? hipErrorOutOfMemory : hipMalloc(p, bytes);
 }
+// Every pinned allocation is PORTABLE: a process that drives several GPUs (phnrec -g N: contexts on devices 0..N-1 in
+// one address space) must be able to hand any of them to any device's copy engine, and a mapped buffer is read in
+// place by the kernels of the context's OWN device, whose pointer is taken under that device (hipSetDevice precedes
+// every hipHostGetDevicePointer here).  Without the flag the registration belongs to the device that was current at
+// allocation time only -- invisible on a one-GPU box.
+constexpr unsigned kPinned = hipHostMallocPortable;
+constexpr unsigned kPinnedMapped = hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent;
 // device_reads: a buffer that kernels read in place (mapped into the device, coherent: never cached on the device side)
 hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false)
 {
     *p = nullptr;
     if (inject_alloc_failure()) return hipErrorOutOfMemory;
-    return hipHostMalloc(p, bytes, device_reads ? hipHostMallocMapped | hipHostMallocCoherent : hipHostMallocDefault);
+    return hipHostMalloc(p, bytes, device_reads ? kPinnedMapped : kPinned);
 }
 
 void free_frame_staging(lcrc_ctx *c)
@@ -676,7 +685,7 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
         c->d_labels = c->h_labels = nullptr;
         c->cap_label_rows = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_labels, cap * sizeof(lcrc_label)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), kPinned));
         c->cap_label_rows = cap;
     }
     if ((size_t)n_utts > c->cap_label_utts) {
@@ -685,7 +694,7 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
         c->d_count = c->h_count = nullptr;
         c->cap_label_utts = 0;
         HIP_TRY(c, hipMalloc((void **)&c->d_count, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), kPinned));
         c->cap_label_utts = cap;
     }
     PhnDecParams p;
@@ -1354,7 +1363,7 @@ static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
         c->d_bytes = c->h_bytes = nullptr; c->cap_bytes = 0;
         const size_t cap = (size_t)total_bytes + total_bytes / 4 + 4096;
         HIP_TRY(c, hipMalloc((void **)&c->d_bytes, cap));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, kPinned));
         c->cap_bytes = cap;
     }
     return LCRC_OK;
@@ -1373,9 +1382,9 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
         c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
         const size_t cap = 2 * (size_t)n_utts + n_utts / 2 + 64;
         HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), kPinned));
         HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), kPinned));
         HIP_TRY(c, hipMalloc((void **)&c->d_means, cap * 64 * sizeof(float)));
         c->cap_fe_utts = cap;
     }
@@ -1597,7 +1606,7 @@ static int ensure_ring(lcrc_ctx *c, size_t n)
         if (H + n + n / 2 + 256 > c->ring_cap) {            // grow (keeps the history)
             const size_t cap = std::max<size_t>(4096, 2 * (H + n) + 256);
             float *h = nullptr, *d = nullptr;
-            HIP_TRY(c, hipHostMalloc((void **)&h, cap * nb * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(c, hipHostMalloc((void **)&h, cap * nb * sizeof(float), kPinnedMapped));
             if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed"); }
             if (c->h_ring) {
                 const size_t keep = std::min(c->ring_rows, H);
@@ -1616,7 +1625,7 @@ static int ensure_ring(lcrc_ctx *c, size_t n)
         const size_t cap = n + n / 4 + 64;
         if (c->h_pushout) (void)hipHostFree(c->h_pushout);
         c->h_pushout = c->d_pushout = nullptr; c->pushout_cap = 0;
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_pushout, cap * O * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_pushout, cap * O * sizeof(float), kPinnedMapped));
         if (hipHostGetDevicePointer((void **)&c->d_pushout, c->h_pushout, 0) != hipSuccess) return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed");
         c->pushout_cap = cap;
     }

@@ -194,7 +194,12 @@ def shard_by_frames(lengths, world):
 
 def timed_steps(ranks, step, sync, steps, warmup, device=None):
     """The bench contract: W untimed steps, then EXACTLY K steps bracketed by a barrier
-    and a device synchronise on both sides; the elapsed time is the MAX over ranks."""
+    and a device synchronise on both sides; the elapsed time is the MAX over ranks.
+
+    Each rank's clock stops at its OWN device synchronise behind step K; the closing barrier follows (it still
+    brackets the region: nobody reports before everybody is done) and the MAX over ranks of those local times is the
+    job's time.  With the barrier inside the clock, an N > 1 run paid one RCCL collective (30-100 us) per timed region
+    that the N = 1 run (no process group) never pays -- 1-3 % of a 20 x 0.2 ms region charged to "scaling"."""
     import time
     for _ in range(warmup):
         step()
@@ -205,7 +210,7 @@ def timed_steps(ranks, step, sync, steps, warmup, device=None):
     for _ in range(steps):
         step()
     sync()
+    dt = time.perf_counter() - t0
     ranks.barrier()
     sync()
-    dt = time.perf_counter() - t0
     return ranks.max_float(dt, device=device)

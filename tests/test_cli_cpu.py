@@ -255,9 +255,66 @@ def test_long_list_leaves_in_list_order(tmp_path, threads, batch):
     assert mlf.read_text() == "#!MLF!#\n" + "".join(entries[n] for n in order)
 
 
-@pytest.mark.parametrize("P,S,prune", [(5, 1, 40), (17, 2, 12), (40, 3, 40), (62, 3, 40), (33, 4, 25), (64, 3, 7), (8, 3, 40)])
+def test_host_pipeline_under_thread_sanitizer(tmp_path):
+    """`make tsan` (csrc/Makefile): the host code with -fsanitize=thread.  The CPU-only list modes -- `-t par -l` (read
+    + front-end on the pool, dumps written by the host workers) and `-s post -l -m` (decode + in-order MLF writer) -- run
+    through the same RunPipeline as the GPU modes with 8 pool threads: zero ThreadSanitizer reports, MLF in list order,
+    every dump bit-identical to the plain build's."""
+    csrc = os.path.join(ROOT, "phnrec_amd", "csrc")
+    b = subprocess.run(["make", "-s", "-C", csrc, "tsan"], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    tsan = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec_tsan")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_thread_leaks=0")
+
+    def run_tsan(*args):
+        p = subprocess.run([tsan] + [str(a) for a in args], capture_output=True, text=True, env=env)
+        assert "ThreadSanitizer" not in p.stderr and p.returncode == 0, p.stderr[-3000:]
+
+    # -t par over 60 waveform files of varying length
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    rng = np.random.default_rng(11)
+    wav = tmp_path / "wav"
+    wav.mkdir()
+    lines = []
+    for i in range(60):
+        n = int(rng.integers(400, len(raw) // 2)) * 2
+        (wav / ("w%02d.raw" % i)).write_bytes(raw[:n])
+        lines.append("%s %s\n" % (wav / ("w%02d.raw" % i), wav / ("w%02d.tsan.mel" % i)))
+    lst = tmp_path / "par.txt"
+    lst.write_text("".join(lines))
+    run_tsan("-c", model_dir(CZ), "-t", "par", "-l", lst, "-j", 8, "-b", 700)
+    lst2 = tmp_path / "par2.txt"
+    lst2.write_text("".join(l.replace(".tsan.mel", ".mel") for l in lines))
+    run("-c", model_dir(CZ), "-t", "par", "-l", lst2, "-j", 8)
+    for i in range(60):
+        assert (wav / ("w%02d.tsan.mel" % i)).read_bytes() == (wav / ("w%02d.mel" % i)).read_bytes()
+
+    # -s post -m over 40 posterior dumps, in list order
+    gold = open(os.path.join(GOLD, "cli", "list.mlf")).read()
+    entries = {}
+    for n in ("utt_a", "utt_b", "utt_c"):
+        i = gold.index('"*/%s.rec"' % n)
+        entries[n] = gold[i:gold.index("\n.\n", i) + 3]
+    order = [("utt_a", "utt_b", "utt_c")[int(k)] for k in rng.integers(0, 3, 40)]
+    lines = []
+    for i, n in enumerate(order):
+        sub = tmp_path / ("p%02d" % i)
+        sub.mkdir()
+        shutil.copyfile(os.path.join(GOLD, "cli", n + ".lop"), sub / (n + ".lop"))
+        lines.append("%s\n" % (sub / (n + ".lop")))
+    lst3 = tmp_path / "post.txt"
+    lst3.write_text("".join(lines))
+    mlf = tmp_path / "tsan.mlf"
+    run_tsan("-c", model_dir(CZ), "-s", "post", "-l", lst3, "-m", mlf, "-j", 8, "-b", 900)
+    assert mlf.read_text() == "#!MLF!#\n" + "".join(entries[n] for n in order)
+
+
+@pytest.mark.parametrize("P,S,prune", [(5, 1, 40), (17, 2, 12), (40, 3, 40), (62, 3, 40), (33, 4, 25), (64, 3, 7), (8, 3, 40),
+                                       (16, 3, 40), (47, 3, 3), (61, 3, 40)])
 def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, S, prune):
-    """The host Viterbi runs state-major, eight phonemes at a time on AVX2 (and as plain C++ with PHNREC_NO_AVX2=1): both
+    """The host Viterbi runs state-major: sixteen phonemes at a time on AVX-512 where the CPU has it (three states per
+    phoneme: the whole frame in one pass, packed tokens, the entry row as scalars), eight on AVX2 (PHNREC_NO_AVX512=1),
+    as plain C++ with PHNREC_NO_AVX2=1: all
     must write exactly what the decoder oracle (the restatement of phndec.cpp:96-303 that reproduces the reference's
     .rec files) gives -- on posteriors drawn from FOUR values, so that ties between tokens (first strict maximum,
     phoneme-major order) occur all the time -- for phoneme counts around the vector width, 1-4 states, short horizons"""
@@ -286,7 +343,7 @@ def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, 
         write_htk(str(lop), post)
         want = ob.phndec(np.log(post), P, S, prune, wpen)
         text = "".join("%d00000 %d00000 q%d %f\n" % (a, b, p, s) for a, b, p, s in want)
-        for env in ({}, {"PHNREC_NO_AVX2": "1"}):
+        for env in ({}, {"PHNREC_NO_AVX512": "1"}, {"PHNREC_NO_AVX2": "1"}):
             rec = tmp_path / "o.rec"
             p = subprocess.run([BIN, "-c", str(d), "-s", "post", "-i", str(lop), "-o", str(rec)], capture_output=True,
                                text=True, env=dict(os.environ, **env))

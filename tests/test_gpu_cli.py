@@ -413,6 +413,29 @@ def test_unreadable_file_in_a_gpu_list_stops_there(tmp_path):
         assert heads == ['"*/f%03d.rec"' % i for i in range(25)], (g, heads[-3:])
 
 
+def test_file_that_turns_unreadable_behind_the_stat_stops_the_list_there(tmp_path):
+    """-F: stage 1 only stat()s a file; it is read later, straight into a context's pinned buffer.  A file that can be
+    stat()ed but not read (mode 000; skipped when the tests run as root, who may read anything) must stop the list AT
+    that file like any other unreadable one: every entry before it is written -- also those of launches other contexts
+    were still computing -- none behind it (srec.cpp:1246-1290)."""
+    if os.geteuid() == 0:
+        pytest.skip("root reads files of mode 000")
+    lst = _make_list(tmp_path, "cz", 40, seed=8)
+    names = lst.read_text().split()
+    os.chmod(names[25], 0)
+    try:
+        for g, flags in ((1, ("-F",)), (4, ("-F",)), (2, ("-F", "-D"))):
+            mlf = tmp_path / ("g%d%s.mlf" % (g, "d" if "-D" in flags else ""))
+            e = dict(os.environ, PHNREC_DEVICE_MAP=",".join(["0"] * g))
+            p = subprocess.run([BIN, "-c", model_dir(CZ), "-l", str(lst), "-m", str(mlf), "-g", str(g), "-b", "400"]
+                               + list(flags), capture_output=True, text=True, env=e)
+            assert p.returncode == 1 and "Can not open waveform file: %s" % names[25] in p.stderr, p.stderr
+            heads = [l for l in mlf.read_text().splitlines() if l.startswith('"')]
+            assert heads == ['"*/f%03d.rec"' % i for i in range(25)], (g, flags, heads[-3:])
+    finally:
+        os.chmod(names[25], 0o644)
+
+
 def test_configs3_list_at_scale(tmp_path):
     """BASELINE configs[3] at its stated size on the one GPU of this box: the shipped HU weights, 10 000 files of
     3-15 s (slices of one synthetic 8 kHz signal, ~9 M frames), host Viterbi, one MLF -- once with `-g 1`, once as
