@@ -231,7 +231,10 @@ def small_launch_legs(capi, modelgen, dev, stream):
     import ctypes as C
     import torch
     out = {}
-    for system in ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500"):
+    # sizes per system: CZ and EN in the small-launch regime (EN 4096 = configs[1]); HU (configs[3]'s system), RU and EN
+    # also at the headline's 8192 frames, so that every shipped system's roofline fraction is in the driver-run line
+    sizes = {"cz": (2048, 4096), "en": (2048, 4096, 8192), "hu": (8192,), "ru": (8192,)}
+    for system in ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500", "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"):
         mdir = os.path.join(ROOT, "tests", "golden", "models", system)
         if not os.path.isdir(mdir):
             continue
@@ -240,16 +243,18 @@ def small_launch_legs(capi, modelgen, dev, stream):
         ctx = capi.Lcrc(mdir, nb, device=dev.index)
         ctx.set_timing(False)
         fpf = algorithmic_flops_per_frame([ctx.net_dims(i) for i in range(3)])
-        d_mel = torch.from_numpy(modelgen.synth_mel(4096, nb, seed=7, mean_norm=spec["sent_mean_norm"])).to(dev)
-        d_post = torch.empty((4096, ctx.n_out), dtype=torch.float32, device=dev)
         tag = system.split("_")[1].lower()
-        for n in (2048, 4096):
+        n_max = max(sizes[tag])
+        d_mel = torch.from_numpy(modelgen.synth_mel(n_max, nb, seed=7, mean_norm=spec["sent_mean_norm"])).to(dev)
+        d_post = torch.empty((n_max, ctx.n_out), dtype=torch.float32, device=dev)
+        for n in sizes[tag]:
             # its own disclosed pre-heat: the legs before this one leave the device idle between calls, and 30 launches
             # of 0.05-0.1 ms do not bring the clock back up (it takes ~25 ms of load, see --preheat)
             time_launches(ctx, stream, d_mel, d_post, n, SMALL_PREHEAT)
             ms = time_launches(ctx, stream, d_mel, d_post, n, 200)
             out["%s_%d" % (tag, n)] = {"kernel_ms": round(ms, 4), "frames_per_s": round(n / ms * 1e3, 1),
                                        "frac": round(n * fpf / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       "flops_per_frame": fpf, "kernel": ctx.kernel_name,
                                        "preheat_launches": SMALL_PREHEAT}
         if tag == "cz":
             # streaming: raw ctypes calls on preallocated buffers (what a C caller pays), wall clock
@@ -389,7 +394,7 @@ def run_cli(exe, args, env, timeout=600):
             "setup_s": float(kv["setup_s"]), "create_s": float(kv.get("create_s", 0)),
             "first_launch_s": float(kv.get("first_launch_s", 0)), "main_s": float(kv.get("main_s", 0)),
             "host_cpu_s": float(kv.get("host_cpu_s", 0)), "host_threads": int(kv.get("host_threads", 0)),
-            "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write") if k in kv}}, pr
+            "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write", "viterbi") if k in kv}}, pr
 
 
 def single_file_leg(mdir, gpu):
@@ -483,6 +488,18 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                 out[key] = {"error": repr(e)}
         if isinstance(out.get("gpu_frontend_F"), dict) and "value" in out["gpu_frontend_F"]:
             out["frames_per_s"] = out["gpu_frontend_F"]["value"]
+        # the headline's system (CZ) through the same list and modes (round 3's cli_e2e leg timed a 0.06-0.1 s loop of
+        # 2000 files: inside the start-up ramp this list exists to amortise)
+        cz_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_CZ_SPDAT_LCRC_N1500")
+        if os.path.isdir(cz_dir):
+            cz = {}
+            for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"])):
+                try:
+                    r, _pr = run_cli(exe, ["-c", cz_dir, "-l", lst, "-m", os.path.join(td, "cz.mlf"), "-g", str(n_gpus)] + extra, env)
+                    cz[key] = r
+                except Exception as e:
+                    cz[key] = {"error": repr(e)}
+            out["cz_same_list"] = cz
         try:
             a, b = open(mlfs["gpu_frontend_F"]).read(), open(mlfs["gpu_frontend_decoder_F_D"]).read()
             out["mlf_F_equals_F_D"] = a == b
@@ -527,54 +544,6 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         except Exception as e:
             ceil["decoder_only_error"] = repr(e)
         out["host_ceiling"] = ceil
-    return out
-
-
-def cli_e2e_leg(mdir, n_files, gpu):
-    """The drop-in CLI end to end on a bounded synthetic list: raw 8 kHz lin16 files of 3-15 s -> MLF on disk
-    (file reads, front-end, posteriors, host Viterbi, output), host front-end and GPU front-end (-F)."""
-    import subprocess
-    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
-    if not os.path.exists(exe):
-        return {"error": "phnrec_amd/bin/phnrec is not built"}
-    rng = np.random.default_rng(1236)
-    n_base = 16 * 8000
-    t = np.arange(n_base) / 8000.0
-    base = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, n_base)
-    base = np.clip(base, -32768, 32767).astype("<i2")
-    out = {"files": n_files, "cores_usable": usable_cpus(),
-           "what": "phnrec -c PHN_CZ -l list -m out.mlf: raw lin16 8 kHz files of 3-15 s (slices of one synthetic "
-                   "signal) -> MLF; wall clock of the list loop as the CLI reports it (PHNREC_STATS), process start-up "
-                   "and model load excluded"}
-    with tempfile.TemporaryDirectory(dir="/tmp") as td:
-        names, frames = [], 0
-        for i in range(n_files):
-            n = int(rng.uniform(3.0, 15.0) * 8000)
-            o = int(rng.integers(0, n_base - n))
-            p = os.path.join(td, "f%05d.raw" % i)
-            base[o:o + n].tofile(p)
-            names.append(p)
-            frames += (n - 200) // 80 + 1
-        lst = os.path.join(td, "list.scp")
-        with open(lst, "w") as f:
-            f.write("".join(n + "\n" for n in names))
-        out["frames"] = frames
-        env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=str(gpu))
-        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"]), ("gpu_frontend_F_split_f16_H", ["-F", "-H"])):
-            try:
-                t0 = time.perf_counter()
-                pr = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "out.mlf")] + extra, env=env,
-                                    capture_output=True, text=True, timeout=300)
-                wall = time.perf_counter() - t0
-                stats = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")]
-                if pr.returncode != 0 or not stats:
-                    out[key] = {"error": "rc=%d %s" % (pr.returncode, pr.stderr.strip()[-200:])}
-                    continue
-                kv = dict(tok.split("=", 1) for tok in stats[-1].replace("(", "").replace(")", "").split() if "=" in tok)
-                out[key] = {"value": float(kv["frames_per_s"]), "unit": "frames/s", "list_wall_s": float(kv["wall_s"]),
-                            "process_wall_s": round(wall, 3), "xrt": float(kv["xRT"])}
-            except Exception as e:
-                out[key] = {"error": repr(e)}
     return out
 
 
@@ -657,7 +626,6 @@ def main():
     # The line states it ("preheat_launches") and also carries the cold figure of the first launches
     # ("roofline.cold"), so a short --warmup neither hides nor includes the ramp silently.  0 switches it off.
     ap.add_argument("--preheat", type=int, default=300)
-    ap.add_argument("--cli-files", type=int, default=2000, help="files of the cli_e2e leg (0 = skip)")
     ap.add_argument("--list-files", type=int, default=10000,
                     help="files of the sharded_list leg (BASELINE configs[3]: 10 000; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-launch / push / wave / CLI legs")
@@ -854,7 +822,6 @@ def main():
                                           "4096 frames, posterior-only): lcrc_wave_to_posteriors(), host bytes in, host posteriors out "
                                           "(reused buffers), synchronous") if os.path.isdir(en_dir) else None),
                                  ("single_file", lambda: single_file_leg(mdir, gpu)),
-                                 ("cli_e2e", lambda: cli_e2e_leg(mdir, args.cli_files, gpu) if args.cli_files > 0 else None),
                                  ("dropin_reference_cli", lambda: reference_cli_leg(mdir, gpu))):
                     try:
                         val = leg()
@@ -866,6 +833,13 @@ def main():
                     for k in ("push_bunch5", "push_bunch512"):
                         if k in line["small_launches"]:
                             line[k] = line["small_launches"].pop(k)
+                    # the other shipped systems at the headline's launch size: same measurement, their own leg
+                    sys_keys = [k for k in line["small_launches"] if k.endswith("_%d" % BATCH)]
+                    if sys_keys:
+                        line["systems"] = {k: line["small_launches"].pop(k) for k in sys_keys}
+                        line["systems"]["what"] = ("roofline fraction (algorithmic FLOP of the system's three nets / f32 MFMA "
+                                                   "peak) of %d-frame launches of the other shipped systems, each behind its own "
+                                                   "disclosed pre-heat; CZ at this size is `roofline`" % BATCH)
             if args.list_files > 0:
                 # the thing north_star asks to scale: the sharded file list through the CLI, -g N over the ranks' GPUs
                 # (the other ranks idle at the barrier below; their contexts hold no work)

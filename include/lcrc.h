@@ -71,6 +71,10 @@ int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len,
  * lcrc_create, the first file's front-end -- overlaps with it (the CLI does).  No reference counterpart: the reference
  * has no device to bring up. */
 int lcrc_device_warmup(int device_id);
+/* PCI address of GPU `device_id` ("0000:c1:00.0") into buf: lets a host that drives several GPUs place the threads of
+ * each near it (the CLI pins a GPU's worker threads to the CPUs of /sys/bus/pci/devices/<id>/numa_node).  No reference
+ * counterpart. */
+int lcrc_device_pci_bus_id(int device_id, char *buf, int len);
 /* A further context for the same model on the same GPU (the reference would construct a second Traps and load the
  * files again, traps.cpp:88-171): own stream, staging buffers, streaming state and settings (all at their defaults),
  * but the read-only device buffers -- packed weights, biases, norms, tables -- are SHARED with `src` and freed with the

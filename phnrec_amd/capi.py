@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 
 # every symbol include/lcrc.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "lcrc_create", "lcrc_clone", "lcrc_device_warmup", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
+    "lcrc_create", "lcrc_clone", "lcrc_device_warmup", "lcrc_device_pci_bus_id", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",

@@ -10,8 +10,11 @@
 #include <cerrno>
 #include <chrono>
 #include <cmath>
+#include <cctype>
 #include <cstring>
+#include <ctime>
 #include <functional>
+#include <map>
 #include <thread>
 
 #include "htk.h"
@@ -60,12 +63,6 @@ std::string GetFilePath(const std::string &name)
     return sep == std::string::npos ? std::string() : name.substr(0, sep);
 }
 
-struct Group {
-    std::mutex mu;
-    std::condition_variable cv;
-    int pending = 0;
-};
-
 // CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (containers
 // commonly show all of the host's cores but grant a fraction; a pool sized to the former is throttled).
 int UsableCpus()
@@ -92,7 +89,9 @@ int UsableCpus()
 
 ThreadPool::ThreadPool(int n)
 {
-    for (int i = 0; i < n; i++) threads_.emplace_back([this] { Run(); });
+    CPU_ZERO(&affinity_);
+    for (int i = 0; i < n; i++) workers_.emplace_back(new Worker);
+    for (int i = 0; i < n; i++) threads_.emplace_back([this, i] { Run(i); });
 }
 
 ThreadPool::~ThreadPool()
@@ -100,65 +99,103 @@ ThreadPool::~ThreadPool()
     {
         std::lock_guard<std::mutex> l(mu_);
         stop_ = true;
+        WakeLocked((int)workers_.size());
     }
-    cv_.notify_all();
     for (auto &t : threads_) t.join();
 }
 
-void ThreadPool::Run()
+void ThreadPool::SetAffinity(const cpu_set_t &set)
 {
+    if (CPU_COUNT(&set) == 0) return;
+    std::lock_guard<std::mutex> l(mu_);
+    affinity_ = set;
+    affinity_gen_++;
+}
+
+void ThreadPool::WakeLocked(int k)
+{
+    while (k-- > 0 && !idle_.empty()) {
+        Worker &w = *workers_[(size_t)idle_.back()];
+        idle_.pop_back();
+        w.wake = true;
+        w.cv.notify_one();
+    }
+}
+
+void ThreadPool::FinishLocked(const Task &t)
+{
+    if (--t.group->pending == 0) t.group->cv.notify_all();
+}
+
+void ThreadPool::Run(int id)
+{
+    Worker &w = *workers_[(size_t)id];
+    std::unique_lock<std::mutex> l(mu_);
     for (;;) {
-        Task t{nullptr, 0, 0, nullptr};
-        std::function<void()> bg;
-        {
-            std::unique_lock<std::mutex> l(mu_);
-            cv_.wait(l, [this] { return stop_ || !queue_.empty() || !background_.empty(); });
-            if (!queue_.empty()) {                        // a blocked caller's chunks come first
-                t = queue_.front();
-                queue_.pop_front();
-            } else if (!background_.empty()) {
-                bg = std::move(background_.front());
-                background_.pop_front();
-            } else {
-                return;
-            }
+        if (w.affinity_seen != affinity_gen_) {
+            w.affinity_seen = affinity_gen_;
+            (void)sched_setaffinity(0, sizeof affinity_, &affinity_);
         }
-        if (bg) { bg(); continue; }
-        for (int i = t.begin; i < t.end; i++) (*t.fn)(i);
-        std::lock_guard<std::mutex> l(t.group->mu);
-        if (--t.group->pending == 0) t.group->cv.notify_all();
+        if (!queue_.empty()) {                            // a blocked caller's chunks come first
+            const Task t = queue_.front();
+            queue_.pop_front();
+            l.unlock();
+            for (int i = t.begin; i < t.end; i++) (*t.fn)(i);
+            l.lock();
+            FinishLocked(t);
+            continue;
+        }
+        if (!background_.empty()) {
+            std::function<void()> bg = std::move(background_.front());
+            background_.pop_front();
+            l.unlock();
+            bg();
+            l.lock();
+            continue;
+        }
+        if (stop_) return;
+        idle_.push_back(id);
+        w.wake = false;
+        w.cv.wait(l, [&w] { return w.wake; });
     }
 }
 
 void ThreadPool::Submit(std::function<void()> fn)
 {
     if (threads_.empty()) { fn(); return; }
-    {
-        std::lock_guard<std::mutex> l(mu_);
-        background_.push_back(std::move(fn));
-    }
-    cv_.notify_one();
+    std::lock_guard<std::mutex> l(mu_);
+    background_.push_back(std::move(fn));
+    WakeLocked(1);
 }
 
-void ThreadPool::ParallelFor(int n, const std::function<void(int)> &fn)
+void ThreadPool::ParallelFor(int n, const std::function<void(int)> &fn, int grain)
 {
     if (n <= 0) return;
-    if (threads_.empty() || n == 1) {
+    const int max_chunks = grain > 1 ? (n + grain - 1) / grain : n;
+    // a few chunks per worker keeps the tail short without flooding the queue
+    const int chunks = std::max(1, std::min(max_chunks, 4 * ((int)threads_.size() + 1)));
+    if (threads_.empty() || chunks == 1) {
         for (int i = 0; i < n; i++) fn(i);
         return;
     }
-    // a few chunks per worker keeps the tail short without flooding the queue
-    const int chunks = std::min(n, 4 * (int)threads_.size());
     Group g;
     g.pending = chunks;
-    {
-        std::lock_guard<std::mutex> l(mu_);
-        for (int c = 0; c < chunks; c++)
-            queue_.push_back(Task{&fn, (int)((long long)n * c / chunks), (int)((long long)n * (c + 1) / chunks), &g});
+    std::unique_lock<std::mutex> l(mu_);
+    for (int c = 0; c < chunks; c++)
+        queue_.push_back(Task{&fn, (int)((long long)n * c / chunks), (int)((long long)n * (c + 1) / chunks), &g});
+    WakeLocked(chunks - 1);                                // the caller takes a share itself
+    while (g.pending > 0) {
+        if (!queue_.empty()) {                             // (possibly another caller's chunk: all the same to the pool)
+            const Task t = queue_.front();
+            queue_.pop_front();
+            l.unlock();
+            for (int i = t.begin; i < t.end; i++) (*t.fn)(i);
+            l.lock();
+            FinishLocked(t);
+        } else {
+            g.cv.wait(l);
+        }
     }
-    cv_.notify_all();
-    std::unique_lock<std::mutex> l(g.mu);
-    g.cv.wait(l, [&g] { return g.pending == 0; });
 }
 
 // posteriors/softening_func and decoder/softening_func (srec.cpp:164-176, srec.h:192-194)
@@ -540,8 +577,28 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
         job.err = "posterior vectors are shorter than the phoneme list needs\n";
         return;
     }
-    for (int r = 0; r < job.frames; r++) dec.ProcessFrame(post + (size_t)r * cols);
-    dec.Done();
+    {
+        timespec a, b;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &a);
+        // The frames are read once, straight out of the context's pinned posterior buffer (DRAM-cold: the copy engine
+        // put them there), and a frame's ~250 dependent instructions fill the core's window: the loads of the frames
+        // behind it are not issued early enough to hide their latency.  Requested kAhead frames ahead, they are:
+        // 10 000-file HU list on an EPYC 9575F, Viterbi CPU seconds 1.0-1.1 -> 0.28-0.30 (33 ns per frame, the rate of
+        // the cache-resident micro-benchmark; gpurun_out/r04_exp_prefetch.txt; 4 / 8 / 16 / 32 frames ahead alike).
+        static const int kAhead = getenv("PHNREC_DEC_PREFETCH") ? atoi(getenv("PHNREC_DEC_PREFETCH")) : 8;
+        const size_t row_bytes = (size_t)cols * sizeof(float);
+        const char *base = reinterpret_cast<const char *>(post), *end = base + (size_t)job.frames * row_bytes;
+        for (int r = 0; r < job.frames; r++) {
+            if (kAhead > 0) {
+                const char *q = base + (size_t)(r + kAhead) * row_bytes;
+                for (const char *e = q + row_bytes; q < e && q < end; q += 64) __builtin_prefetch(q, 0, 3);
+            }
+            dec.ProcessFrame(post + (size_t)r * cols);
+        }
+        dec.Done();
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b);
+        viterbi_ns_ += (long long)(b.tv_sec - a.tv_sec) * 1000000000LL + (b.tv_nsec - a.tv_nsec);
+    }
     EmitLabels(job, mlf, dec.Labels());
 }
 
@@ -627,6 +684,94 @@ bool ReadWholeFile(const char *path, unsigned char *dst, long long bytes)
     return got == bytes;
 }
 
+// Launch slots of one physical GPU.  Contexts that share a GPU run their launches under processor sharing: three
+// equal launches submitted together also END together, their contexts then read / decode together while the GPU has
+// nothing to do, and the convoy repeats (profiles/r03_cli_timeline.txt: device busy 69-80 % of a list run).  With at
+// most `slots` launches admitted at a time -- first come, first served -- the admitted ones finish one after the other
+// and a context that is ready takes the slot the moment one leaves: the contexts fall out of step and stay so.
+class DeviceSlots {
+public:
+    explicit DeviceSlots(int n) : free_(n) {}
+    void Acquire()
+    {
+        std::unique_lock<std::mutex> l(mu_);
+        const long long my = next_++;
+        cv_.wait(l, [&] { return free_ > 0 && serving_ == my; });
+        free_--;
+        serving_++;
+        cv_.notify_all();
+    }
+    void Release()
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        free_++;
+        cv_.notify_all();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int free_;
+    long long next_ = 0, serving_ = 0;
+};
+
+// CPU seconds of the calling thread (not wall clock: a thread that waits for its time slice under a cgroup quota,
+// beside spinning waiters, consumes nothing -- the host ceiling wants what the cores must DELIVER)
+long long ThreadCpuNs()
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+
+// CPUs of a GPU's NUMA node -- the node its PCIe root hangs on -- that the process may use.  The thread that feeds and
+// waits for GPU g keeps to them (it touches g's pinned staging buffers, allocated next to the GPU, and its doorbells),
+// and the pool keeps to the nodes of the GPUs in use.  Only where the node is known and has CPUs inside the process's
+// affinity mask, and PHNREC_NO_PIN is unset; silently nothing otherwise.
+bool GpuNodeCpus(int device, cpu_set_t *want)
+{
+    CPU_ZERO(want);
+    if (getenv("PHNREC_NO_PIN")) return false;
+    char bus[64] = {0};
+    if (lcrc_device_pci_bus_id(device, bus, sizeof bus) != 0 || !bus[0]) return false;
+    for (char *q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return false;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    for (char *q = list; *q;) {                    // "0-63,128-191"
+        char *end = nullptr;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') { q = end + 1; b = strtol(q, &end, 10); if (end == q) break; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, want);
+        if (*end != ',') break;
+        q = end + 1;
+    }
+    return CPU_COUNT(want) > 0;
+}
+
+void PinToGpuNode(int device)
+{
+    cpu_set_t want;
+    if (GpuNodeCpus(device, &want)) (void)sched_setaffinity(0, sizeof want, &want);
+}
+
 struct Slot {
     int state = 0;          // 0: stage 1 pending, 1: staged (waits for a launch), 2: in a launch, 3: done
 };
@@ -650,6 +795,16 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
         // list that eight GPUs finish in a tenth of a second are a loss.
         if (!EnsureGpus(single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3)) return false;
+    }
+    if (need_gpu && !single_file && pool_->Size() > 0) {
+        cpu_set_t all, one;
+        CPU_ZERO(&all);
+        bool every = true;
+        for (int d : gpu_devices_) {
+            if (!GpuNodeCpus(d, &one)) { every = false; break; }
+            CPU_OR(&all, &all, &one);
+        }
+        if (every) pool_->SetAffinity(all);
     }
     const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
     std::vector<std::string> phn_names;
@@ -692,9 +847,9 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     std::atomic<long long> stage1_us(0), read_us(0), gather_us(0), stage3_us(0);
     struct CpuTimer {
         std::atomic<long long> &acc;
-        clock::time_point t0;
-        explicit CpuTimer(std::atomic<long long> &a) : acc(a), t0(clock::now()) {}
-        ~CpuTimer() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0).count(); }
+        long long t0;
+        explicit CpuTimer(std::atomic<long long> &a) : acc(a), t0(ThreadCpuNs()) {}
+        ~CpuTimer() { acc += ThreadCpuNs() - t0; }
     };
     std::atomic<bool> first_launch(true);
     const int n_ctx = need_gpu ? (int)gpus_.size() : 0;
@@ -772,19 +927,34 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         }
     };
 
+    // launch slots per PHYSICAL device (logical GPUs mapped onto one device share its slots); PHNREC_GPU_SLOTS=0: none
+    int slots_per_gpu = 2;
+    if (const char *e = getenv("PHNREC_GPU_SLOTS")) slots_per_gpu = std::max(0, atoi(e));
+    std::map<int, std::unique_ptr<DeviceSlots>> dev_slots;
+    if (need_gpu && slots_per_gpu > 0 && !single_file)
+        for (int d : gpu_devices_)
+            if (!dev_slots.count(d)) dev_slots[d].reset(new DeviceSlots(slots_per_gpu));
+    const int n_log = std::max(1, (int)gpu_devices_.size());
+    // items per ParallelFor chunk so that a chunk is worth waking a thread for: ~8000 frames of decoding / formatting
+    // (a quarter of a millisecond), ~1 MB of file reads
+    auto frame_grain = [](int cnt, long long frames) {
+        return (int)std::max<long long>(1, 8000LL * cnt / std::max<long long>(1, frames));
+    };
     std::vector<double> kms((size_t)n_ctx, 0.0);
     // conversions that do not touch the GPU (-t par, -s post) take the same road -- runs of consecutive staged jobs --
     // so that nothing BEHIND a file that cannot be read is ever written
     auto host_worker = [&]() {
         std::vector<Item *> items;
         while (take_launch(items)) {
+            long long fr = 0;
+            for (Item *it : items) fr += it->job.frames;
             pool_->ParallelFor((int)items.size(), [&](int k) {
                 CpuTimer tm(stage3_us);
                 Job &j = items[k]->job;
                 Stage3(out, j, mlf != nullptr, out == dfParams ? nullptr : j.post.data(), j.cols);
                 std::vector<float>().swap(j.mel);
                 std::vector<float>().swap(j.post);
-            });
+            }, frame_grain((int)items.size(), fr));
             std::lock_guard<std::mutex> l(mu);
             for (Item *it : items) it->slot.state = 3;
             drain();
@@ -792,6 +962,14 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     };
     auto worker = [&](int g) {
         Traps &tr = *gpus_[g];
+        const int device = gpu_devices_[(size_t)(g % n_log)];
+        DeviceSlots *slots = dev_slots.count(device) ? dev_slots[device].get() : nullptr;
+        struct SlotHold {                       // one launch's stay on the device
+            DeviceSlots *s;
+            explicit SlotHold(DeviceSlots *x) : s(x) { if (s) s->Acquire(); }
+            ~SlotHold() { if (s) s->Release(); }
+        };
+        if (!single_file) PinToGpuNode(device);
         std::vector<Item *> items;
         std::vector<int> off;
         auto abort_run = [&](const std::string &msg) {
@@ -810,7 +988,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     v[i] = Label{lb.start, lb.end, phn_names[lb.phn], lb.score};
                 }
                 EmitLabels(items[k]->job, mlf != nullptr, v);
-            });
+            }, 16);
             return true;
         };
         while (take_launch(items)) {
@@ -839,7 +1017,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                         int e = bad.load();
                         while (k < e && !bad.compare_exchange_weak(e, k)) {}
                     }
-                });
+                }, (int)std::max<long long>(1, (1LL << 20) * cnt / std::max<long long>(1, pos)));
                 if (bad < cnt) {
                     // The file was there for stage 1's stat() and cannot be read now.  Same meaning as a stage-1
                     // failure (srec.cpp:1246-1290 works file by file): the list stops AT this file -- the jobs in
@@ -862,7 +1040,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     off.resize((size_t)b + 1);
                 }
                 foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
-                if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                {
+                    SlotHold hold(slots);
+                    if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                }
                 h_post = tr.StagedPosteriors();
             } else {
                 float *h_mel = nullptr, *hp = nullptr;
@@ -872,8 +1053,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     Job &j = items[k]->job;
                     memcpy(h_mel + (size_t)off[k] * nbanks_, j.mel.data(), j.mel.size() * sizeof(float));
                     std::vector<float>().swap(j.mel);
-                });
-                if (!tr.StageRun(off.data(), cnt)) { abort_run(tr.LastError()); return; }
+                }, frame_grain(cnt, 2LL * off.back()));
+                {
+                    SlotHold hold(slots);
+                    if (!tr.StageRun(off.data(), cnt)) { abort_run(tr.LastError()); return; }
+                }
                 foff = off;
                 h_post = hp;
             }
@@ -889,7 +1073,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     Job &j = items[k]->job;
                     j.cols = n_out_;
                     Stage3(out, j, mlf != nullptr, const_cast<float *>(h_post) + (size_t)foff[k] * n_out_, n_out_, true);
-                });
+                }, frame_grain(cnt, off.back()));
             }
             std::lock_guard<std::mutex> l(mu);
             for (Item *it : items) it->slot.state = 3;
@@ -949,6 +1133,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     stats_.cpu_read += read_us.load() * 1e-9;
     stats_.cpu_gather += gather_us.load() * 1e-9;
     stats_.cpu_stage3 += stage3_us.load() * 1e-9;
+    stats_.cpu_viterbi = viterbi_ns_.load() * 1e-9;
     stats_.host_threads = std::max(1, pool_->Size());
     for (double k : kms) stats_.gpu_kernel_ms += k;
     stats_.files += files_done;

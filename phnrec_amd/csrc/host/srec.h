@@ -19,6 +19,9 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -41,6 +44,7 @@ struct RunStats {
     // CPU seconds of the host stages, summed over threads: stage 1 (file read [+ front-end]; stat() with -F), file reads
     // into pinned memory (-F), gather into pinned memory, stage 3 (Viterbi / label formatting / dump writing)
     double cpu_stage1 = 0, cpu_read = 0, cpu_gather = 0, cpu_stage3 = 0;
+    double cpu_viterbi = 0;             // of cpu_stage3: the Viterbi frames alone (the rest is label text and output)
     int host_threads = 1;
 };
 
@@ -50,23 +54,39 @@ struct RunStats {
 // waits behind the front-end of files that are not needed yet.
 int UsableCpus();   // affinity mask capped by the cgroup CPU quota
 
+// Host thread pool.  Two things keep its CPU seconds down on hosts where a core that has slept runs slowly for a
+// while (cold clock, cold caches: the per-frame CPU time of the host Viterbi was 2.7 x higher with sixteen
+// intermittently busy threads than with one busy one, gpurun_out/r04_host_decoder_probe.txt):
+//   * idle threads wait on a STACK -- work wakes the thread that went idle last, so a load that needs five cores keeps
+//     five threads busy and warm instead of touring all sixteen;
+//   * ParallelFor takes a grain (items per chunk) and the CALLER works through chunks too instead of sleeping.
 class ThreadPool {
 public:
     explicit ThreadPool(int n);
     ~ThreadPool();
-    void ParallelFor(int n, const std::function<void(int)> &fn);
+    // fn(i) for i in [0, n); chunks of at least `grain` items; returns when all have run (the caller runs chunks too)
+    void ParallelFor(int n, const std::function<void(int)> &fn, int grain = 1);
     void Submit(std::function<void()> fn);                  // runs inline when the pool has no threads
     int Size() const { return (int)threads_.size(); }
+    // CPUs the pool's threads keep to from now on (each thread applies it before its next task); empty set: no change
+    void SetAffinity(const cpu_set_t &set);
 
 private:
-    struct Task { const std::function<void(int)> *fn; int begin, end; struct Group *group; };
-    void Run();
+    struct Group { int pending = 0; std::condition_variable cv; };
+    struct Task { const std::function<void(int)> *fn; int begin, end; Group *group; };
+    struct Worker { std::condition_variable cv; bool wake = false; int affinity_seen = 0; };
+    void Run(int id);
+    void WakeLocked(int k);                          // the k most recently idled threads
+    void FinishLocked(const Task &t);
     std::vector<std::thread> threads_;
-    std::deque<Task> queue_;                       // ParallelFor chunks: served first
-    std::deque<std::function<void()>> background_;  // Submit tasks
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::vector<int> idle_;                          // stack: back() went idle last
+    std::deque<Task> queue_;                         // ParallelFor chunks: served first
+    std::deque<std::function<void()>> background_;   // Submit tasks
     std::mutex mu_;
-    std::condition_variable cv_;
     bool stop_ = false;
+    cpu_set_t affinity_;
+    int affinity_gen_ = 0;
 };
 
 class SpeechRec {
@@ -119,6 +139,7 @@ private:
     bool Fail(const std::string &msg) { err_ = msg; return false; }
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
 
+    std::atomic<long long> viterbi_ns_{0};
     std::string config_dir_, err_;
     bool sent_max_norm_ = false, sent_chmax_norm_ = false;
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false, split_f16_ = false;

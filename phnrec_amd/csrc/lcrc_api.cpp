@@ -1023,6 +1023,18 @@ int lcrc_device_warmup(int device_id)
     return LCRC_OK;
 }
 
+int lcrc_device_pci_bus_id(int device_id, char *buf, int len)
+{
+    if (!buf || len < 13) return fail(nullptr, LCRC_E_ARG, "lcrc_device_pci_bus_id: buffer of at least 13 bytes needed");
+    buf[0] = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
+    HIP_TRY(nullptr, hipDeviceGetPCIBusId(buf, len, device_id));
+    return LCRC_OK;
+}
+
 int lcrc_create(lcrc_ctx **out, const char *model_dir, int nbanks, int trap_len, int add_c0, int device_id)
 {
     if (!out || !model_dir) return fail(nullptr, LCRC_E_ARG, "lcrc_create: NULL argument");

@@ -3,10 +3,11 @@
 // the CLI does so unless -D is given; this kernel exists so that a `-t str` run needs neither the
 // 4*nOut bytes per frame of posteriors over PCIe nor host cores for decoding.
 //
-// One wave per utterance, lane i = phoneme i (<= 64 phonemes), each lane carrying its model's S+1 token
-// slots (score, entry winner, length) in registers; the time_pruning+1 <= 64 entries of the winner history
-// live one per lane in three more registers (v_readlane / v_writelane with a scalar index), wave maxima go
-// through DPP: the kernel touches no LDS and needs no barrier.  Restates, operation by operation in f32:
+// One wave per utterance (sixteen utterances per workgroup), lane i = phoneme i (<= 64 phonemes), each lane carrying
+// its model's S+1 token slots (score, entry winner, length) in registers; the time_pruning+1 <= 64 entries of the
+// winner history live one per lane in five more registers (v_readlane with a scalar index, compare + select to
+// write), wave maxima go through DPP: the kernel touches no LDS and needs no barrier.  Restates, operation by
+// operation in f32:
 //   PhnDec::Init          phndec.cpp:44-94     entry slot = insertion penalty, the rest -FLT_MAX
 //   PhnDec::ProcessFrame  phndec.cpp:96-189    inside the models last state first (stay vs enter, ln 0.5
 //                                              each, strict >), best exit token = first strict maximum,
@@ -53,28 +54,45 @@ __device__ __forceinline__ float lane_get(float v, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
-// lane `lane` of the register := v (both wave-uniform): a compare + select
-__device__ __forceinline__ int lane_set(int old, int lane, int v) { return (int)threadIdx.x == lane ? v : old; }
-__device__ __forceinline__ float lane_set(float old, int lane, float v) { return (int)threadIdx.x == lane ? v : old; }
-
 }  // namespace
 
-__global__ __launch_bounds__(64) void phndec_kernel(const PhnDecParams p)
+// kDecWaves utterances per workgroup, one wave each, no barrier and no LDS: the waves of a workgroup have nothing to do
+// with each other.  What the grouping buys is CU time: every step of a frame depends on the one before, so a wave
+// issues an instruction every few cycles at best and sixteen of them share a CU (four per SIMD) at nearly the speed of
+// one -- while a CU that holds even ONE decoder wave cannot take a workgroup of the posterior kernel (512 registers x
+// 4 waves: the whole register file).  One wave per workgroup (round 3) held 36 CUs for the 1.2 ms of a 36-utterance
+// launch, this form holds 3.
+constexpr int kDecWaves = 16;
+
+template <int S>
+__global__ __launch_bounds__(64 * kDecWaves) void phndec_kernel(const PhnDecParams p)
 {
-    const int u = blockIdx.x, lane = threadIdx.x;
+    // (readfirstlane: the wave number is the same in all 64 lanes, which hipcc cannot know -- without it the utterance's
+    //  bounds, the history head and every other wave-uniform value live in vector registers and each scalar-indexed
+    //  readlane costs a v_readfirstlane and its hazard no-ops)
+    const int u = blockIdx.x * kDecWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (u >= p.n_utts) return;                                  // wave-uniform
     const int a0 = p.off[u], T = p.off[u + 1] - a0;
-    const int S = p.S, P = p.P, H = p.prune + 1;
+    const int P = p.P, H = p.prune + 1;
     const float lh = -0.69314718055994530941723212145818f;      // ln 0.5, both transitions (phndec.cpp:9,14-15)
     const bool active = lane < P;
     lcrc_label *out = p.labels + a0;
+    auto lane_set_i = [&](int old, int at, int v) { return lane == at ? v : old; };
+    auto lane_set_f = [&](float old, int at, float v) { return lane == at ? v : old; };
 
-    // winner history (phndec.cpp's hphn / hlen / halpha): physical slot = lane, logical slot q = (head + q) % H
-    int hphn = -1, hlen = -1;
+    // winner history (phndec.cpp's hphn / hlen / halpha): physical slot = lane, logical slot q = (head + q) % H.
+    // hmask (round 4): bit d of slot q's 64-bit word says that TimePruning's walk, started at q, visits q - d --
+    // the walk "offs -= hlen[offs]" (phndec.cpp:206-214) is a chain of back pointers that never changes once a slot is
+    // pushed, so the set of positions it visits is built when the slot is pushed, 1 | mask[q - hlen] << hlen, and the
+    // per-frame walk (3-8 dependent readlane round trips) becomes two readlanes and a few scalar bit operations.
+    // Distances are relative, so the words stay valid while the logical indices slide.
+    int hphn = -1, hlen = -1, hm_lo = 0, hm_hi = 0;
     float halpha = -1.0f;
-    float a[kMaxStates + 1];
-    int pv[kMaxStates + 1], ln[kMaxStates + 1];
+    // a lane's token slots: pad lanes (>= P) carry -FLT_MAX and harmless bookkeeping; they never win a strict compare
+    float a[S + 1];
+    int pv[S + 1], ln[S + 1];
 #pragma unroll
-    for (int j = 0; j <= kMaxStates; j++) { a[j] = j == 0 ? p.wpen : -FLT_MAX; pv[j] = -1; ln[j] = 0; }
+    for (int j = 0; j <= S; j++) { a[j] = j == 0 && active ? p.wpen : -FLT_MAX; pv[j] = -1; ln[j] = 0; }
     float prev_alpha = 0.0f;
     int nlab = 0, head = 0;
     auto phys = [&](int q) { const int x = head + q; return x >= H ? x - H : x; };   // uniform
@@ -83,74 +101,78 @@ __global__ __launch_bounds__(64) void phndec_kernel(const PhnDecParams p)
     // per frame (the frames are strictly sequential), so they are requested kAhead frames ahead into a
     // register ring whose slots are compile-time (the loop is unrolled by kAhead).
     constexpr int kAhead = 8;
-    float ob[kAhead][kMaxStates];
+    float ob[kAhead][S];
     const int lidx = min(lane, P - 1) * S;
-    auto fetch = [&](int t, float (&o)[kMaxStates]) {        // unconditional loads, clamped indices
+    auto fetch = [&](int t, float (&o)[S]) {                 // unconditional loads, clamped indices
         const float *f = p.logpost + (size_t)(a0 + max(0, min(t, T - 1))) * p.cols + lidx;
 #pragma unroll
-        for (int j = 0; j < kMaxStates; j++) o[j] = f[min(j, S - 1)];
+        for (int j = 0; j < S; j++) o[j] = f[j];
     };
-    auto step = [&](int t, const float (&o)[kMaxStates]) {
-        if (active) {
+    auto step = [&](int t, const float (&o)[S]) {
+        // inside the models, last state first, on the old values (phndec.cpp:96-119); pad lanes compute along
 #pragma unroll
-            for (int j = kMaxStates; j > 0; j--) {
-                if (j <= S) {
-                    const float stay = a[j] + lh, enter = a[j - 1] + lh;
-                    const float obs = o[j - 1];
-                    if (stay > enter) {
-                        a[j] = stay + obs;
-                        ln[j] += 1;
-                    } else {
-                        a[j] = enter + obs;
-                        pv[j] = pv[j - 1];
-                        ln[j] = ln[j - 1] + 1;
-                    }
-                }
-            }
+        for (int j = S; j > 0; j--) {
+            const float stay = a[j] + lh, enter = a[j - 1] + lh;
+            const bool keep = stay > enter;
+            a[j] = (keep ? stay : enter) + o[j - 1];
+            pv[j] = keep ? pv[j] : pv[j - 1];
+            ln[j] = (keep ? ln[j] : ln[j - 1]) + 1;
         }
-        // exit tokens: slot S of every phoneme
-        float ex = -FLT_MAX;
-        int epv = -1, eln = 0;
+        if (!active) {                                          // -FLT_MAX + x is -FLT_MAX for every finite x here; keep it exact
 #pragma unroll
-        for (int j = 1; j <= kMaxStates; j++)
-            if (j == S) { ex = active ? a[j] : -FLT_MAX; epv = pv[j]; eln = ln[j]; }
-        float best;
-        int bi;
-        wave_argmax(ex, best, bi);
-        epv = lane_get(epv, bi);
-        eln = lane_get(eln, bi);
+            for (int j = 1; j <= S; j++) a[j] = -FLT_MAX;
+        }
+        // the best inner token of each lane (TimePruning, phndec.cpp:191-205: first strict maximum = smallest state)
+        float bv = a[1];
+        int bl = ln[1], bp = pv[1];
+#pragma unroll
+        for (int j = 2; j <= S; j++)
+            if (a[j] > bv) { bv = a[j]; bl = ln[j]; bp = pv[j]; }
+        // exit tokens: slot S of every phoneme
+        float best, wv;
+        int bi, wi;
+        wave_argmax(a[S], best, bi);
+        wave_argmax(bv, wv, wi);
+        const int epv = lane_get(pv[S], bi), eln = lane_get(ln[S], bi);
         head = head + 1 == H ? 0 : head + 1;                    // shift the history left by one ...
         {                                                       // ... and push the winner at the back
             const int back = phys(H - 1);
-            hphn = lane_set(hphn, back, epv);
-            hlen = lane_set(hlen, back, eln);
-            halpha = lane_set(halpha, back, best);
+            // positions the walk from the new slot visits: itself, then whatever the slot eln frames back visits
+            unsigned long long m = 1ull;
+            if (eln >= 1 && eln <= H - 1) {
+                const int src = phys(H - 1 - eln);
+                const unsigned long long sm = ((unsigned long long)(unsigned)lane_get(hm_hi, src) << 32) | (unsigned)lane_get(hm_lo, src);
+                m |= sm << eln;                                 // eln <= 63
+            }
+            hphn = lane_set_i(hphn, back, epv);
+            hlen = lane_set_i(hlen, back, eln);
+            halpha = lane_set_f(halpha, back, best);
+            hm_lo = lane_set_i(hm_lo, back, (int)(unsigned)m);
+            hm_hi = lane_set_i(hm_hi, back, (int)(unsigned)(m >> 32));
         }
-        a[0] = best + p.wpen;
+        a[0] = active ? best + p.wpen : -FLT_MAX;
         pv[0] = bi;
         ln[0] = 0;
 
         const int nframes = t + 1;
         if (nframes >= H) {                                     // TimePruning
-            float bv = -FLT_MAX;
-            int bl = 1, bp = 0;
-#pragma unroll
-            for (int j = 1; j <= kMaxStates; j++)
-                if (j <= S && active && a[j] > bv) { bv = a[j]; bl = ln[j]; bp = pv[j]; }
-            float wv;
-            int wi;
-            wave_argmax(bv, wv, wi);
             int blen = lane_get(bl, wi), bprev = lane_get(bp, wi);
             if (!(wv > -FLT_MAX)) { blen = 1; bprev = 0; }      // no token beat the initial -FLT_MAX
-            int offs = H - 1 - blen, phn = bprev;
-            while (offs > 0) {
-                const int q = phys(offs);
-                const int l = lane_get(hlen, q);
-                phn = lane_get(hphn, q);
-                if (l <= 0) break;
-                offs -= l;
+            const int s0 = H - 1 - blen;                        // where the walk starts; < 0: it ends below the horizon
+            bool hit = s0 == 0;
+            int phn = bprev;
+            if (s0 > 0) {
+                const int q = phys(s0);
+                const unsigned long long m = ((unsigned long long)(unsigned)lane_get(hm_hi, q) << 32) | (unsigned)lane_get(hm_lo, q);
+                hit = (m >> s0) & 1ull;                         // the walk lands exactly on the horizon
+                if (hit) {
+                    // the last slot it visits above the horizon names the phoneme that ends there
+                    const unsigned long long above = m & ((1ull << s0) - 1ull);      // never 0: bit 0 is the start
+                    const int d = 63 - __builtin_clzll(above);
+                    phn = lane_get(hphn, phys(s0 - d));
+                }
             }
-            if (offs == 0) {                                    // a phoneme ends exactly at the horizon
+            if (hit) {                                          // a phoneme ends exactly at the horizon
                 const int q0 = phys(0);
                 const int end = nframes - H + 1, start = end - lane_get(hlen, q0);
                 const float h0 = lane_get(halpha, q0);
@@ -209,7 +231,13 @@ hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream)
     if (p.P < 1 || p.P > 64 || p.S < 1 || p.S > kMaxStates || p.prune < 1 || p.prune + 1 > kMaxHist ||
         p.P * p.S > p.cols)
         return hipErrorInvalidValue;
-    phndec_kernel<<<dim3(p.n_utts), dim3(64), 0, stream>>>(p);
+    const dim3 grid((p.n_utts + kDecWaves - 1) / kDecWaves), block(64 * kDecWaves);
+    switch (p.S) {
+    case 1: phndec_kernel<1><<<grid, block, 0, stream>>>(p); break;
+    case 2: phndec_kernel<2><<<grid, block, 0, stream>>>(p); break;
+    case 3: phndec_kernel<3><<<grid, block, 0, stream>>>(p); break;
+    default: phndec_kernel<4><<<grid, block, 0, stream>>>(p); break;
+    }
     return hipGetLastError();
 }
 
