@@ -157,16 +157,20 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
 //
 // colmean_kernel: one workgroup per utterance; what bounds it is ONE dependent f32 add per frame and bank, so
 // everything else is kept off that chain.  Wave 0 is the ADDER: lane b owns column b and does nothing but the chain.
-// Waves 1-3 are LOADERS: they stream the utterance's rows (coalesced dword loads, 768 B per step) into a ring of
-// kMeanSlots LDS slots, TRANSPOSED -- slot[b][r], row pitch a multiple of 4 with an odd number of quads, so that the
-// adder fetches four consecutive frames of its column with one conflict-free ds_read_b128 (a [r][b] image costs one
-// LDS instruction per add and the LDS issue, not the add, set the pace: 13 ns per frame in round 3).  The loaders run
-// kMeanSlots - 1 chunks ahead; one barrier per chunk hands a slot over in each direction.  The adder requests the next
-// 16 frames from LDS before it adds the current 16.
+// Waves 1-7 are LOADERS: they stream the utterance's rows (coalesced dword loads) into a ring of kMeanSlots LDS slots,
+// TRANSPOSED -- slot[b][r], row pitch a multiple of 4 with an odd number of quads, so that the adder fetches four
+// consecutive frames of its column with one conflict-free ds_read_b128 (a [r][b] image costs one LDS instruction per
+// add, and the LDS issue, not the add, set the pace: 13 ns per frame in round 3).  A loader thread holds a whole
+// chunk's share in registers and requests chunk c + 4 BEFORE it stores chunk c + 3, so a request has a whole step of
+// the adder to arrive (with one request group in flight per step the loaders' round trips set the pace: 7 ns per
+// frame); one barrier per chunk hands a slot over in each direction.  The adder requests the next 16 frames from LDS
+// before it adds the current 16.
 constexpr int kMeanSlots = 4;
 constexpr int kMeanSlotFloats = 4352;           // 17 KiB per slot: 272 rows of 15 banks (+ pad), 176 rows of 23
-__global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
-                                                      float *means)
+constexpr int kMeanThreads = 512, kMeanLoaders = kMeanThreads - 64;
+constexpr int kMeanPer = (kMeanSlotFloats + kMeanLoaders - 1) / kMeanLoaders;       // values per loader thread and chunk
+__global__ __launch_bounds__(kMeanThreads) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
+                                                               float *means)
 {
     extern __shared__ float ring[];             // [kMeanSlots][nbanks][RP]
     const int u = blockIdx.x;
@@ -179,83 +183,89 @@ __global__ __launch_bounds__(256) void colmean_kernel(const float *mel, const in
     const int n_chunks = (rows + R - 1) / R;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
-    // loaders: thread t of 192 takes elements t, t + 192, ... of a chunk's [r][b] image; (r, b) advance without division
+    // loaders: thread t takes elements t, t + kMeanLoaders, ... of a chunk's [r][b] image; (r, b) advance without division
     const int lt = (int)threadIdx.x - 64;
-    const int step_r = 192 / nbanks, step_b = 192 % nbanks;
-    auto load_chunk = [&](int c) {
+    const int step_r = kMeanLoaders / nbanks, step_b = kMeanLoaders % nbanks;
+    const int r0 = lt / nbanks, b0 = lt % nbanks;
+    auto request = [&](int c, float (&v)[kMeanPer]) {               // unconditional loads, clamped indices
         if (c >= n_chunks) return;
-        const int nr = min(R, rows - c * R), n = nr * nbanks;
+        const int n = min(R, rows - c * R) * nbanks;
         const float *src = x + (size_t)c * R * nbanks;
+#pragma unroll
+        for (int k = 0; k < kMeanPer; k++) v[k] = src[min(lt + k * kMeanLoaders, n - 1)];
+    };
+    auto commit = [&](int c, const float (&v)[kMeanPer]) {
+        if (c >= n_chunks) return;
+        const int n = min(R, rows - c * R) * nbanks;
         float *dst = ring + (size_t)(c % kMeanSlots) * slot_floats;
-        int r = lt / nbanks, b = lt % nbanks;
-        int i = lt;
-        for (; i + 3 * 192 < n; i += 4 * 192) {                         // four loads in flight per thread
-            float v[4]; int at[4];
+        int r = r0, b = b0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                v[k] = src[i + k * 192];
-                at[k] = b * RP + r;
-                b += step_b; r += step_r;
-                if (b >= nbanks) { b -= nbanks; r++; }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) dst[at[k]] = v[k];
-        }
-        for (; i < n; i += 192) {
-            dst[b * RP + r] = src[i];
+        for (int k = 0; k < kMeanPer; k++) {
+            if (lt + k * kMeanLoaders < n) dst[b * RP + r] = v[k];
             b += step_b; r += step_r;
             if (b >= nbanks) { b -= nbanks; r++; }
         }
     };
-    if (wave > 0)
-        for (int c = 0; c < kMeanSlots - 1; c++) load_chunk(c);
+    float va[kMeanPer], vb[kMeanPer];
+    if (wave > 0) {
+        float vc[kMeanPer];
+        request(0, va); request(1, vb); request(2, vc);             // the ring's first three chunks, all requested at once
+        commit(0, va); commit(1, vb); commit(2, vc);
+        request(3, vb);                                             // stored at step 0
+    }
     __syncthreads();
 
     float sum = 0.0f;
-    for (int c = 0; c < n_chunks; c++) {
-        if (wave > 0) {
-            load_chunk(c + kMeanSlots - 1);     // into the slot the adder left at the last barrier
-        } else if (lane < nbanks) {
-            const int nr = min(R, rows - c * R);
-            const float *col = ring + (size_t)(c % kMeanSlots) * slot_floats + lane * RP;
-            const float4 *q = reinterpret_cast<const float4 *>(col);
-            int r = 0;
-            if (nr >= 16) {
-                // two register sets, no copies: while one set's 16 frames are added the other set's are on their way
-                // (the fences keep hipcc from sinking the requests behind the adds they are meant to overlap)
-                float4 ra[4], rb[4];
-                auto request = [&](float4 (&d)[4], int row) {
+    // step c: the adder consumes slot c % 4; the loaders store chunk c + 3 (requested a step ago) into the slot the adder
+    // left at the last barrier and request chunk c + 4.  Two steps per pass: the register sets alternate by name.
+    auto adder_step = [&](int c) {
+        const int nr = min(R, rows - c * R);
+        const float *col = ring + (size_t)(c % kMeanSlots) * slot_floats + lane * RP;
+        const float4 *q = reinterpret_cast<const float4 *>(col);
+        int r = 0;
+        if (nr >= 16) {
+            // two register sets, no copies: while one set's 16 frames are added the other set's are on their way
+            // (the fences keep hipcc from sinking the requests behind the adds they are meant to overlap)
+            float4 ra[4], rb[4];
+            auto fetch = [&](float4 (&d)[4], int row) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) d[k] = q[(row >> 2) + k];
-                };
-                auto add16 = [&](const float4 (&d)[4]) {
+                for (int k = 0; k < 4; k++) d[k] = q[(row >> 2) + k];
+            };
+            auto add16 = [&](const float4 (&d)[4]) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { sum += d[k].x; sum += d[k].y; sum += d[k].z; sum += d[k].w; }
-                };
-                request(ra, 0);
-                for (; r + 48 <= nr; r += 32) {
-                    request(rb, r + 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                    add16(ra);
-                    __builtin_amdgcn_sched_barrier(0);
-                    request(ra, r + 32);
-                    __builtin_amdgcn_sched_barrier(0);
-                    add16(rb);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (r + 32 <= nr) {
-                    request(rb, r + 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                    add16(ra);
-                    add16(rb);
-                    r += 32;
-                } else {
-                    add16(ra);
-                    r += 16;
-                }
+                for (int k = 0; k < 4; k++) { sum += d[k].x; sum += d[k].y; sum += d[k].z; sum += d[k].w; }
+            };
+            fetch(ra, 0);
+            for (; r + 48 <= nr; r += 32) {
+                fetch(rb, r + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                add16(ra);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(ra, r + 32);
+                __builtin_amdgcn_sched_barrier(0);
+                add16(rb);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            for (; r < nr; r++) sum += col[r];
+            if (r + 32 <= nr) {
+                fetch(rb, r + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                add16(ra);
+                add16(rb);
+                r += 32;
+            } else {
+                add16(ra);
+                r += 16;
+            }
         }
+        for (; r < nr; r++) sum += col[r];
+    };
+    for (int c = 0; c < n_chunks; c += 2) {
+        if (wave > 0) { commit(c + 3, vb); request(c + 4, va); }
+        else if (lane < nbanks) adder_step(c);
+        __syncthreads();
+        if (c + 1 >= n_chunks) break;
+        if (wave > 0) { commit(c + 4, va); request(c + 5, vb); }
+        else if (lane < nbanks) adder_step(c + 1);
         __syncthreads();
     }
     if (wave == 0 && lane < nbanks) means[(size_t)u * nbanks + lane] = sum * (1.0f / (float)rows);
@@ -390,7 +400,7 @@ hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_of
     if (block_off == nullptr) {                 // the reference's sequential sums (lcrc_set_mean_order)
         const int R = std::min(((kMeanSlotFloats / nbanks) - 4) & ~15, 1024);
         const size_t lds = (size_t)kMeanSlots * nbanks * (R + 4) * sizeof(float);
-        colmean_kernel<<<n_utts, 256, lds, stream>>>(mel, frame_off, nbanks, means);
+        colmean_kernel<<<n_utts, kMeanThreads, lds, stream>>>(mel, frame_off, nbanks, means);
     } else {
         colmean_block_kernel<<<n_blocks, 256, 0, stream>>>(mel, frame_off, block_off, n_utts, nbanks, partial);
         submean_tree_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, partial, frame_off, block_off, n_utts, n_rows, nbanks);
