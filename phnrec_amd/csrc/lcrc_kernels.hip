@@ -51,7 +51,10 @@
 namespace phnrec {
 
 // ln() of a band posterior on its way into the merger (sLn, dspc.h:155-160).
-#ifdef LCRC_FAST_LN     // A/B switch (tools/build_ab_lib.sh): v_log_f32 * ln 2 -- 2 instructions instead of logf's ~25
+// (A/B switch, tools/build_ab_lib.sh: v_log_f32 * ln 2 -- 2 instructions instead of logf's ~25; -0.4 % on every shape, not
+//  adopted: 2 ulp instead of 1, and v_log_f32 takes a DENORMAL posterior for zero (-inf into the merger's operand image
+//  where the reference's logf gives -90...-103), so the switch would need logf's own rescaling branch back)
+#ifdef LCRC_FAST_LN
 __device__ __forceinline__ float band_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 #else
 __device__ __forceinline__ float band_ln(float x) { return logf(x); }

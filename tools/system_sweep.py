@@ -32,6 +32,11 @@ def main():
         ctx = capi.Lcrc(mdir, spec["nbanks"])
         if os.environ.get("SWEEP_NO_SPLIT"):        # as the CLI runs: fused kernels only (batch-invariant bits)
             ctx.set_hidden_split(1)
+        if os.environ.get("SWEEP_SPLIT"):           # forced workgroups per tile (tuning)
+            ctx.set_hidden_split(int(os.environ["SWEEP_SPLIT"]))
+        if os.environ.get("SWEEP_SYSTEMS") and system.split("_")[1] not in os.environ["SWEEP_SYSTEMS"].split(","):
+            ctx.close()
+            continue
         for n in sizes:
             mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
             post = torch.empty((n, ctx.n_out), device="cuda")
