@@ -670,21 +670,6 @@ def main():
     oversubscribed = len(set(dmap)) < len(dmap)
     if args.stub:
         return stub_main(args, ranks)
-    # A one-GPU box admits few processes on its card: a functional N-rank run there (every rank mapped onto device 0) may
-    # cap the ranks that touch the GPU -- PHNREC_BENCH_MAX_GPU_RANKS=k: ranks >= k take part in every rendezvous, barrier
-    # and reduction with a sleeping step and never initialise HIP.  Only honoured for oversubscribed maps; the line says
-    # how many ranks did GPU work ("ranks.gpu_ranks") and counts only their frames.
-    gpu_ranks = ranks.world
-    if oversubscribed and os.environ.get("PHNREC_BENCH_MAX_GPU_RANKS"):
-        gpu_ranks = max(1, min(ranks.world, int(os.environ["PHNREC_BENCH_MAX_GPU_RANKS"])))
-    if ranks.rank >= gpu_ranks:
-        ranks.init("gloo")
-        distrun.timed_steps(ranks, lambda: time.sleep(0.0002), lambda: None, args.steps, args.warmup)
-        ranks.max_float(0.0)
-        ranks.host_barrier()
-        ranks.finish()
-        return
-
     import torch
     from phnrec_amd import capi, modelgen
 
@@ -740,7 +725,7 @@ def main():
         elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=red_dev)
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         kernel_ms = ranks.max_float(kernel_ms, device=red_dev)
-        total_frames = args.batch * args.steps * max(1, gpu_ranks)
+        total_frames = args.batch * args.steps * max(1, ranks.world)
         fps = total_frames / elapsed
 
         line = None
@@ -774,9 +759,9 @@ def main():
                            "sharding": "one replica per GPU, utterances never exchanged (no collective)"},
                 # what actually ran: ranks as the process group counted them, how they were started, where
                 "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
-                          "device_map": dmap, "oversubscribed": oversubscribed, "gpu_ranks": gpu_ranks},
-                "frames_per_s_per_gpu": round(fps / max(1, gpu_ranks), 1),
-                "xrt": round(100.0 / (fps / max(1, gpu_ranks)), 8),
+                          "device_map": dmap, "oversubscribed": oversubscribed},
+                "frames_per_s_per_gpu": round(fps / max(1, ranks.world), 1),
+                "xrt": round(100.0 / (fps / max(1, ranks.world)), 8),
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                              "traffic": traffic, "traffic_source": traffic_source,

@@ -125,6 +125,33 @@ def test_bench_under_torch_distributed_run():
     assert line["frames_all_ranks"] == 2 * (3 + 1) * 8192
 
 
+def test_bench_eight_ranks_in_the_drivers_exact_form():
+    """Pre-flight of the driver's scaling run at N = 8, as far as a box without eight GPUs allows: the driver's exact
+    command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 8 --steps 20 --warmup 5` -- with --stub in place of the GPU step (gloo instead of RCCL; a one-GPU box
+    admits six processes on its card, so eight GPU ranks cannot be rehearsed there either).  Everything else is the real
+    path: rendezvous, the barriers around the timed region, the clock that stops at the rank's own synchronise, MAX over
+    ranks, SUM of the frames, one line from rank 0 -- well inside the driver's 600 s."""
+    import time
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        BENCH, "--gpus", "8", "--steps", "20", "--warmup", "5", "--stub"],
+                       capture_output=True, text=True, env=env, timeout=580)
+    dt = time.time() - t0
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1, p.stdout[:500]
+    line = _last_json(p.stdout)
+    assert line["ranks"]["world"] == 8 and line["ranks"]["launcher"] == "torch.distributed.run"
+    assert line["ranks"]["device_map"] == list(range(8)) and line["steps"] == 20 and line["warmup"] == 5
+    assert line["frames_all_ranks"] == 8 * (20 + 5) * 8192
+    # rank 7 sleeps 16 ms per step: MAX over ranks; the closing barrier is outside the clock (timed_steps)
+    assert 16.0 * 0.9 <= line["ms_per_step"] < 16.0 * 1.5
+    assert dt < 300, "took %.0f s" % dt
+
+
 def test_bench_refuses_to_misreport_the_gpu_count():
     """More GPUs asked for than the node has (none here): a loud failure, never an n_gpus: 1 line; and a
     launcher's WORLD_SIZE that disagrees with --gpus is refused as well."""
