@@ -135,19 +135,24 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
         pw[wave][i] = re * re + im * im;
     }
     __syncthreads();
-    if (live && lane < p.nbanks) {
+    // The workgroup's 4 x nbanks outputs are dealt to its first threads -- thread q: frame q / nbanks, bank q % nbanks --
+    // instead of nbanks lanes in each of the four waves: the bin sums and the double-precision ln (~150 instructions at
+    // the f64 rate) are then issued by one or two waves, not by four waves with three quarters of their lanes idle.
+    const int q = threadIdx.x, f = q / p.nbanks, b = q - f * p.nbanks;
+    const int ofr = blockIdx.x * 4 + f;
+    if (f < 4 && ofr < p.n_frames) {
         // bank b: bins whose falling edge is b (Banks == b) contribute p - v, then bins whose rising
         // edge... i.e. Banks == b + 1 contribute v; both runs are contiguous and in ascending order
-        const int b = lane;
+        const float *pf = pw[f];
         float e = 0.0f;
         for (int i = p.run_begin[2 * b]; i < p.run_end[2 * b]; i++) {
-            const float pp = pw[wave][i], v = p.coeffs[i] * pp;
+            const float pp = pf[i], v = p.coeffs[i] * pp;
             e += (pp - v);
         }
-        for (int i = p.run_begin[2 * b + 1]; i < p.run_end[2 * b + 1]; i++) e += p.coeffs[i] * pw[wave][i];
+        for (int i = p.run_begin[2 * b + 1]; i < p.run_end[2 * b + 1]; i++) e += p.coeffs[i] * pf[i];
         // ln in double, rounded once: glibc's logf is correctly rounded in all but rare cases, the
         // device's f32 logf is only good to a few ulp
-        p.mel[(size_t)fr * p.nbanks + b] = e > 0.0f ? (float)log((double)e) : 0.0f;
+        p.mel[(size_t)ofr * p.nbanks + b] = e > 0.0f ? (float)log((double)e) : 0.0f;
     }
 }
 

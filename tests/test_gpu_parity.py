@@ -869,6 +869,17 @@ def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
         ctx.set_posterior_readback(True)
         lp = ctx.posteriors(u)
         assert ctx.last_labels() == [oracle_mod.phndec(lp, P, S, prune, wpen)]
+        # more utterances than one workgroup of the decoder kernel holds (sixteen, one per wave): three workgroups, the
+        # last one partly empty, lengths all over the place
+        rng = np.random.default_rng(P)
+        lens2 = [int(x) for x in rng.integers(0, 3 * prune + 40, 37)]
+        off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+        mel2 = modelgen.synth_mel(int(off2[-1]), nb, seed=S + 7)
+        lp2 = ctx.posteriors_batch(mel2, off2)
+        got2 = ctx.last_labels()
+        assert len(got2) == len(lens2)
+        for k in range(len(lens2)):
+            assert got2[k] == oracle_mod.phndec(lp2[off2[k]:off2[k + 1]], P, S, prune, wpen), (P, S, prune, k, lens2[k])
         ctx.configure_decoder(0)
         ctx.posteriors(u)
         assert ctx.last_labels() == []

@@ -1,10 +1,12 @@
 #!/bin/bash
 # Regenerates everything under profiles/ that a round reports (run on the GPU box from the repo root):
-#   tools/refresh_profiles.sh r03          -> gpurun_out/refresh_r03/...   (tools/collect_profiles.sh copies the summaries)
+#   make -C phnrec_amd/csrc stamps         (HERE, before the call: the stamped library travels with the snapshot; round 3's
+#                                           phase_stamps.txt was a traceback of a stale one)
+#   tools/refresh_profiles.sh r04          -> gpurun_out/refresh_r04/...   (tools/collect_profiles.sh copies the summaries)
 # rocprofv3 is always given `python3 <script>` directly (no shell hop), PMC passes are separate runs
 # with --kernel-trace only.  Every step writes a file under $OUT as it ends (progress for the harness).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}     # a | b | all: the run fits gpurun's 20-minute limit in two halves
 OUT=gpurun_out/refresh_$TAG
 [ "$PART" != "b" ] && rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
@@ -58,4 +60,12 @@ for g in 2 4 8; do echo "== -g $g, every logical GPU on device 0"; python3 -c "
 import bench, json
 r = bench.sharded_list_leg($g, [0] * $g, 10000)
 print(json.dumps({k: r[k] for k in ('host_frontend', 'gpu_frontend_F', 'gpu_frontend_decoder_F_D', 'host_ceiling')}))"; done >> $OUT/cli_contexts.txt 2>&1
+# round 4: where a list run's wall clock goes, the host decoder's CPU time by thread count, pinned-memory reads
+TIMELINE_ROWS=40 python3 tools/cli_timeline.py 10000 -F > $OUT/cli_timeline.txt 2>&1
+python3 tools/cli_timeline.py 10000 -F -D >> $OUT/cli_timeline.txt 2>&1
+python3 tools/cli_timeline.py 10000 >> $OUT/cli_timeline.txt 2>&1
+python3 tools/cli_sweep.py 10000 "2,3,0;0,3,0;2,4,0" > $OUT/cli_sweep.txt 2>&1
+python3 tools/host_decoder_probe.py > $OUT/host_decoder_probe.txt 2>&1
+./tools/ubench/pinned_read 256 16 > $OUT/pinned_read.txt 2>&1
+./tools/ubench/pinned_read 256 1 >> $OUT/pinned_read.txt 2>&1
 ls -R $OUT | head -80
