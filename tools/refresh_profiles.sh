@@ -7,12 +7,12 @@
 # with --kernel-trace only.  Every step writes a file under $OUT as it ends (progress for the harness).
 set -u
 TAG=${1:-r04}
-PART=${2:-all}     # a | b | all: the run fits gpurun's 20-minute limit in two halves
+PART=${2:-all}     # a | b | c | all: the run fits gpurun's 20-minute limit in three parts
 OUT=gpurun_out/refresh_$TAG
-[ "$PART" != "b" ] && rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
+[ "$PART" = "a" -o "$PART" = "all" ] && rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
 mkdir -p $OUT
 export TMPDIR=/tmp
-if [ "$PART" != "b" ]; then
+if [ "$PART" = "a" -o "$PART" = "all" ]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2>> $OUT/bench.err      # the driver's invocation
 # the N-rank form on this box's one GPU (two ranks mapped onto it: functional, labelled oversubscribed)
@@ -38,6 +38,7 @@ python3 tools/stamp_profile.py PHN_EN_TIMIT_LCRC_N500 8192 >> $OUT/phase_stamps.
 LCRC_BM=16 python3 tools/stamp_profile.py PHN_EN_TIMIT_LCRC_N500 4096 >> $OUT/phase_stamps.txt 2>&1
 fi
 [ "$PART" = "a" ] && { ls -R $OUT | head -60; exit 0; }
+if [ "$PART" = "b" -o "$PART" = "all" ]; then
 # launch sizes incl. the cut points of the launch plan (whole rounds + cheaper tail), with the split path and without
 python3 tools/system_sweep.py 2048 3072 4096 4100 5120 6144 8192 10240 12288 16384 32768 > $OUT/system_sweep.txt 2>&1
 SWEEP_NO_SPLIT=1 python3 tools/system_sweep.py 4100 6144 12288 > $OUT/system_sweep_fused_only.txt 2>&1
@@ -51,6 +52,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/traps_stats -- pyth
 # split-f16 arithmetic (opt-in): both arithmetics side by side, its own kernel stats
 python3 tools/split_f16_bench.py > $OUT/split_f16_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/split_stats -- python3 tools/split_f16_bench.py 8192 > $OUT/split_prof.txt 2>&1
+fi
+[ "$PART" = "b" ] && { ls -R $OUT | head -60; exit 0; }
 # the CLI on the configs[3] list: contexts per GPU, logical -g N on this one GPU (host-side cost of more contexts)
 for n in 1 2 3 4; do echo "== PHNREC_CTX_PER_GPU=$n, -g 1"; PHNREC_CTX_PER_GPU=$n python3 -c "
 import bench, json
