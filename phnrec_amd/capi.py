@@ -108,6 +108,7 @@ def load():
     L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcrc_clone.argtypes = [C.POINTER(vp), vp]
     L.lcrc_device_warmup.argtypes = [C.c_int]
+    L.lcrc_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.lcrc_model_outputs.argtypes = [C.c_char_p, C.c_char_p]
     L.lcrc_create_system.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcrc_destroy.argtypes = [vp]

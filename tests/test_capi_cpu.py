@@ -125,6 +125,9 @@ def test_no_cpu_fallback():
         capi.Lcrc(model_dir("PHN_CZ_SPDAT_LCRC_N1500"), 15)
     assert e.value.code == capi.LCRC_E_DEVICE
     assert capi.load().lcrc_device_warmup(0) == capi.LCRC_E_DEVICE          # the start-up helper says so too
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    assert capi.load().lcrc_device_pci_bus_id(0, buf, 64) == capi.LCRC_E_DEVICE and buf.value == b""
     # and nothing in the product imports, links or loads anything under oracle/
     pat = re.compile(r"from\s+oracle|import\s+oracle|lcrc_oracle|liblcrc_oracle|libphnrec_ref|orc_[a-z_]+\(")
     for root, _, files in os.walk(os.path.join(ROOT, "phnrec_amd")):

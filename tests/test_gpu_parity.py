@@ -417,6 +417,14 @@ def test_clone_shares_the_model_and_outlives_its_source(capi, oracle_mod):
     system = "PHN_CZ_SPDAT_LCRC_N1500"
     assert capi.load().lcrc_device_warmup(0) == 0
     assert capi.load().lcrc_device_warmup(4096) == capi.LCRC_E_DEVICE
+    # the PCI address the CLI places a GPU's threads by ("0000:c1:00.0"); a sysfs node of that name exists
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    assert capi.load().lcrc_device_pci_bus_id(0, buf, 64) == 0
+    bus = buf.value.decode().lower()
+    assert len(bus.split(":")) == 3 and os.path.isdir("/sys/bus/pci/devices/" + bus), bus
+    assert capi.load().lcrc_device_pci_bus_id(0, buf, 4) == capi.LCRC_E_ARG
+    assert capi.load().lcrc_device_pci_bus_id(4096, buf, 64) == capi.LCRC_E_DEVICE
     a = capi.Lcrc(model_dir(system), 15)
     a.set_hidden_split(1)
     b = a.clone()
