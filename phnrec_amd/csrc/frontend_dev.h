@@ -29,7 +29,7 @@ hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
 // fixed-shape tree sum; block_off == NULL the reference's sequential sums.
 int meannorm_blocks(int rows);
 hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_off, int n_blocks, float *partial,
-                           int n_utts, int n_rows, int nbanks, float *means, hipStream_t stream);
+                           int n_utts, int n_rows, int nbanks, float *means, int max_utt_rows, hipStream_t stream);
 
 }  // namespace phnrec
 #endif

@@ -174,7 +174,13 @@ constexpr int kMeanSlots = 4;
 constexpr int kMeanSlotFloats = 4352;           // 17 KiB per slot: 272 rows of 15 banks (+ pad), 176 rows of 23
 constexpr int kMeanThreads = 512, kMeanLoaders = kMeanThreads - 64;
 constexpr int kMeanPer = (kMeanSlotFloats + kMeanLoaders - 1) / kMeanLoaders;       // values per loader thread and chunk
-__global__ __launch_bounds__(kMeanThreads) void colmean_kernel(const float *mel, const int *frame_off, int nbanks,
+constexpr int kMeanFuseRows = 2048;             // longest utterance of a launch up to which the means' workgroups subtract too
+// SUBTRACT: the workgroup also subtracts its utterance's mean (x += -mean, srec.cpp:1510) once it has it -- the rows
+// are in its L2 -- and the launch needs no submean_kernel behind it: the form for launches of short utterances (a list's
+// 3-15 s files), where that kernel is one more launch that waits for CUs beside the posterior kernel's workgroups; one
+// long utterance keeps the separate kernel (the whole chip subtracts in 5 us what one CU would in 9).
+template <bool SUBTRACT>
+__global__ __launch_bounds__(kMeanThreads) void colmean_kernel(float *mel, const int *frame_off, int nbanks,
                                                                float *means)
 {
     extern __shared__ float ring[];             // [kMeanSlots][nbanks][RP]
@@ -273,7 +279,32 @@ __global__ __launch_bounds__(kMeanThreads) void colmean_kernel(const float *mel,
         else if (lane < nbanks) adder_step(c + 1);
         __syncthreads();
     }
-    if (wave == 0 && lane < nbanks) means[(size_t)u * nbanks + lane] = sum * (1.0f / (float)rows);
+    const float mean = sum * (1.0f / (float)rows);
+    if (wave == 0 && lane < nbanks) means[(size_t)u * nbanks + lane] = mean;
+    if constexpr (SUBTRACT) {
+        __shared__ float mean_s[64];
+        if (wave == 0 && lane < nbanks) mean_s[lane] = mean;
+        __syncthreads();
+        // element i of the utterance is bank i % nbanks: the bank advances with the thread's stride, no division
+        const int n = rows * nbanks, tid = threadIdx.x;
+        const int step_bb = kMeanThreads % nbanks;
+        float *xw = mel + (size_t)a * nbanks;
+        int b = tid % nbanks;
+        for (int i = tid; i < n; i += 8 * kMeanThreads) {           // eight loads in flight per thread
+            float v[8];
+            int bb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                v[k] = xw[min(i + k * kMeanThreads, n - 1)];
+                bb[k] = b;
+                b += step_bb;
+                if (b >= nbanks) b -= nbanks;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i + k * kMeanThreads < n) xw[i + k * kMeanThreads] = v[k] + -mean_s[bb[k]];
+        }
+    }
 }
 
 // The OPT-IN order of the column sums (lcrc_set_mean_order(ctx, 0)): a FIXED-SHAPE TREE per utterance instead of the
@@ -398,14 +429,18 @@ hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
 int meannorm_blocks(int rows) { return (rows + kMeanBlock - 1) / kMeanBlock; }
 
 hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_off, int n_blocks, float *partial,
-                           int n_utts, int n_rows, int nbanks, float *means, hipStream_t stream)
+                           int n_utts, int n_rows, int nbanks, float *means, int max_utt_rows, hipStream_t stream)
 {
     if (n_utts <= 0 || n_rows <= 0) return hipSuccess;
     if (nbanks > 64) return hipErrorInvalidValue;
     if (block_off == nullptr) {                 // the reference's sequential sums (lcrc_set_mean_order)
         const int R = std::min(((kMeanSlotFloats / nbanks) - 4) & ~15, 1024);
         const size_t lds = (size_t)kMeanSlots * nbanks * (R + 4) * sizeof(float);
-        colmean_kernel<<<n_utts, kMeanThreads, lds, stream>>>(mel, frame_off, nbanks, means);
+        if (max_utt_rows > 0 && max_utt_rows <= kMeanFuseRows) {     // short utterances: means and subtraction in one launch
+            colmean_kernel<true><<<n_utts, kMeanThreads, lds, stream>>>(mel, frame_off, nbanks, means);
+            return hipGetLastError();
+        }
+        colmean_kernel<false><<<n_utts, kMeanThreads, lds, stream>>>(mel, frame_off, nbanks, means);
     } else {
         colmean_block_kernel<<<n_blocks, 256, 0, stream>>>(mel, frame_off, block_off, n_utts, nbanks, partial);
         submean_tree_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>(mel, partial, frame_off, block_off, n_utts, n_rows, nbanks);

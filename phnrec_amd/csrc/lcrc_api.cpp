@@ -1486,9 +1486,12 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
 static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
 {
     const bool copy_post = c->readback || c->dec_P <= 0;
-    if (c->fe.sent_mean_norm)
+    if (c->fe.sent_mean_norm) {
+        int longest = 0;                         // (h_foff: the host copy of this call's frame offsets)
+        for (int u = 0; u < n_utts; u++) longest = std::max(longest, c->h_foff[u + 1] - c->h_foff[u]);
         HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, c->mean_sequential ? nullptr : c->d_foff + n_utts + 1, c->mean_blocks,
-                                   c->d_mean_part, n_utts, rows, c->nbanks, c->d_means, c->stream));
+                                   c->d_mean_part, n_utts, rows, c->nbanks, c->d_means, longest, c->stream));
+    }
     int rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
     rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);

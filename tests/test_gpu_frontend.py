@@ -127,6 +127,14 @@ def test_default_mean_order_is_the_references(capi):
     assert np.array_equal(dflt, seq)
     post, foff = a.wave_to_posteriors([raw[:30000], raw, raw[:100]])
     assert np.array_equal(post[foff[1]:foff[2]], dflt)
+    # launches of short utterances subtract the mean inside the means' own workgroups, launches with a long utterance
+    # (> 2048 frames) keep the separate subtract kernel: the same bits either way
+    long_one = raw * 4
+    post2, foff2 = a.wave_to_posteriors([raw, long_one, raw[:30000]])
+    assert foff2[2] - foff2[1] > 2048
+    assert np.array_equal(post2[foff2[0]:foff2[1]], dflt)
+    alone, _ = a.wave_to_posteriors([long_one])
+    assert np.array_equal(post2[foff2[1]:foff2[2]], alone)
     a.close()
 
 
