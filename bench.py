@@ -490,6 +490,25 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                 out[key] = {"error": repr(e)}
         if isinstance(out.get("gpu_frontend_F"), dict) and "value" in out["gpu_frontend_F"]:
             out["frames_per_s"] = out["gpu_frontend_F"]["value"]
+        if n_gpus > 1:
+            # N GPUs finish the 10 000 files in 0.32 s / N of list loop: at N = 8 that is 40 ms, most of it the ramp until
+            # every context has its first launch -- nothing a scaling curve can be read from.  So beside it: the same files
+            # listed N times (fixed work per GPU, nothing more to generate; the MLF repeats its entries), `-F` and `-F -D`.
+            rep_lst = os.path.join(td, "list_x%d.scp" % n_gpus)
+            with open(rep_lst, "w") as f:
+                for _ in range(n_gpus):
+                    f.write("".join(n + "\n" for n in names))
+            weak = {"files": n_files * n_gpus, "frames": frames * n_gpus,
+                    "what": "the same list with every file listed %d times: fixed work per GPU" % n_gpus}
+            for key, extra in (("gpu_frontend_F", ["-F"]), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+                try:
+                    r, _pr = run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", os.path.join(td, "weak.mlf"), "-g", str(n_gpus)] + extra, env)
+                    weak[key] = r
+                    if "error" not in r and r.get("host_cpu_s", 0) > 0:
+                        weak[key]["host_ceiling_frames_per_s"] = round(frames * n_gpus * cores / r["host_cpu_s"], 1)
+                except Exception as e:
+                    weak[key] = {"error": repr(e)}
+            out["weak_list"] = weak
         # the headline's system (CZ) through the same list and modes (round 3's cli_e2e leg timed a 0.06-0.1 s loop of
         # 2000 files: inside the start-up ramp this list exists to amortise)
         cz_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_CZ_SPDAT_LCRC_N1500")

@@ -553,6 +553,10 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     # the N-rank line carries the sharded-list figure: `phnrec -g 2` over the ranks' GPUs, and the host's ceiling
     sl = line["sharded_list"]
     assert sl["gpus"] == 2 and sl["device_map"] == [0, 0] and sl["files"] == 150
+    # ... and the fixed-work-per-GPU form of the list (every file listed N times)
+    wl = sl["weak_list"]
+    assert wl["files"] == 300 and wl["frames"] == 2 * sl["frames"]
+    assert wl["gpu_frontend_F"]["value"] > 50000 and wl["gpu_frontend_decoder_F_D"]["value"] > 50000
     assert sl["frames_per_s"] > 50000 and sl["host_ceiling"]["frames_per_s"] > 0 and sl["cores_usable"] >= 1
 
 
