@@ -33,24 +33,43 @@ __device__ __forceinline__ float alaw_to_linear(unsigned b)
 template <int FFT>
 __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
 {
-    constexpr int LOG2 = FFT == 256 ? 8 : 9;
-    __shared__ float buf[4][2 * FFT];           // interleaved (re, im) per wave
+    __shared__ __attribute__((aligned(16))) float buf[4][2 * FFT];   // interleaved (re, im) per wave
     __shared__ float pw[4][FFT / 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = blockIdx.x * 4 + wave;
     const bool live = fr < p.n_frames;
     float *d = buf[wave];
 
+    // Eight workgroups fit a CU and each is a chain of dependent steps: the kernel's rate is (workgroups resident) /
+    // (a workgroup's latency).  The search for a frame's utterance was seven or eight DEPENDENT L2 round trips in a
+    // list's launch (36-150 utterances): the offsets now come into LDS with one coalesced load and the search runs there;
+    // the filter weights of the tail's bin sums come along (they were a global load per bin, in a dependent loop).
+    constexpr int kOffLds = 1024;
+    __shared__ int off_s[kOffLds];
+    __shared__ float coef_s[FFT / 2];
+    const bool off_in_lds = p.n_utts + 1 <= kOffLds;
+    if (off_in_lds)
+        for (int i = threadIdx.x; i <= p.n_utts; i += 256) off_s[i] = p.frame_off[i];
+    for (int i = threadIdx.x; i < FFT / 2; i += 256) coef_s[i] = p.coeffs[i];
+    __syncthreads();
     int u = 0, t = 0;
     long long s0 = 0, ns = 0;
     if (live) {
         int lo = 0, hi = p.n_utts;              // largest u with frame_off[u] <= fr
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (p.frame_off[mid] <= fr) lo = mid; else hi = mid;
+        if (off_in_lds) {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off_s[mid] <= fr) lo = mid; else hi = mid;
+            }
+            t = fr - off_s[lo];
+        } else {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (p.frame_off[mid] <= fr) lo = mid; else hi = mid;
+            }
+            t = fr - p.frame_off[lo];
         }
         u = lo;
-        t = fr - p.frame_off[u];
         s0 = p.sample_start[u];
         ns = p.sample_start[p.n_utts + u];      // second half of the array: sample counts
     }
@@ -96,36 +115,82 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
         for (int k = 0; k < FFT / 64; k++) x[k] = d[lane + 64 * k];
         __syncthreads();
     }
-    // ---- window, bit-reversed placement ----
+    // ---- window; the first log2(FFT / 64) Danielson-Lanczos stages in registers ----
+    // A lane's samples i = lane + 64 k land on the R = FFT / 64 CONSECUTIVE bit-reversed positions brev6(lane) * R +
+    // brev(k): the butterflies of the stages with span < R pair values of one lane, and their twiddle index
+    // (position & (span - 1)) is the same in every lane: wave-uniform constants.  Two (FFT 256) or three (512) of the
+    // eight / nine stages need neither LDS nor a wait; twiddle (1, 0) -- the first butterfly of every group -- passes
+    // its operand through as the host front-end does (host/frontend.cpp Fft8: exact up to the sign of a zero).
+    constexpr int R = FFT / 64, LR = R == 4 ? 2 : 3;
+    float re[R], im[R];
 #pragma unroll
-    for (int k = 0; k < FFT / 64; k++) {
+    for (int q = 0; q < R; q++) {
+        constexpr int kRev4[4] = {0, 2, 1, 3}, kRev8[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+        const int k = R == 4 ? kRev4[q & 3] : kRev8[q & 7];
         const int i = lane + 64 * k;
-        const float v = i < vs ? x[k] * p.hamming[i] : 0.0f;
-        const int r = (int)(__brev((unsigned)i) >> (32 - LOG2));
-        d[2 * r] = v;
-        d[2 * r + 1] = 0.0f;
+        re[q] = i < vs ? x[k] * p.hamming[i] : 0.0f;
+        im[q] = 0.0f;
     }
-    __syncthreads();
-    // ---- Danielson-Lanczos stages; twiddle (stage, k) = entry h - 1 + k of the host-built table ----
-#pragma unroll 1
-    for (int h = 1; h < FFT; h <<= 1) {
+#pragma unroll
+    for (int st = 0; st < LR; st++) {
+        const int h = 1 << st;
+#pragma unroll
+        for (int pq = 0; pq < R; pq++) {
+            if (pq & h) continue;
+            const int i = pq, j = pq + h, kk = pq & (h - 1);
+            float tr, ti;
+            if (kk == 0) {
+                tr = re[j];
+                ti = im[j];
+            } else {
+                const double wr = p.twiddle[2 * (h - 1 + kk)], wi = p.twiddle[2 * (h - 1 + kk) + 1];
+                tr = (float)(wr * re[j] - wi * im[j]);
+                ti = (float)(wr * im[j] + wi * re[j]);
+            }
+            re[j] = re[i] - tr;
+            im[j] = im[i] - ti;
+            re[i] += tr;
+            im[i] += ti;
+        }
+    }
+    {
+        const int base = (int)(__brev((unsigned)lane) >> 26) * R;      // brev6(lane) * R
+        float2 *d2 = reinterpret_cast<float2 *>(d);
+#pragma unroll
+        for (int q = 0; q < R; q++) d2[base + q] = make_float2(re[q], im[q]);
+    }
+    // A wave works on its own frame's buffer: between stages only ITS OWN LDS writes must be ordered before its reads
+    // -- the LDS executes a wave's instructions in order; the fence keeps the compiler from reordering them -- so the
+    // workgroup's barriers (eight or nine per frame, each waiting for the slowest of four unrelated waves) are gone.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    wave_sync();
+    // ---- the remaining stages through LDS; twiddle (stage, k) = entry h - 1 + k of the host-built table ----
+    // (fully unrolled: the span is a compile-time constant in every stage -- masks and shifts fold --, and the twiddle's
+    //  index is unsigned so that its load takes a 32-bit offset from the table's scalar base)
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const dbl2 *tw2 = reinterpret_cast<const dbl2 *>(p.twiddle);
+#pragma unroll
+    for (int h = R; h < FFT; h <<= 1) {
+        float2 *d2 = reinterpret_cast<float2 *>(d);
 #pragma unroll
         for (int q = 0; q < FFT / 128; q++) {
             const int bidx = lane + 64 * q;          // butterfly index 0 .. FFT/2-1
             const int k = bidx & (h - 1);
             const int i = ((bidx & ~(h - 1)) << 1) + k;
             const int j = i + h;
-            const double wr = p.twiddle[2 * (h - 1 + k)], wi = p.twiddle[2 * (h - 1 + k) + 1];
-            const float jr = d[2 * j], ji = d[2 * j + 1];
-            const float tr = (float)(wr * jr - wi * ji);
-            const float ti = (float)(wr * ji + wi * jr);
-            const float ir = d[2 * i], ii = d[2 * i + 1];
-            d[2 * j] = ir - tr;
-            d[2 * j + 1] = ii - ti;
-            d[2 * i] = ir + tr;
-            d[2 * i + 1] = ii + ti;
+            const dbl2 w = tw2[(unsigned)(h - 1 + k)];
+            const double wr = w.x, wi = w.y;
+            const float2 vj = d2[j], vi = d2[i];
+            const float tr = (float)(wr * vj.x - wi * vj.y);
+            const float ti = (float)(wr * vj.y + wi * vj.x);
+            d2[j] = make_float2(vi.x - tr, vi.y - ti);
+            d2[i] = make_float2(vi.x + tr, vi.y + ti);
         }
-        __syncthreads();
+        wave_sync();
     }
     // ---- power spectrum, mel filters, ln ----
 #pragma unroll
@@ -144,12 +209,29 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
         // bank b: bins whose falling edge is b (Banks == b) contribute p - v, then bins whose rising
         // edge... i.e. Banks == b + 1 contribute v; both runs are contiguous and in ascending order
         const float *pf = pw[f];
+        const int a0 = p.run_begin[2 * b], a1 = p.run_end[2 * b], c0 = p.run_begin[2 * b + 1], c1 = p.run_end[2 * b + 1];
         float e = 0.0f;
-        for (int i = p.run_begin[2 * b]; i < p.run_end[2 * b]; i++) {
-            const float pp = pf[i], v = p.coeffs[i] * pp;
+        int i = a0;
+        for (; i + 4 <= a1; i += 4) {               // four bins' operands requested together, added in bin order
+            float pp[4], cc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { pp[k] = pf[i + k]; cc[k] = coef_s[i + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const float v = cc[k] * pp[k]; e += (pp[k] - v); }
+        }
+        for (; i < a1; i++) {
+            const float pp = pf[i], v = coef_s[i] * pp;
             e += (pp - v);
         }
-        for (int i = p.run_begin[2 * b + 1]; i < p.run_end[2 * b + 1]; i++) e += p.coeffs[i] * pf[i];
+        i = c0;
+        for (; i + 4 <= c1; i += 4) {
+            float pp[4], cc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { pp[k] = pf[i + k]; cc[k] = coef_s[i + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) e += cc[k] * pp[k];
+        }
+        for (; i < c1; i++) e += coef_s[i] * pf[i];
         // ln in double, rounded once: glibc's logf is correctly rounded in all but rare cases, the
         // device's f32 logf is only good to a few ulp
         p.mel[(size_t)ofr * p.nbanks + b] = e > 0.0f ? (float)log((double)e) : 0.0f;
