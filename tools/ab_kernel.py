@@ -3,7 +3,7 @@
 a few percent, so numbers from separate runs cannot be compared at that level).
 
 usage: ab_kernel.py LIB_A LIB_B [frames]      (paths relative to the repo root; needs a GPU)
-LCRC_ARITH=1 in the environment: both sides on the split-f16 kernels.
+LCRC_ARITH=1 in the environment: both sides on the split-f16 kernels.  AB_UTTS=k: the frames as a batch of k utterances.
 Each library is loaded under its own handle; per system the two are timed alternately (order swapped every
 round), 9 rounds of 100 launches, first round dropped, medians reported.
 """
@@ -38,7 +38,9 @@ class Ctx:
         self.n_out = lib.lcrc_num_outputs(self.h)
 
     def run(self, mel, post, n, stream):
-        assert self.L.lcrc_posteriors_device(self.h, mel.data_ptr(), None, 1, n, post.data_ptr(), stream) == 0
+        off = getattr(self, "d_off", None)        # AB_UTTS=k: a batch of k utterances (offsets resident on the device)
+        assert self.L.lcrc_posteriors_device(self.h, mel.data_ptr(), off.data_ptr() if off is not None else None,
+                                             self.n_utts if off is not None else 1, n, post.data_ptr(), stream) == 0
 
 
 def main():
@@ -54,6 +56,13 @@ def main():
             mdir = "/tmp/ab_model_" + system
             modelgen.write_system(mdir, system, seed=1)
         ctxs = [Ctx(L, mdir, spec["nbanks"]) for L in libs]
+        k = int(os.environ.get("AB_UTTS", "0"))
+        if k > 1:
+            off = torch.tensor(np.linspace(0, n, k + 1).astype(np.int32), device="cuda")
+            for c in ctxs:
+                c.d_off, c.n_utts = off, k
+                c.L.lcrc_set_hidden_split.argtypes = [C.c_void_p, C.c_int]
+                c.L.lcrc_set_hidden_split(c.h, 1)              # as the CLI runs: fused kernels only
         mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
         posts = [torch.empty((n, c.n_out), device="cuda") for c in ctxs]
         for c, p in zip(ctxs, posts):
