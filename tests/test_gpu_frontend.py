@@ -115,6 +115,37 @@ def test_sentence_mean_orders(capi, oracle_mod):
         assert np.abs(p[rows] - ref).max() < 1e-4, seq
 
 
+@pytest.mark.parametrize("system", [CZ, EN])
+def test_sequential_sentence_mean_bit_for_bit(capi, system):
+    """The default sentence mean IS the reference's: column sums added frame by frame in f32 (matrix.h:2101-2116), mean =
+    sum * (1.0f / rows), x += -mean (srec.cpp:1500-1511).  Checked bit for bit through the posterior kernel: the waveform
+    entry's posteriors must EQUAL those of the host-pointer entry fed with the front-end's own features normalised on the
+    host in exactly that order (the posterior kernel is deterministic and, with the fused kernels pinned, batch-invariant,
+    so equal posteriors on every row mean equal normalised features).  Short utterances (the means' workgroups subtract
+    themselves), a long one (separate subtract kernel), a batch; 15 banks and -- the EN system with the normalisation
+    switched on -- 23."""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ctx = _ctx(capi, system, sent_mean_norm=True)
+    ctx.set_hidden_split(1)
+    blobs = [raw, raw[:20000], raw * 6, raw[:1000]]
+    mel, foff = ctx.wave_to_mel(blobs)                        # un-normalised features, as `-t par` dumps them
+    assert foff[3] - foff[2] > 2048
+    norm = np.empty_like(mel)
+    for u in range(len(blobs)):
+        x = mel[foff[u]:foff[u + 1]]
+        total = np.add.accumulate(x, axis=0, dtype=np.float32)[-1]          # sequential f32 sums, frame by frame
+        mean = total * (np.float32(1.0) / np.float32(len(x)))
+        norm[foff[u]:foff[u + 1]] = x + (-mean)
+    want = ctx.posteriors_batch(norm, np.asarray(foff, np.int32))
+    got, foff2 = ctx.wave_to_posteriors(blobs)
+    assert list(foff2) == list(foff)
+    assert np.array_equal(got, want)
+    for u in (0, 2):                                          # ... and alone
+        one, _ = ctx.wave_to_posteriors([blobs[u]])
+        assert np.array_equal(one, want[foff[u]:foff[u + 1]])
+    ctx.close()
+
+
 def test_default_mean_order_is_the_references(capi):
     """a fresh context sums the sentence mean in the reference's sequential order (ABI 2): identical bits to an
     explicit lcrc_set_mean_order(1), and batch-invariant"""
