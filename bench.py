@@ -564,6 +564,35 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                     ceil["decoder_only_sample"] = "%d posterior dumps: `phnrec -s post` (HTK read + Viterbi + MLF), no GPU" % sub
         except Exception as e:
             ceil["decoder_only_error"] = repr(e)
+        # ---- ... and what the pipeline's SERIAL per-file work allows ----
+        # CPU seconds say what the cores must deliver in sum; the feeder, the window's lock and the in-order writer handle
+        # every file one after the other.  Files so short that the GPU has next to nothing to do (0.25 s = 23 frames)
+        # measure that: files per second of the `-F` pipeline, times this list's frames per file = the frame rate the
+        # serial part could feed with configs[3]'s files.
+        try:
+            tiny = 20000
+            sig = np.clip(np.random.default_rng(5).normal(0, 3000, 2000), -32768, 32767).astype("<i2")
+            tdir = os.path.join(td, "tiny")
+            os.mkdir(tdir)
+            tnames = []
+            for i in range(tiny):
+                pth = os.path.join(tdir, "s%05d.raw" % i)
+                sig.tofile(pth)
+                tnames.append(pth)
+            tl = os.path.join(td, "tiny.scp")
+            with open(tl, "w") as f:
+                f.write("".join(x + "\n" for x in tnames))
+            best = None
+            for _ in range(2):
+                r, _pr = run_cli(exe, ["-c", mdir, "-l", tl, "-m", os.path.join(td, "tiny.mlf"), "-g", str(n_gpus), "-F"], env)
+                if "error" not in r and (best is None or r["list_wall_s"] < best["list_wall_s"]):
+                    best = r
+            if best:
+                fps = tiny / best["list_wall_s"]
+                ceil["per_file_serial"] = {"files_per_s": round(fps, 1), "frames_per_s_at_this_lists_file_length": round(fps * frames / n_files, 1),
+                                           "sample": "%d files of 0.25 s (23 frames), -F: list loop %.3f s" % (tiny, best["list_wall_s"])}
+        except Exception as e:
+            ceil["per_file_serial_error"] = repr(e)
         out["host_ceiling"] = ceil
     return out
 

@@ -532,6 +532,7 @@ def test_bench_line_carries_every_leg():
     assert sl["files"] == 120 and sl["gpus"] == 1 and sl["frames_per_s"] > 50000 and sl["mlf_F_equals_F_D"] is True
     assert sl["host_ceiling"]["frames_per_s"] > 0 and sl["host_ceiling"]["gpu_frontend_F"]["host_cpu_s"] > 0
     assert sl["cz_same_list"]["host_frontend"]["value"] > 50000 and sl["cz_same_list"]["gpu_frontend_F"]["value"] > 50000
+    assert sl["host_ceiling"]["per_file_serial"]["files_per_s"] > 20000      # (round 3's pipeline: 80 k on these hosts; now ~400 k)
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
