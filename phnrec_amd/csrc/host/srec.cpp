@@ -1190,6 +1190,7 @@ bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string
     if (!mlf_path.empty()) {
         mlf = fopen(mlf_path.c_str(), "w");
         if (!mlf) { fclose(fl); return Fail("Can not create the MLF: " + mlf_path + "\n"); }
+        setvbuf(mlf, nullptr, _IOFBF, 1 << 20);      // entries leave under the pipeline's lock: a write() per MB, not per 4 KB
         fprintf(mlf, "#!MLF!#\n");
     }
     char buf[1024];
