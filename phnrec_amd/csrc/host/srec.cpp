@@ -845,7 +845,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     long long files_done = 0, frames_done = 0;
     // CPU time the host stages take, summed over the threads that run them (what the cores must deliver however
     // fast the GPUs are: PHNREC_STATS prints it, bench.py derives the host ceiling of a list from it)
-    std::atomic<long long> stage1_us(0), read_us(0), gather_us(0), stage3_us(0);
+    std::atomic<long long> stage1_us(0), read_us(0), gather_us(0), stage3_us(0), stage1_jobs(0);
     struct CpuTimer {
         std::atomic<long long> &acc;
         long long t0;
@@ -883,6 +883,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             CpuTimer tm(stage1_us);
             for (Item *it : its) Stage1(in, out, it->job);
         }
+        stage1_jobs += (long long)its.size();
         std::lock_guard<std::mutex> l(mu);
         for (Item *it : its) {
             pending1--;
@@ -1094,8 +1095,17 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // ---- feeder ----
     // Jobs whose stage 1 is next to nothing (-F: a stat(); the file is read when its launch is assembled) go to the pool
     // in chunks; the others one by one (a file's read + front-end is a task worth a thread by itself).
-    const size_t chunk_max = need_gpu && gpu_frontend_ && in == dfWaveform && !single_file ? 32 : 1;
-    const int max_pending_jobs = max_pending * (int)chunk_max;
+    // (the others too once their measured stage 1 turns out short -- lists of very short files: a chunk is sized to ~200 us)
+    const bool cheap_stage1 = need_gpu && gpu_frontend_ && in == dfWaveform;
+    auto chunk_max = [&]() -> size_t {
+        if (single_file) return 1;
+        if (cheap_stage1) return 32;
+        const long long jobs = stage1_jobs.load();
+        if (jobs < 64) return 1;
+        const long long avg_ns = stage1_us.load() / jobs;
+        return (size_t)std::max<long long>(1, std::min<long long>(32, 200000 / std::max<long long>(1, avg_ns)));
+    };
+    const int max_pending_jobs = max_pending * 32;
     std::vector<Item *> chunk;
     auto flush_chunk = [&]() {
         if (chunk.empty()) return;
@@ -1139,7 +1149,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             pending1++;
         }
         chunk.push_back(raw);
-        if (chunk.size() >= chunk_max) flush_chunk();
+        if (chunk.size() >= chunk_max()) flush_chunk();
     }
     flush_chunk();                                     // (also behind an error: every job in the window gets its stage 1)
     {
