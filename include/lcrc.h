@@ -283,6 +283,14 @@ int lcrc_set_timing(lcrc_ctx *ctx, int enabled);
  * noticed up to n (plus the timer's slack) late.  For callers that keep more contexts in flight -- a thread each -- than
  * they have cores to burn: the CLI switches to it when its contexts outnumber half of the usable cores. */
 int lcrc_set_wait_mode(lcrc_ctx *ctx, int poll_interval_us);
+/* Optional notification for callers that keep several contexts in flight on one GPU: fn(arg) is called on the CALLING
+ * thread, once per host-pointer / staged / waveform entry-point call that launches, as soon as the posterior kernel(s) of
+ * that call have finished on the device -- while the call's decoder launch and copy-back may still be running -- and
+ * before the call returns.  (The CLI admits a limited number of its contexts' launches to a GPU at a time; it releases a
+ * launch's slot here, so that the next context's kernels start while this one's labels / posteriors travel back.)
+ * fn = NULL switches it off.  Not called when a call launches nothing or fails before its launch. */
+typedef void (*lcrc_kernel_done_fn)(void *arg);
+int lcrc_set_kernel_done_callback(lcrc_ctx *ctx, lcrc_kernel_done_fn fn, void *arg);
 /* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
  * (tuning and test hook; results are bit-identical either way) */
 int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);

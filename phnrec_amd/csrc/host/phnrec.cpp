@@ -29,7 +29,7 @@ static void Help()
     puts(" -p num [-3.8]      phoneme insertion penalty");
     puts(" -v                 verbose");
     puts(" -g num [1]         number of GPUs to spread a file list over (MI355X build)");
-    puts(" -b num [32768]     frames per GPU launch when batching a file list (65536 with -D)");
+    puts(" -b num [32768]     frames per GPU launch when batching a file list");
     puts(" -j num [all]       host threads for the front-end and the decoder");
     puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
     puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)");
@@ -135,7 +135,6 @@ int main(int argc, char **argv)
     if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
-    else if (gpu_dec) SR.SetBatchFrames(65536);      // the decoder is sequential per utterance: more of them per launch
     if (threads > 0) SR.SetHostThreads(threads);
     SR.SetGpuFrontend(gpu_fe);
     SR.SetGpuDecoder(gpu_dec);

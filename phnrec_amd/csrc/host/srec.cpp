@@ -971,10 +971,25 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         Traps &tr = *gpus_[g];
         const int device = gpu_devices_[(size_t)(g % n_log)];
         DeviceSlots *slots = dev_slots.count(device) ? dev_slots[device].get() : nullptr;
-        struct SlotHold {                       // one launch's stay on the device
+        // One launch's stay on the device: from its admission until its posterior kernels are done -- the library says
+        // so (lcrc_set_kernel_done_callback) while the launch's decoder kernel, labels and posteriors are still on their
+        // way: the next context's kernels start meanwhile.  (Released at the latest when the call has returned.)
+        struct SlotHold {
             DeviceSlots *s;
-            explicit SlotHold(DeviceSlots *x) : s(x) { if (s) s->Acquire(); }
-            ~SlotHold() { if (s) s->Release(); }
+            Traps &t;
+            const bool registered;
+            SlotHold(DeviceSlots *x, Traps &tr) : s(x), t(tr), registered(x != nullptr)
+            {
+                if (!s) return;
+                s->Acquire();
+                t.SetKernelDoneCallback([](void *self) { static_cast<SlotHold *>(self)->Leave(); }, this);
+            }
+            void Leave() { if (s) { s->Release(); s = nullptr; } }
+            ~SlotHold()
+            {
+                if (registered) t.SetKernelDoneCallback(nullptr, nullptr);
+                Leave();
+            }
         };
         if (!single_file) PinToGpuNode(device);
         std::vector<Item *> items;
@@ -1048,7 +1063,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                 }
                 foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
                 {
-                    SlotHold hold(slots);
+                    SlotHold hold(slots, tr);
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
                 }
                 h_post = tr.StagedPosteriors();
@@ -1062,7 +1077,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     std::vector<float>().swap(j.mel);
                 }, frame_grain(cnt, 2LL * off.back()));
                 {
-                    SlotHold hold(slots);
+                    SlotHold hold(slots, tr);
                     if (!tr.StageRun(off.data(), cnt)) { abort_run(tr.LastError()); return; }
                 }
                 foff = off;

@@ -65,6 +65,8 @@ public:
     void SetHiddenSplit(int v) { hidden_split_ = v; if (ctx_) lcrc_set_hidden_split(ctx_, v); }
     // 0: the calling thread spins while the device works; n: it sleeps, looking every n microseconds (lcrc_set_wait_mode)
     void SetWaitMode(int poll_us) { if (ctx_) lcrc_set_wait_mode(ctx_, poll_us); }
+    // fn(arg) on the calling thread as soon as a call's posterior kernels are done (lcrc_set_kernel_done_callback)
+    void SetKernelDoneCallback(lcrc_kernel_done_fn fn, void *arg) { if (ctx_) lcrc_set_kernel_done_callback(ctx_, fn, arg); }
     // lcrc_set_arithmetic: false when the model has no split-f16 form (LastError() says why)
     bool SetArithmetic(int a)
     {

@@ -126,6 +126,10 @@ struct lcrc_ctx {
     int poll_wait_us = 0;                // lcrc_set_wait_mode: 0 = spin in hipStreamSynchronize, > 0 = sleep between completion queries
     hipEvent_t ev_wait = nullptr;
     hipEvent_t ev_piece[8] = {};         // copy_back's pieces
+    lcrc_kernel_done_fn kdone_fn = nullptr;      // lcrc_set_kernel_done_callback
+    void *kdone_arg = nullptr;
+    hipEvent_t ev_kdone = nullptr;
+    bool kdone_armed = false;            // an event behind this call's posterior kernels is recorded and not yet reported
     // posterior writer path
     lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     int out_be = 0;
@@ -448,6 +452,16 @@ hipError_t wait_event(lcrc_ctx *c, hipEvent_t ev)
     }
 }
 
+// the caller learns that its posterior kernels are done (the rest of the call -- decoder, copies -- is queued behind them)
+hipError_t report_kernel_done(lcrc_ctx *c)
+{
+    if (!c->kdone_armed) return hipSuccess;
+    c->kdone_armed = false;
+    hipError_t e = wait_event(c, c->ev_kdone);
+    if (e == hipSuccess && c->kdone_fn) c->kdone_fn(c->kdone_arg);
+    return e;
+}
+
 // Device -> caller's (pageable) buffer through the pinned staging buffer: the copy engine moves piece k + 1 while the
 // host copies piece k out, instead of one DMA followed by one memcpy of the whole (4.5 MB of posteriors for 8192 CZ
 // frames: 90 us + 80 us).  Pieces of >= 512 KiB, at most four (lcrc_posteriors of 8192 CZ frames, median of 60 calls on
@@ -456,6 +470,7 @@ hipError_t wait_event(lcrc_ctx *c, hipEvent_t ev)
 constexpr int kCopyPieces = 4;           // <= lcrc_ctx::ev_piece
 hipError_t copy_back(lcrc_ctx *c, float *dst, float *pinned, const float *dev, size_t nbytes)
 {
+    // (the kernel-done report comes after the copies have been queued: the copy engine starts behind the kernel either way)
     int pieces = (int)std::min<size_t>(kCopyPieces, nbytes / (512u << 10));
     if (!dst || pieces < 2) {
         hipError_t e = hipMemcpyAsync(pinned, dev, nbytes, hipMemcpyDeviceToHost, c->stream);
@@ -474,6 +489,10 @@ hipError_t copy_back(lcrc_ctx *c, float *dst, float *pinned, const float *dev, s
         if (e == hipSuccess) e = hipEventRecord(c->ev_piece[k], c->stream);
         if (e != hipSuccess) return e;
     }
+    {
+        hipError_t e = report_kernel_done(c);
+        if (e != hipSuccess) return e;
+    }
     for (int k = 0; k < pieces; k++) {
         hipError_t e = wait_event(c, c->ev_piece[k]);
         if (e != hipSuccess) return e;
@@ -485,6 +504,10 @@ hipError_t copy_back(lcrc_ctx *c, float *dst, float *pinned, const float *dev, s
 
 hipError_t wait_stream(lcrc_ctx *c)
 {
+    {
+        hipError_t e = report_kernel_done(c);    // (a no-op unless a launch of this call armed it)
+        if (e != hipSuccess) return e;
+    }
     if (c->poll_wait_us <= 0) return hipStreamSynchronize(c->stream);
     hipError_t e = hipSuccess;
     if (!c->ev_wait) e = hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming);
@@ -681,6 +704,17 @@ void ensure_split_scratch(lcrc_ctx *c)
 
 // Rows [row_first, row_first + row_count) of the n_rows rows are computed (row_count < 0: all of them);
 // d_post receives row_first's posteriors first.
+// lcrc_set_kernel_done_callback: an event behind the posterior kernels of the current call; reported by
+// report_kernel_done() once everything else of the call has been queued
+int arm_kernel_done(lcrc_ctx *c, hipStream_t s)
+{
+    if (!c->kdone_fn) return LCRC_OK;
+    if (!c->ev_kdone) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kdone, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_kdone, s));
+    c->kdone_armed = true;
+    return LCRC_OK;
+}
+
 int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
            hipStream_t s, float *const *dbg, int row_first = 0, int row_count = -1, bool timed = true)
 {
@@ -689,7 +723,9 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
         if (dbg) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
         if (row_first != 0 || row_count != n_rows)
             return fail(c, LCRC_E_UNSUPPORTED, "row ranges exist for posteriors/system=LCRC only");
-        return launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
+        int rc = launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
+        if (rc == LCRC_OK) rc = arm_kernel_done(c, s);
+        return rc;
     }
     if (row_count == 0) return LCRC_OK;
     // (the scratch's clears run on the context's stream: a launch on another stream waits for them once)
@@ -716,7 +752,7 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, s));
     HIP_TRY(c, lcrc_launch(p, s, nullptr));
     if (timed) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
-    return LCRC_OK;
+    return arm_kernel_done(c, s);
 }
 
 // Decoder behind the posterior kernel: labels and counts are copied to pinned memory on the same stream.
@@ -1228,6 +1264,7 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     for (hipEvent_t e : c->ev_piece) if (e) (void)hipEventDestroy(e);
+    if (c->ev_kdone) (void)hipEventDestroy(c->ev_kdone);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1351,7 +1388,9 @@ int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, in
     if (n_rows == 0) return LCRC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // NULL = HIP's default stream
-    return launch(c, d_mel, d_off, n_utts, n_rows, d_post, s, nullptr);
+    const int rc = launch(c, d_mel, d_off, n_utts, n_rows, d_post, s, nullptr);
+    c->kdone_armed = false;          // asynchronous entry: nobody waits here, lcrc_set_kernel_done_callback does not apply
+    return rc;
 }
 
 // ---- waveform entry: GPU mel-bank front-end ------------------------------------------------
@@ -1843,6 +1882,15 @@ int lcrc_debug_set_stamps(lcrc_ctx *c, void *d_buf)
     return LCRC_OK;
 }
 #endif
+
+int lcrc_set_kernel_done_callback(lcrc_ctx *c, lcrc_kernel_done_fn fn, void *arg)
+{
+    if (!c) return LCRC_E_ARG;
+    c->kdone_fn = fn;
+    c->kdone_arg = arg;
+    c->kdone_armed = false;
+    return LCRC_OK;
+}
 
 int lcrc_set_wait_mode(lcrc_ctx *c, int poll_interval_us)
 {

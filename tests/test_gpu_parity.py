@@ -841,6 +841,40 @@ def test_other_posterior_systems(capi, oracle_mod, tmp_path):
         capi.Lcrc(d, 16, system="3BT")
 
 
+def test_kernel_done_callback(capi, tmp_path):
+    """lcrc_set_kernel_done_callback: fn(arg) on the calling thread, once per call that launches, before the call returns
+    (host-pointer, batch, staged and streaming entries; not for calls that launch nothing; off again with NULL)"""
+    import ctypes as C
+    d = str(tmp_path / "m")
+    modelgen.write_model_dir(d, 15, 64, 138, seed=3)
+    ctx = capi.Lcrc(d, 15)
+    L = ctx.L
+    calls = []
+    FN = C.CFUNCTYPE(None, C.c_void_p)
+    fn = FN(lambda arg: calls.append(arg))
+    L.lcrc_set_kernel_done_callback.argtypes = [C.c_void_p, FN, C.c_void_p]
+    assert L.lcrc_set_kernel_done_callback(ctx.h, fn, C.c_void_p(7)) == 0
+    mel = modelgen.synth_mel(5000, 15, seed=1)
+    a = ctx.posteriors(mel)                                   # copy-back in pieces (2.7 MB)
+    assert calls == [7]
+    ctx.posteriors(mel[:40])                                  # small: the plain copy-back
+    off = np.array([0, 100, 100, 900], np.int32)
+    ctx.posteriors_batch(mel[:900], off)
+    ctx.posteriors_staged(mel[:900], off)
+    assert calls == [7, 7, 7, 7]
+    ctx.posteriors_batch(mel[:0], np.array([0, 0], np.int32))  # nothing to launch: no call
+    assert len(calls) == 4
+    ctx.reset()
+    ctx.push(mel[:31], needed=False)                          # history only: no launch
+    assert len(calls) == 4
+    ctx.push(mel[31:36])
+    assert len(calls) == 5
+    assert L.lcrc_set_kernel_done_callback(ctx.h, FN(0), None) == 0
+    b = ctx.posteriors(mel)
+    assert len(calls) == 5 and np.array_equal(a, b)
+    ctx.close()
+
+
 def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
     """lcrc_decoder_configure ("next" row f3): the PhnDec kernel behind the posterior kernel against the
     decoder oracle run on the SAME log-posteriors (bit-identical labels, times and scores: both do the same
