@@ -309,6 +309,33 @@ def test_host_pipeline_under_thread_sanitizer(tmp_path):
     assert mlf.read_text() == "#!MLF!#\n" + "".join(entries[n] for n in order)
 
 
+def test_list_pipeline_many_settings_no_hang(tmp_path):
+    """The pipeline (feeder with chunked stage 1, LIFO pool whose callers work along, workers, in-order writer) under 24
+    combinations of pool size and launch size, each run under a timeout: every run ends, with the same MLF.  (A lost
+    wake-up shows as a hang, not as a wrong answer: hence the timeout.)"""
+    data = tmp_path / "d"
+    data.mkdir()
+    rng = np.random.default_rng(3)
+    lines = []
+    for i in range(120):
+        n = ("utt_a", "utt_b", "utt_c")[int(rng.integers(0, 3))]
+        sub = data / ("%03d" % i)
+        sub.mkdir()
+        shutil.copyfile(os.path.join(GOLD, "cli", n + ".lop"), sub / (n + ".lop"))
+        lines.append("%s\n" % (sub / (n + ".lop")))
+    lst = tmp_path / "list.txt"
+    lst.write_text("".join(lines))
+    first = None
+    for k in range(24):
+        mlf = tmp_path / ("o%d.mlf" % (k % 2))
+        p = subprocess.run([BIN, "-c", model_dir(CZ), "-s", "post", "-l", str(lst), "-m", str(mlf), "-j", str(k % 8 + 1),
+                            "-b", str((k % 5) * 700 + 100)], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        text = mlf.read_text()
+        first = first or text
+        assert text == first
+
+
 @pytest.mark.parametrize("P,S,prune", [(5, 1, 40), (17, 2, 12), (40, 3, 40), (62, 3, 40), (33, 4, 25), (64, 3, 7), (8, 3, 40),
                                        (16, 3, 40), (47, 3, 3), (61, 3, 40)])
 def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, S, prune):
