@@ -466,7 +466,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         return {"error": "CLI or %s model directory missing" % HU}
     cores = usable_cpus()
     out = {"system": HU, "files": n_files, "gpus": n_gpus, "device_map": dmap, "cores_usable": cores,
-           "what": "phnrec -c HU -l list -m out.mlf -g N (PHNREC_DEVICE_MAP = the ranks' GPUs): raw lin16 8 kHz files of "
+           "what": "phnrec -c HU -l list -m out.mlf -g N [-E | -F | -F -D] (PHNREC_DEVICE_MAP = the ranks' GPUs): raw lin16 8 kHz files of "
                    "3-15 s -> MLF on disk; frames/s of the list loop as the CLI reports it (process start-up and model load "
                    "excluded; process_wall_s includes them)"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -474,7 +474,8 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         out["frames"] = frames
         env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=",".join(str(d) for d in dmap))
         mlfs = {}
-        for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"]), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+        for key, extra in (("host_frontend", []), ("gpu_energies_E", ["-E"]), ("gpu_frontend_F", ["-F"]),
+                           ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
             mlf = os.path.join(td, key + ".mlf")
             try:
                 best = None
@@ -525,6 +526,8 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             a, b = open(mlfs["gpu_frontend_F"]).read(), open(mlfs["gpu_frontend_decoder_F_D"]).read()
             out["mlf_F_equals_F_D"] = a == b
             out["mlf_entries"] = a.count('"\n') if a else 0
+            # -E's features are the host front-end's bit for bit: so is its MLF
+            out["mlf_E_equals_host_frontend"] = open(mlfs["gpu_energies_E"]).read() == open(mlfs["host_frontend"]).read()
         except Exception:
             pass
         # ---- what the host alone can do on this list ----
@@ -535,7 +538,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                         "file reads into pinned memory, gather, host Viterbi, label / MLF formatting -- summed over the "
                         "pool's threads); the rate the host side of `phnrec -g N` cannot exceed on this box however many "
                         "GPUs serve it"}
-        for key in ("host_frontend", "gpu_frontend_F", "gpu_frontend_decoder_F_D"):
+        for key in ("host_frontend", "gpu_energies_E", "gpu_frontend_F", "gpu_frontend_decoder_F_D"):
             r = out.get(key)
             if isinstance(r, dict) and r.get("host_cpu_s", 0) > 0:
                 ceil[key] = {"frames_per_s": round(frames * cores / r["host_cpu_s"], 1), "host_cpu_s": r["host_cpu_s"],

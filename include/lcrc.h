@@ -210,6 +210,16 @@ int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const lon
 int lcrc_wave_stage_buffer(lcrc_ctx *ctx, long long capacity, unsigned char **bytes);
 int lcrc_wave_stage_run(lcrc_ctx *ctx, const long long *start, const long long *n_bytes, int n_utts,
                         float *post, int *frame_off);
+/* The front-end's arithmetic up to the mel-bank ENERGIES on the GPU, everything behind them left to the caller: the
+ * utterances in the wave stage buffer (as for lcrc_wave_stage_run) go through decode, window, FFT, power spectrum and the
+ * bank sums -- the reference's operations in the reference's order (melbanks.cpp:111-149, dspc.cpp:24-78,236-269), so the
+ * energies equal the host front-end's bit for bit -- and come back in the context's pinned feature buffer, *energies =
+ * [rows][nbanks] (the buffer lcrc_stage_buffers hands out, with room for the posteriors reserved too).  The caller takes
+ * ln() with ITS libm (dspc.h:155-160: x > 0 ? logf(x) : 0), applies framenorm / offlinenorm in place and calls
+ * lcrc_stage_run(frame_off, n_utts): features, and therefore posteriors, identical to a host front-end's at a tenth of
+ * its CPU time (the FFTs are 90 % of it).  No sentence normalisation happens here, whatever lcrc_frontend_configure said. */
+int lcrc_wave_stage_energies(lcrc_ctx *ctx, const long long *start, const long long *n_bytes, int n_utts, float **energies,
+                             int *frame_off);
 /* post == NULL in lcrc_wave_stage_run leaves the posteriors in the context's pinned output buffer: this
  * returns it (rows as in frame_off; valid until the next call on the context) */
 int lcrc_staged_posteriors(lcrc_ctx *ctx, const float **post);

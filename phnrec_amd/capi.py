@@ -19,7 +19,7 @@ SYMBOLS = [
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
-    "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_staged_posteriors",
+    "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_kernel_done_callback", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",

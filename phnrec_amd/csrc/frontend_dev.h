@@ -21,6 +21,7 @@ struct FrontendParams {
     int vector_size, vector_step;
     float dc_shift, scale, preem_coef;
     int z_mean_source;
+    int raw_energies;             // 1: store the mel-bank energies themselves (the caller takes the logarithm: lcrc_wave_stage_energies)
 };
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
         for (; i < c1; i++) e += coef_s[i] * pf[i];
         // ln in double, rounded once: glibc's logf is correctly rounded in all but rare cases, the
         // device's f32 logf is only good to a few ulp
-        p.mel[(size_t)ofr * p.nbanks + b] = e > 0.0f ? (float)log((double)e) : 0.0f;
+        p.mel[(size_t)ofr * p.nbanks + b] = p.raw_energies ? e : (e > 0.0f ? (float)log((double)e) : 0.0f);
     }
 }
 

@@ -32,6 +32,8 @@ static void Help()
     puts(" -b num [32768]     frames per GPU launch when batching a file list");
     puts(" -j num [all]       host threads for the front-end and the decoder");
     puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
+    puts(" -E                 the front-end's FFTs and bank sums on the GPU, ln() and the normalisations on the host:\n"
+         "                    the host front-end's features bit for bit, at a tenth of its CPU time");
     puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)");
     puts(" -H                 split-f16 arithmetic: f32 products as three exact f16 MFMA products (2x the kernel rate,\n"
          "                    same distance to the reference; shipped LCRC systems)\n");
@@ -79,7 +81,7 @@ int main(int argc, char **argv)
     const auto t_main = std::chrono::steady_clock::now();
     const char *config_dir = nullptr, *file_list = nullptr, *input_file = nullptr, *output_file = nullptr;
     const char *output_mlf = nullptr, *wpenalty = nullptr;
-    bool live = false, verbose = false, gpu_fe = false, gpu_dec = false, split_f16 = false;
+    bool live = false, verbose = false, gpu_fe = false, gpu_en = false, gpu_dec = false, split_f16 = false;
     int gpus = 1, batch = 0, threads = 0;
     DataFormat iformat = dfWaveform, oformat = dfStrings;
     WaveFormat wformat = WF_UNKNOWN;
@@ -88,7 +90,7 @@ int main(int argc, char **argv)
     int ind = 0;
     for (;;) {
         const char *arg = nullptr;
-        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:FDH", ind, arg);
+        const int c = NextOpt(argc, argv, "-c:l:i:o:m:as:t:w:f:p:vg:b:j:FEDH", ind, arg);
         if (c == -1) break;
         switch (c) {
         case 'c': config_dir = arg; break;
@@ -119,6 +121,7 @@ int main(int argc, char **argv)
         case 'b': batch = atoi(arg); break;
         case 'j': threads = atoi(arg); break;
         case 'F': gpu_fe = true; break;
+        case 'E': gpu_en = true; break;
         case 'D': gpu_dec = true; break;
         case 'H': split_f16 = true; break;
         case '?': Die("Error during command line parsing\n");
@@ -136,7 +139,9 @@ int main(int argc, char **argv)
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
     if (threads > 0) SR.SetHostThreads(threads);
+    if (gpu_fe && gpu_en) Die("-F and -E are two forms of the GPU front-end: give one\n");
     SR.SetGpuFrontend(gpu_fe);
+    SR.SetGpuEnergies(gpu_en);
     SR.SetGpuDecoder(gpu_dec);
     SR.SetSplitF16(split_f16);
     if (!SR.Init(std::string(config_dir) + "/config")) Die(SR.LastError());

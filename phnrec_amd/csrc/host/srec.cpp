@@ -378,8 +378,8 @@ SpeechRec::~SpeechRec()
 std::string SpeechRec::SetUpContext(Traps &t)
 {
     if (split_f16_ && !t.SetArithmetic(LCRC_ARITH_SPLIT_F16)) return t.LastError() + "\n";
-    if (gpu_frontend_) {
-        if (wave_.noise_level != 0.0f) return "source/noise_level needs the host front-end (libc rand()); drop -F\n";
+    if (gpu_frontend_ || gpu_energies_) {
+        if (wave_.noise_level != 0.0f) return "source/noise_level needs the host front-end (libc rand()); drop -F / -E\n";
         lcrc_frontend fe;
         fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
         fe.sample_freq = C.GetInt("source", "sample_freq");
@@ -392,10 +392,13 @@ std::string SpeechRec::SetUpContext(Traps &t)
         fe.scale = wave_.scale;
         fe.dc_shift = wave_.dc_shift;
         fe.z_mean_source = C.GetBool("melbanks", "z_mean_source") ? 1 : 0;
-        fe.sent_mean_norm = sent_mean_norm_ ? 1 : 0;
-        if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
-            return "framenorm/* needs the host front-end; drop -F\n";
-        if (sent_max_norm_ || sent_chmax_norm_) return "offlinenorm/sent_max_norm and sent_chmax_norm need the host front-end; drop -F\n";
+        fe.sent_mean_norm = sent_mean_norm_ && !gpu_energies_ ? 1 : 0;      // (-E: every normalisation runs on the host)
+        if (!gpu_energies_) {
+            if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
+                return "framenorm/* needs the host front-end; drop -F (or use -E)\n";
+            if (sent_max_norm_ || sent_chmax_norm_)
+                return "offlinenorm/sent_max_norm and sent_chmax_norm need the host front-end; drop -F (or use -E)\n";
+        }
         if (!t.ConfigureFrontend(fe)) return t.LastError() + "\n";
     }
     return std::string();
@@ -479,7 +482,7 @@ static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
 void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
 {
     char msg[1200];
-    if (in == dfWaveform && gpu_frontend_ && out != dfParams) {
+    if (in == dfWaveform && (gpu_frontend_ || gpu_energies_) && out != dfParams) {
         // -F: only the size is needed to plan the launches; the GPU worker reads the file straight into
         // its context's pinned byte buffer
         struct stat st;
@@ -795,7 +798,9 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // From four GPUs on: two -- on one GPU the third is worth 0-2 %, while every context costs ~10 ms of start-up that
         // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
         // list that eight GPUs finish in a tenth of a second are a loss.
-        if (!EnsureGpus(single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3)) return false;
+        // (-E has two device phases per launch with the host's ln() between them: one context more keeps the GPU fed,
+        //  25.4 -> 26.7 M frames/s on one GPU)
+        if (!EnsureGpus(single_file ? 1 : (std::max(1, n_gpus_) >= 4 ? 2 : 3) + (gpu_energies_ ? 1 : 0))) return false;
     }
     if (need_gpu && !single_file && pool_->Size() > 0) {
         cpu_set_t all, one;
@@ -1020,7 +1025,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             const auto l0 = clock::now();
             const float *h_post = nullptr;
             std::vector<int> foff;
-            if (gpu_frontend_ && in == dfWaveform) {
+            if ((gpu_frontend_ || gpu_energies_) && in == dfWaveform) {
                 // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the three nets all run
                 // on the device; the files go straight into the context's pinned byte buffer (read in parallel)
                 std::vector<long long> bstart(cnt), blen(cnt);
@@ -1062,11 +1067,35 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     off.resize((size_t)b + 1);
                 }
                 foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
-                {
+                if (gpu_energies_) {
+                    // -E: the GPU stops at the mel-bank energies (bit for bit the host front-end's); ln() with this host's
+                    // libm and the normalisations follow here, in the pinned buffer the posterior kernel then reads in place
+                    float *feat = nullptr;
+                    if (!tr.WaveStageEnergies(bstart.data(), blen.data(), cnt, &feat, foff.data())) { abort_run(tr.LastError()); return; }
+                    if (foff[cnt] > 0) {
+                        const float shift = C.GetFloat("framenorm", "shift"), floor_ = C.GetFloat("framenorm", "min_floor");
+                        pool_->ParallelFor(cnt, [&](int k) {
+                            CpuTimer tm(stage1_us);
+                            float *x = feat + (size_t)foff[k] * nbanks_;
+                            const int fr = foff[k + 1] - foff[k];
+                            const size_t nv = (size_t)fr * nbanks_;
+                            for (size_t i = 0; i < nv; i++) x[i] = x[i] > 0.0f ? logf(x[i]) : 0.0f;      // sLn, dspc.h:155-160
+                            if (shift != 0.0f) for (size_t i = 0; i < nv; i++) x[i] += shift;            // srec.cpp:1594-1620
+                            if (floor_ != -9999.9f) for (size_t i = 0; i < nv; i++) if (x[i] < floor_) x[i] = floor_;
+                            if (fr > 0 && sent_mean_norm_) SentenceMeanNorm(x, fr, nbanks_);
+                            if (fr > 0 && (sent_max_norm_ || sent_chmax_norm_)) SentenceMaxNorm(x, fr, nbanks_, sent_max_norm_);
+                        }, frame_grain(cnt, foff[cnt]));
+                        float *h_mel = nullptr, *hp = nullptr;
+                        if (!tr.StageBuffers(foff[cnt], &h_mel, &hp) || h_mel != feat) { abort_run("staging buffers moved under -E"); return; }
+                        SlotHold hold(slots, tr);
+                        if (!tr.StageRun(foff.data(), cnt)) { abort_run(tr.LastError()); return; }
+                        h_post = hp;
+                    }
+                } else {
                     SlotHold hold(slots, tr);
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                    h_post = tr.StagedPosteriors();
                 }
-                h_post = tr.StagedPosteriors();
             } else {
                 float *h_mel = nullptr, *hp = nullptr;
                 if (!tr.StageBuffers(off.back(), &h_mel, &hp)) { abort_run(tr.LastError()); return; }
@@ -1111,7 +1140,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // Jobs whose stage 1 is next to nothing (-F: a stat(); the file is read when its launch is assembled) go to the pool
     // in chunks; the others one by one (a file's read + front-end is a task worth a thread by itself).
     // (the others too once their measured stage 1 turns out short -- lists of very short files: a chunk is sized to ~200 us)
-    const bool cheap_stage1 = need_gpu && gpu_frontend_ && in == dfWaveform;
+    const bool cheap_stage1 = need_gpu && (gpu_frontend_ || gpu_energies_) && in == dfWaveform;
     auto chunk_max = [&]() -> size_t {
         if (single_file) return 1;
         if (cheap_stage1) return 32;

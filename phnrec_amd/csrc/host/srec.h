@@ -101,6 +101,9 @@ public:
     void SetGpuDecoder(bool v) { gpu_decoder_ = v; }     // -D: PhnDec on the GPU, posteriors never leave it
     void SetSplitF16(bool v) { split_f16_ = v; }         // -H: lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16)
     void SetGpuFrontend(bool v) { gpu_frontend_ = v; }   // -F: waveform -> posteriors without the host front-end
+    // -E: the front-end's FFTs and bank sums on the GPU, ln() and the normalisations on the host: the host front-end's
+    // features bit for bit at a tenth of its CPU time
+    void SetGpuEnergies(bool v) { gpu_energies_ = v; }
     // Starts the HIP runtime and the first GPU's context on a helper thread (lcrc_device_warmup): ~0.2 s that then overlap
     // with Init(), the model files and their re-packing.  Call it as early as the conversion is known to need the GPU.
     void WarmUpGpuAsync();
@@ -142,7 +145,7 @@ private:
     std::atomic<long long> viterbi_ns_{0};
     std::string config_dir_, err_;
     bool sent_max_norm_ = false, sent_chmax_norm_ = false;
-    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_decoder_ = false, split_f16_ = false;
+    bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_energies_ = false, gpu_decoder_ = false, split_f16_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     float wpenalty_ = -2.0f;

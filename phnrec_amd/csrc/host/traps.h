@@ -145,6 +145,13 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // the front-end up to the mel-bank energies (lcrc_wave_stage_energies): they come back in the pinned feature buffer
+    bool WaveStageEnergies(const long long *start, const long long *n_bytes, int n_utts, float **energies, int *frame_off)
+    {
+        if (lcrc_wave_stage_energies(ctx_, start, n_bytes, n_utts, energies, frame_off) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     const float *StagedPosteriors() { const float *p = nullptr; lcrc_staged_posteriors(ctx_, &p); return p; }
     float LastKernelMs() { float ms = 0; lcrc_last_kernel_ms(ctx_, &ms); return ms; }
     const std::string &LastError() const { return err_; }

@@ -1472,7 +1472,7 @@ static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
 // The front-end over utterances that already lie in the pinned byte buffer: utterance u = bytes
 // [start[u], start[u] + len[u]) of c->h_bytes.  Leaves the features in c->d_mel.
 static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long long *len, int n_utts,
-                               long long extent, int *frame_off, int *rows)
+                               long long extent, int *frame_off, int *rows, bool raw_energies = false)
 {
     long long total_frames = 0;
     for (int u = 0; u < n_utts; u++) total_frames += lcrc_frontend_frames(c, len[u]);
@@ -1525,6 +1525,7 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     p.wave_format = c->fe.wave_format; p.vector_size = c->fe.vector_size; p.vector_step = c->fe.vector_step;
     p.dc_shift = c->fe.dc_shift; p.scale = c->fe.scale; p.preem_coef = c->fe.preem_coef;
     p.z_mean_source = c->fe.z_mean_source;
+    p.raw_energies = raw_energies ? 1 : 0;
     HIP_TRY(c, frontend_launch(p, c->stream));
     return LCRC_OK;
 }
@@ -1620,6 +1621,34 @@ int lcrc_wave_stage_buffer(lcrc_ctx *c, long long capacity, unsigned char **byte
     int rc = ensure_wave_bytes(c, capacity);
     if (rc) return rc;
     *bytes = c->h_bytes;
+    return LCRC_OK;
+}
+
+int lcrc_wave_stage_energies(lcrc_ctx *c, const long long *start, const long long *n_bytes, int n_utts, float **energies,
+                             int *frame_off)
+{
+    if (!c) return LCRC_E_ARG;
+    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
+    if (n_utts < 0 || !energies || (n_utts > 0 && (!start || !n_bytes || !frame_off)))
+        return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: bad argument");
+    *energies = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    long long extent = 0;
+    for (int u = 0; u < n_utts; u++) {
+        if (start[u] < extent || n_bytes[u] < 0 || (c->fe.wave_format == 1 && (start[u] & 1)))
+            return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: utterances must be in order, not overlap, and start on even bytes (lin16)");
+        extent = start[u] + n_bytes[u];
+    }
+    if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: beyond the capacity lcrc_wave_stage_buffer reserved");
+    int rows = 0;
+    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, true);
+    if (rc || rows == 0) return rc;
+    rc = ensure_host_post(c);                    // lcrc_stage_run follows: everything it needs exists now and will not move
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_mel, c->d_mel, (size_t)rows * c->nbanks * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->kdone_armed = false;
+    HIP_TRY(c, wait_stream(c));
+    *energies = c->h_mel;
     return LCRC_OK;
 }
 

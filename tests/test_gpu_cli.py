@@ -166,6 +166,52 @@ def test_gpu_front_end_flag(tmp_path):
     assert open(mel, "rb").read() == open(os.path.join(GOLD, CZ, "test.mel"), "rb").read()
 
 
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
+def test_gpu_energies_flag_is_the_host_front_end_bit_for_bit(system, tmp_path):
+    """-E: decode, window, FFT, power spectrum and bank sums on the GPU, ln() (this host's libm) and the normalisations on
+    the host.  The GPU part repeats the reference's operations in the reference's order, so the features ARE the host
+    front-end's and the posterior dump must equal the default mode's BYTE FOR BYTE (the CLI pins the fused kernels, whose
+    bits do not depend on how frames are batched); A-law too; labels equal the shipped ones; `-t par` keeps the host
+    front-end."""
+    raw = os.path.join(GOLD, "test.raw")
+    a, b = tmp_path / "host.lop", tmp_path / "e.lop"
+    run("-c", model_dir(system), "-i", raw, "-t", "post", "-o", a)
+    run("-c", model_dir(system), "-i", raw, "-t", "post", "-o", b, "-E")
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert np.abs(read_htk(str(b)) - read_htk(os.path.join(GOLD, system, "test.lop"))).max() < 1e-4
+    if system == CZ:
+        run("-c", model_dir(system), "-w", "alaw", "-i", raw, "-t", "post", "-o", a)
+        run("-c", model_dir(system), "-w", "alaw", "-i", raw, "-t", "post", "-o", b, "-E")
+        assert open(a, "rb").read() == open(b, "rb").read()
+        mel = tmp_path / "t.mel"
+        run("-c", model_dir(CZ), "-E", "-i", raw, "-t", "par", "-o", mel)
+        assert open(mel, "rb").read() == open(os.path.join(GOLD, CZ, "test.mel"), "rb").read()
+    out = tmp_path / "t.rec"
+    run("-c", model_dir(system), "-i", raw, "-o", out, "-E")
+    _labels_match(out, os.path.join(GOLD, "rec", system + ".rec"))
+    out2 = tmp_path / "t2.rec"
+    run("-c", model_dir(system), "-i", raw, "-o", out2, "-E", "-D")
+    _labels_match(out2, os.path.join(GOLD, "rec", system + ".rec"))
+
+
+def test_gpu_energies_flag_on_a_list(tmp_path):
+    """-E over a list (150 synthetic files, several launches, two logical GPUs): the MLF equals the default mode's byte
+    for byte, and so does every posterior dump"""
+    lst = _make_list(tmp_path, "hu", 150, seed=21)
+    host, en = tmp_path / "host.mlf", tmp_path / "e.mlf"
+    run("-c", model_dir(HU), "-l", lst, "-m", host, "-b", 3000)
+    run("-c", model_dir(HU), "-l", lst, "-m", en, "-b", 3000, "-E", "-g", 2, env={"PHNREC_DEVICE_MAP": "0,0"})
+    assert host.read_text() == en.read_text()
+    names = lst.read_text().split()[:12]
+    sub = tmp_path / "sub.scp"
+    sub.write_text("".join("%s %s.h.lop\n" % (n, n) for n in names))
+    run("-c", model_dir(HU), "-l", sub, "-t", "post")
+    sub.write_text("".join("%s %s.e.lop\n" % (n, n) for n in names))
+    run("-c", model_dir(HU), "-l", sub, "-t", "post", "-E")
+    for n in names:
+        assert open(n + ".h.lop", "rb").read() == open(n + ".e.lop", "rb").read(), n
+
+
 def test_default_system_1bt_dct_end_to_end(tmp_path):
     """posteriors/system=1BT_DCT (the schema default, srec.cpp:69) through the CLI on the bundled utterance,
     against what the reference CLI wrote for the same synthetic model (tools/make_golden_systems.py)"""
@@ -207,6 +253,9 @@ def test_sentence_maximum_normalisations(tmp_path):
         dumps[name] = got
         p = subprocess.run([BIN, "-c", d, "-i", raw, "-t", "post", "-o", str(lop), "-F"], capture_output=True, text=True)
         assert p.returncode != 0 and "host front-end" in p.stderr
+        lop_e = tmp_path / (name + "_E.lop")                # -E: the normalisations run on the host: accepted, same bytes
+        run("-c", d, "-i", raw, "-t", "post", "-o", lop_e, "-E")
+        assert open(lop_e, "rb").read() == open(lop, "rb").read(), name
     assert np.abs(dumps["maxnorm"] - dumps["chmaxnorm"]).max() > 1e-3        # (they do differ)
     assert np.array_equal(dumps["maxnorm"], dumps["bothmax"])                # the global form overrides the per-channel one
 
@@ -289,7 +338,7 @@ def _es_model(tmp_path):
     return d
 
 
-@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D")])
+@pytest.mark.parametrize("flags", [(), ("-F",), ("-F", "-D"), ("-E",)])
 def test_reference_list_golden_8580(flags, tmp_path):
     """/root/reference/test: `phnrec -c PHN_ES -l lsit.txt -m test` run inside that directory.  lsit.txt:1 is a
     one-column line with a bare file name, so the MLF entry is "8580.rec" (no "*/": ChangeFilePath leaves a name
@@ -530,6 +579,7 @@ def test_bench_line_carries_every_leg():
     # the sharded list (configs[3]'s system and list recipe), with what the host alone can do beside it
     sl = d["sharded_list"]
     assert sl["files"] == 120 and sl["gpus"] == 1 and sl["frames_per_s"] > 50000 and sl["mlf_F_equals_F_D"] is True
+    assert sl["gpu_energies_E"]["value"] > 50000 and sl["mlf_E_equals_host_frontend"] is True
     assert sl["host_ceiling"]["frames_per_s"] > 0 and sl["host_ceiling"]["gpu_frontend_F"]["host_cpu_s"] > 0
     assert sl["cz_same_list"]["host_frontend"]["value"] > 50000 and sl["cz_same_list"]["gpu_frontend_F"]["value"] > 50000
     assert sl["host_ceiling"]["per_file_serial"]["files_per_s"] > 20000      # (round 3's pipeline: 80 k on these hosts; now ~400 k)

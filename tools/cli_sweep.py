@@ -19,7 +19,7 @@ grid = sys.argv[2] if len(sys.argv) > 2 else "0,3,0;1,3,0;2,3,0;2,4,0;3,4,0;2,5,
 with tempfile.TemporaryDirectory(dir="/tmp") as td:
     lst, names, frames = bench.synthetic_list(td, n_files)
     print("files %d frames %d cores %d" % (n_files, frames, bench.usable_cpus()), flush=True)
-    for flags in ([], ["-F"], ["-F", "-D"]):
+    for flags in ([], ["-E"], ["-F"], ["-F", "-D"]):
         for cfg in grid.split(";"):
             slots, ctx, batch = (int(x) for x in cfg.split(","))
             env = dict(os.environ, PHNREC_STATS="1", PHNREC_GPU_SLOTS=str(slots), PHNREC_CTX_PER_GPU=str(ctx))
