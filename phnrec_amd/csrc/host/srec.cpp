@@ -791,6 +791,13 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
     }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
+    // A list over two or more GPUs, called as the reference is called (no -F, no -E): the host front-end's 0.36 us per
+    // frame and core would feed 1.4 GPUs on 16 cores.  -E produces the same features bit for bit (tests compare dumps and
+    // MLFs byte for byte) at a fifth of the CPU time, so it is switched on by itself there; one GPU is served faster by
+    // the host front-end and keeps it.  PHNREC_NO_AUTO_E=1 keeps the host front-end whatever -g says.
+    if (need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ && n_gpus_ >= 2 && gpus_.empty() &&
+        wave_.noise_level == 0.0f && !getenv("PHNREC_NO_AUTO_E"))
+        gpu_energies_ = true;
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
         // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the

@@ -194,6 +194,24 @@ def test_gpu_energies_flag_is_the_host_front_end_bit_for_bit(system, tmp_path):
     _labels_match(out2, os.path.join(GOLD, "rec", system + ".rec"))
 
 
+def test_two_gpus_called_as_the_reference_take_the_energies_road(tmp_path):
+    """`phnrec -g 2 -l ... -m ...` without -F / -E switches -E on by itself (the host front-end would feed 1.4 GPUs): its
+    stage-1 CPU time falls to a fraction, the MLF stays the one `-g 1` (host front-end) writes, byte for byte;
+    PHNREC_NO_AUTO_E=1 keeps the host front-end"""
+    lst = _make_list(tmp_path, "hu", 150, seed=23)
+    one, two, two_host = tmp_path / "g1.mlf", tmp_path / "g2.mlf", tmp_path / "g2h.mlf"
+    a = run("-c", model_dir(HU), "-l", lst, "-m", one, env={"PHNREC_STATS": "1"})
+    b = run("-c", model_dir(HU), "-l", lst, "-m", two, "-g", 2, env={"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0"})
+    c = run("-c", model_dir(HU), "-l", lst, "-m", two_host, "-g", 2,
+            env={"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0", "PHNREC_NO_AUTO_E": "1"})
+    assert one.read_text() == two.read_text() == two_host.read_text()
+
+    def stage1(p):
+        line = [l for l in p.stderr.splitlines() if l.startswith("phnrec: files=")][-1]
+        return float(line.split("stage1=")[1].split()[0])
+    assert stage1(b) < 0.5 * stage1(a) and stage1(c) > 0.5 * stage1(a)
+
+
 def test_gpu_energies_flag_on_a_list(tmp_path):
     """-E over a list (150 synthetic files, several launches, two logical GPUs): the MLF equals the default mode's byte
     for byte, and so does every posterior dump"""
