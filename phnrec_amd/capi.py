@@ -331,6 +331,28 @@ class Lcrc:
                                                len(blobs), out, foff))
         return out, foff
 
+    def wave_energies_staged(self, blobs):
+        """lcrc_wave_stage_buffer / lcrc_wave_stage_energies: mel-bank energies (before ln) of raw files, as a COPY of the
+        pinned feature buffer the call hands out; returns (energies [rows][nbanks], frame offsets)"""
+        blobs = [bytes(b) for b in blobs]
+        start, pos = [], 0
+        for b in blobs:
+            start.append(pos)
+            pos += len(b) + (len(b) & 1)
+        buf = C.POINTER(C.c_ubyte)()
+        self._check(self.L.lcrc_wave_stage_buffer(self.h, pos, C.byref(buf)))
+        for s, b in zip(start, blobs):
+            C.memmove(C.addressof(buf.contents) + s, b, len(b))
+        foff = np.zeros(len(blobs) + 1, np.int32)
+        en = C.POINTER(C.c_float)()
+        i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+        self.L.lcrc_wave_stage_energies.argtypes = [C.c_void_p, i64p, i64p, C.c_int, C.POINTER(C.POINTER(C.c_float)), _i32p]
+        self._check(self.L.lcrc_wave_stage_energies(self.h, np.array(start, np.int64), np.array([len(b) for b in blobs], np.int64),
+                                                    len(blobs), C.byref(en), foff))
+        rows = int(foff[-1])
+        out = np.ctypeslib.as_array(en, shape=(rows, self.nbanks)).copy() if rows else np.zeros((0, self.nbanks), np.float32)
+        return out, foff
+
     def posteriors_probe(self, mel):
         mel = np.ascontiguousarray(mel, dtype=np.float32).reshape(-1, self.nbanks)
         n = mel.shape[0]

@@ -45,6 +45,27 @@ def test_mel_matches_reference_dump(capi, system):
     assert (mel == want).mean() > 0.999, "identical up to the rare last-bit difference of logf"
 
 
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
+def test_energies_plus_libm_logf_equal_the_reference_dump_bit_for_bit(capi, system):
+    """lcrc_wave_stage_energies: the GPU front-end stopped in front of ln().  Everything up to there is IEEE arithmetic in
+    the reference's order, so ln() taken by THIS host's libm (the reference's `x > 0 ? logf(x) : 0`, dspc.h:155-160) must
+    give the reference CLI's `-t par` dump bit for bit -- where the all-GPU features are allowed one ulp."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype, libm.logf.argtypes = ctypes.c_float, [ctypes.c_float]
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ctx = _ctx(capi, system)
+    en, foff = ctx.wave_energies_staged([raw])
+    want = read_htk(os.path.join(GOLD, system, "test.mel"))
+    assert en.shape == want.shape and list(foff) == [0, want.shape[0]]
+    got = np.array([libm.logf(float(v)) if v > 0 else 0.0 for v in en.ravel()], np.float32).reshape(en.shape)
+    assert np.array_equal(got, want)
+    # ... batched, the same energies per utterance
+    en2, foff2 = ctx.wave_energies_staged([raw[:20000], raw, raw[:3000]])
+    assert np.array_equal(en2[foff2[1]:foff2[2]], en)
+    ctx.close()
+
+
 def test_alaw_and_short_files(capi):
     raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
     ctx = _ctx(capi, CZ, wave_format="alaw")
