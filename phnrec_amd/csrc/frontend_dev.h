@@ -25,6 +25,8 @@ struct FrontendParams {
 };
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
+// host (pinned, mapped) -> device by a kernel instead of a copy command; both 16-byte aligned, `bytes` rounded up to 16
+hipError_t pull_bytes_launch(const void *mapped_src, void *dst, size_t bytes, hipStream_t stream);
 // Sentence mean normalisation.  means: device scratch [n_utts][nbanks].  block_off [n_utts + 1] (first
 // 256-row block of each utterance, meannorm_blocks(rows) blocks each) and partial [n_blocks][nbanks] select the
 // fixed-shape tree sum; block_off == NULL the reference's sequential sums.

@@ -15,6 +15,8 @@
 // and the sentence mean normalisation (srec.cpp:1500-1511) with its sequential f32 column sums.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "frontend_dev.h"
 
 namespace phnrec {
@@ -496,6 +498,22 @@ __global__ void submean_kernel(float *mel, const int *frame_off, int n_utts, int
     float *x = mel + (size_t)r * nbanks;
     const float *m = means + (size_t)lo * nbanks;
     for (int b = 0; b < nbanks; b++) x[b] += -m[b];
+}
+
+// Host -> device by a kernel instead of a copy command: `src` is pinned host memory mapped into the device.  For callers
+// whose upload must not stand in the copy engine's queue behind other contexts' large copy-backs (lcrc_wave_stage_energies).
+__global__ __launch_bounds__(256) void pull_bytes_kernel(const uint4 *src, uint4 *dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t pull_bytes_launch(const void *mapped_src, void *dst, size_t bytes, hipStream_t stream)
+{
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return hipSuccess;
+    const int blocks = (int)std::min<size_t>(512, (n16 + 255) / 256);
+    pull_bytes_kernel<<<blocks, 256, 0, stream>>>(static_cast<const uint4 *>(mapped_src), static_cast<uint4 *>(dst), n16);
+    return hipGetLastError();
 }
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)

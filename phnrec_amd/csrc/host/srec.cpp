@@ -805,9 +805,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // From four GPUs on: two -- on one GPU the third is worth 0-2 %, while every context costs ~10 ms of start-up that
         // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
         // list that eight GPUs finish in a tenth of a second are a loss.
-        // (-E has two device phases per launch with the host's ln() between them: one context more keeps the GPU fed,
-        //  25.4 -> 26.7 M frames/s on one GPU)
-        if (!EnsureGpus(single_file ? 1 : (std::max(1, n_gpus_) >= 4 ? 2 : 3) + (gpu_energies_ ? 1 : 0))) return false;
+        if (!EnsureGpus(single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3)) return false;
     }
     if (need_gpu && !single_file && pool_->Size() > 0) {
         cpu_set_t all, one;
