@@ -1518,6 +1518,9 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     // commands they stood behind other contexts' 24 MB of posteriors on their way back, which wait for those contexts'
     // kernels (-E: 24.7 M frames/s on one GPU with them).
     float *mel_out = c->d_mel;
+    // (-E with the upload as a copy command and only the energies stored directly: 20.8-24.7 M; -F with its upload pulled
+    //  by the kernel instead of copied: 27.4 against 28.7 M -- a caller that does not wait in between is better off with
+    //  the copy engine; profiles/r04_ab_runs.txt 18)
     if (raw_energies) {
         void *src = nullptr;
         HIP_TRY(c, hipHostGetDevicePointer(&src, c->h_bytes, 0));
