@@ -301,8 +301,9 @@ int lcrc_set_wait_mode(lcrc_ctx *ctx, int poll_interval_us);
  * fn = NULL switches it off.  Not called when a call launches nothing or fails before its launch. */
 typedef void (*lcrc_kernel_done_fn)(void *arg);
 int lcrc_set_kernel_done_callback(lcrc_ctx *ctx, lcrc_kernel_done_fn fn, void *arg);
-/* Frames per workgroup: 0 = chosen per launch (32 when that fills the GPU, else 16), or 16 / 32 forced
- * (tuning and test hook; results are bit-identical either way) */
+/* Frames per workgroup: 0 = chosen per launch (whole rounds as pairs of 16-frame workgroups per CU where two fit side by
+ * side -- every shipped shape --, else 32-frame ones; 16-frame ones for what fills less than half of the GPU), or 16 / 32
+ * forced (tuning and test hook; results are bit-identical either way) */
 int lcrc_set_tile_frames(lcrc_ctx *ctx, int frames);
 /* NOTE on batch invariance: with the default (0) a frame's last bits depend on the size of the launch it is part
  * of, for every caller of this library (as the reference's do on bunch_size through BLAS's sgemv / sgemm kernels);

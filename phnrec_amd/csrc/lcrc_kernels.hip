@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 
 #include "lcrc_dev.h"
 #include "mlp_dev.h"
@@ -829,6 +830,17 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     Part parts[3];
     int n_parts = 0;
     const bool free_choice = p.tile_frames == 0 && fits32 && !probes && !p.stamps;
+    // Whole rounds run as PAIRS of 16-frame workgroups per CU where two of them fit side by side (every shipped shape:
+    // <= 256 registers, <= 80 KB of LDS): the same rows per round as one 32-frame workgroup per CU, but while one of the
+    // pair is in a phase the f32 MFMA cannot hide -- staging, projection, the softmax / ln() epilogues: 6 % of a CZ
+    // workgroup, 15-19 % of an EN one -- the other's hidden loops have the matrix pipe.  Measured (round 4, same bits):
+    // CZ 8192 rows 0.1945 -> 0.1925 ms, 32768 0.7738 -> 0.7622; HU 32768 0.9379 -> 0.9253; RU 0.7825 -> 0.7670; EN 8192
+    // 0.0803 -> 0.0786, 32768 0.3151 -> 0.3056 (0.731 -> 0.754 of peak).  (Rounds 1 and 2 found the opposite: the weight
+    // loads' 64-bit per-lane addresses then cost twice as much per MFMA in 16-frame workgroups; with scalar-base loads they
+    // do not.)  LCRC_NO_PAIR16=1 keeps the 32-frame rounds (A/B).
+    static const bool no_pair16 = getenv("LCRC_NO_PAIR16") != nullptr;
+    const bool pair16 = !no_pair16 && 2u * lcrc_lds_plan(1, p.nbanks, k1, km, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
+    const int ft_round = pair16 ? 1 : 2;
     const int tiles16_all = (rows + 15) / 16;
     const bool small_splits = p.tile_frames != 32 && choose_split(p, tiles16_all, n_cu) > 1;
     if (!free_choice || rows <= round16 || small_splits) {
@@ -842,19 +854,28 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         // would the split path take a tail of `r` rows?
         auto splits = [&](int r) { return r > 0 && choose_split(p, (r + 15) / 16, n_cu) > 1; };
         if (rem == 0) {
-            parts[n_parts++] = Part{args.row_first, rows, 2, false};
+            parts[n_parts++] = Part{args.row_first, rows, ft_round, false};
         } else if (rem <= round16) {
-            // whole rounds of 32-frame tiles, then half a round (or less) of 16-frame tiles / the split path
-            if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, 2, false};
-            parts[n_parts++] = Part{args.row_first + main_rows, rem, 1, splits(rem)};
+            // whole rounds, then half a round (or less) of 16-frame tiles / the split path; rounds of 16-frame pairs and a
+            // fused tail of 16-frame tiles are one launch
+            if (splits(rem) || ft_round != 1) {
+                if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, ft_round, false};
+                parts[n_parts++] = Part{args.row_first + main_rows, rem, 1, splits(rem)};
+            } else {
+                parts[n_parts++] = Part{args.row_first, rows, 1, false};
+            }
         } else if (splits(rem - round16)) {
             // between half a round and a round, and what lies beyond the half round is small enough for the split
-            // path: half a round of 16-frame tiles + the split tail beat the full round of 32-frame tiles
-            if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, 2, false};
-            parts[n_parts++] = Part{args.row_first + main_rows, round16, 1, false};
+            // path: half a round of 16-frame tiles + the split tail beat the full round
+            if (ft_round == 1) {
+                parts[n_parts++] = Part{args.row_first, main_rows + round16, 1, false};      // rounds + the half round: one launch
+            } else {
+                if (main_rows > 0) parts[n_parts++] = Part{args.row_first, main_rows, 2, false};
+                parts[n_parts++] = Part{args.row_first + main_rows, round16, 1, false};
+            }
             parts[n_parts++] = Part{args.row_first + main_rows + round16, rem - round16, 1, true};
         } else {
-            parts[n_parts++] = Part{args.row_first, rows, 2, false};
+            parts[n_parts++] = Part{args.row_first, rows, ft_round, false};
         }
     }
     float *const post0 = args.post;
