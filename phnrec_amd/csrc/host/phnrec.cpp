@@ -29,7 +29,7 @@ static void Help()
     puts(" -p num [-3.8]      phoneme insertion penalty");
     puts(" -v                 verbose");
     puts(" -g num [1]         number of GPUs to spread a file list over (MI355X build)");
-    puts(" -b num [32768]     frames per GPU launch when batching a file list");
+    puts(" -b num [32768]     frames per GPU launch when batching a file list (65536 with -D)");
     puts(" -j num [all]       host threads for the front-end and the decoder");
     puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
     puts(" -E                 the front-end's FFTs and bank sums on the GPU, ln() and the normalisations on the host:\n"
@@ -138,6 +138,7 @@ int main(int argc, char **argv)
     if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
+    else if (gpu_dec) SR.SetBatchFrames(65536);      // one decoder wave per utterance: twice the utterances per launch keep more SIMDs busy
     if (threads > 0) SR.SetHostThreads(threads);
     if (gpu_fe && gpu_en) Die("-F and -E are two forms of the GPU front-end: give one\n");
     SR.SetGpuFrontend(gpu_fe);

@@ -863,6 +863,18 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         ~CpuTimer() { acc += ThreadCpuNs() - t0; }
     };
     std::atomic<bool> first_launch(true);
+    // PHNREC_TRACE_PIPELINE=1: a time line of the workers' steps on stderr at the end of the run (diagnostic)
+    const bool trace_on = getenv("PHNREC_TRACE_PIPELINE") != nullptr;
+    std::mutex trace_mu;
+    std::vector<std::string> trace_rows;
+    auto trace = [&](int ctx, const char *what, long long a = 0, long long b = 0) {
+        if (!trace_on) return;
+        char line[160];
+        snprintf(line, sizeof line, "%9.3f ms  ctx %d  %-18s %lld %lld\n",
+                 std::chrono::duration<double, std::milli>(clock::now() - t1).count(), ctx, what, a, b);
+        std::lock_guard<std::mutex> l(trace_mu);
+        trace_rows.emplace_back(line);
+    };
     const int n_ctx = need_gpu ? (int)gpus_.size() : 0;
     const int max_pending = std::max(8, 4 * std::max(1, pool_->Size()));
     const long long max_staged_frames = (long long)batch_frames_ * (n_ctx + 2);
@@ -1023,10 +1035,12 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             }, 16);
             return true;
         };
+        trace(g, "worker up");
         while (take_launch(items)) {
             int cnt = (int)items.size();
             off.assign(1, 0);
             for (int k = 0; k < cnt; k++) off.push_back(off.back() + items[k]->job.frames);
+            trace(g, "took launch", cnt, off.back());
             const auto l0 = clock::now();
             const float *h_post = nullptr;
             std::vector<int> foff;
@@ -1042,6 +1056,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                 }
                 unsigned char *pinned = nullptr;
                 if (!tr.WaveStageBuffer(pos, &pinned)) { abort_run(tr.LastError()); return; }
+                trace(g, "byte buffer", pos);
                 std::atomic<int> bad(cnt);     // lowest index whose read failed
                 pool_->ParallelFor(cnt, [&](int k) {
                     CpuTimer tm(read_us);
@@ -1050,6 +1065,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                         while (k < e && !bad.compare_exchange_weak(e, k)) {}
                     }
                 }, (int)std::max<long long>(1, (1LL << 20) * cnt / std::max<long long>(1, pos)));
+                trace(g, "files read");
                 if (bad < cnt) {
                     // The file was there for stage 1's stat() and cannot be read now.  Same meaning as a stage-1
                     // failure (srec.cpp:1246-1290 works file by file): the list stops AT this file -- the jobs in
@@ -1098,7 +1114,9 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     }
                 } else {
                     SlotHold hold(slots, tr);
+                    trace(g, "slot");
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                    trace(g, "run returned");
                     h_post = tr.StagedPosteriors();
                 }
             } else {
@@ -1131,10 +1149,12 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     Stage3(out, j, mlf != nullptr, const_cast<float *>(h_post) + (size_t)foff[k] * n_out_, n_out_, true);
                 }, frame_grain(cnt, off.back()));
             }
+            trace(g, "decoded");
             std::lock_guard<std::mutex> l(mu);
             for (Item *it : items) it->slot.state = 3;
             drain();
         }
+        trace(g, "worker done");
     };
 
     std::vector<std::thread> workers;
@@ -1211,6 +1231,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // every queued stage-1 task must have ended before the window goes out of scope
         std::unique_lock<std::mutex> l(mu);
         cv_idle.wait(l, [&] { return pending1 == 0; });
+    }
+    if (trace_on) {
+        std::sort(trace_rows.begin(), trace_rows.end());
+        for (const std::string &r : trace_rows) fputs(r.c_str(), stderr);
     }
     stats_.stage1_seconds += stage1_us.load() * 1e-9 / std::max(1, pool_->Size());
     stats_.cpu_stage1 += stage1_us.load() * 1e-9;

@@ -3,7 +3,7 @@
 // the CLI does so unless -D is given; this kernel exists so that a `-t str` run needs neither the
 // 4*nOut bytes per frame of posteriors over PCIe nor host cores for decoding.
 //
-// One wave per utterance (sixteen utterances per workgroup), lane i = phoneme i (<= 64 phonemes), each lane carrying
+// One wave per utterance (four utterances per workgroup), lane i = phoneme i (<= 64 phonemes), each lane carrying
 // its model's S+1 token slots (score, entry winner, length) in registers; the time_pruning+1 <= 64 entries of the
 // winner history live one per lane in five more registers (v_readlane with a scalar index, compare + select to
 // write), wave maxima go through DPP: the kernel touches no LDS and needs no barrier.  Restates, operation by
@@ -57,15 +57,18 @@ __device__ __forceinline__ float lane_get(float v, int lane)
 }  // namespace
 
 // kDecWaves utterances per workgroup, one wave each, no barrier and no LDS: the waves of a workgroup have nothing to do
-// with each other.  What the grouping buys is CU time: every step of a frame depends on the one before, so a wave
-// issues an instruction every few cycles at best and sixteen of them share a CU (four per SIMD) at nearly the speed of
-// one -- while a CU that holds even ONE decoder wave cannot take a workgroup of the posterior kernel (512 registers x
-// 4 waves: the whole register file).  One wave per workgroup (round 3) held 36 CUs for the 1.2 ms of a 36-utterance
-// launch, this form holds 3.
-constexpr int kDecWaves = 16;
+// with each other.  What the grouping and the register budget buy is CU time for the posterior kernel, whose workgroups
+// fill a CU's register file almost entirely (one 32-frame workgroup: 4 waves x <= 254 registers; since round 4 a PAIR of
+// 16-frame workgroups: 8 waves, 384-448 of the 512 registers per SIMD lane).  Round 3's one-wave workgroups landed on 36
+// different CUs and kept posterior workgroups off all of them for the 1.2 ms of a 36-utterance launch.  Now a workgroup is
+// FOUR waves -- one per SIMD -- of at most 64 registers: it fits into what a pair of posterior workgroups leaves free
+// (448 + 64 = 512), so the decoder runs BESIDE the posterior kernel's workgroups instead of in place of them.  (Sixteen waves
+// per workgroup, four per SIMD, need 256 registers per SIMD lane: beside one 32-frame workgroup that fitted, beside a pair
+// it does not, and -F -D fell 10 % behind -F until this was changed.)
+constexpr int kDecWaves = 4;
 
 template <int S>
-__global__ __launch_bounds__(64 * kDecWaves) void phndec_kernel(const PhnDecParams p)
+__global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecParams p)      // 8 waves per SIMD: <= 64 registers
 {
     // (readfirstlane: the wave number is the same in all 64 lanes, which hipcc cannot know -- without it the utterance's
     //  bounds, the history head and every other wave-uniform value live in vector registers and each scalar-indexed
