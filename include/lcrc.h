@@ -203,6 +203,13 @@ int lcrc_wave_to_mel(lcrc_ctx *ctx, const unsigned char *bytes, const long long 
                      float *mel, int *frame_off);
 int lcrc_wave_to_posteriors(lcrc_ctx *ctx, const unsigned char *bytes, const long long *byte_off,
                             int n_utts, float *post, int *frame_off);
+/* Allocates NOW every buffer a later call of up to max_rows frames in max_utts utterances would otherwise allocate on
+ * demand inside its first call (device staging, pinned features / posteriors / offsets; with max_wave_bytes > 0 -- after
+ * lcrc_frontend_configure -- the byte buffers of the waveform entries too).  Optional: the entry points grow their buffers
+ * themselves; page pinning is what that costs (~8 ms per 32 768 HU frames), and a caller with a set-up phase calls this
+ * there.  Call it after lcrc_decoder_configure / lcrc_set_posterior_readback (they decide whether a pinned posterior
+ * buffer is needed at all).  Has no reference counterpart (the reference allocates per bunch, traps.cpp:63-101). */
+int lcrc_reserve(lcrc_ctx *ctx, int max_rows, int max_utts, long long max_wave_bytes);
 /* Zero-copy variant: lcrc_wave_stage_buffer returns the context's pinned byte buffer (valid until a later
  * call asks for more capacity); the caller reads its files straight into it -- utterance u at start[u]
  * (ascending, not overlapping, even for lin16), n_bytes[u] long -- and lcrc_wave_stage_run does what

@@ -19,7 +19,7 @@ SYMBOLS = [
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
-    "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
+    "lcrc_reserve", "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_kernel_done_callback", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
@@ -139,6 +139,7 @@ def load():
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
     L.lcrc_wave_to_mel.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
     L.lcrc_wave_to_posteriors.argtypes = [vp, _u8p, _i64p, C.c_int, _f32p, _i32p]
+    L.lcrc_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_longlong]
     L.lcrc_wave_stage_buffer.argtypes = [vp, C.c_longlong, C.POINTER(C.POINTER(C.c_ubyte))]
     L.lcrc_wave_stage_run.argtypes = [vp, _i64p, _i64p, C.c_int, _f32p, _i32p]
     L.lcrc_model_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_size_t,
@@ -312,6 +313,10 @@ class Lcrc:
 
     def wave_to_posteriors(self, blobs):
         return self._wave(self.L.lcrc_wave_to_posteriors, blobs, self.n_out)
+
+    def reserve(self, max_rows, max_utts, max_wave_bytes=0):
+        """lcrc_reserve: the buffers later calls of up to this size would allocate on demand, allocated now"""
+        self._check(self.L.lcrc_reserve(self.h, int(max_rows), int(max_utts), int(max_wave_bytes)))
 
     def wave_to_posteriors_staged(self, blobs):
         """lcrc_wave_stage_buffer / lcrc_wave_stage_run: the files are written straight into the pinned buffer"""

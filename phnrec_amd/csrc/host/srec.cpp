@@ -431,34 +431,42 @@ bool SpeechRec::EnsureGpus(int per_gpu)
         for (int g = 0; g < n; g++) gpu_devices_.push_back(dmap.empty() ? g : dmap[g]);
     }
     const auto t0 = std::chrono::steady_clock::now();
-    for (int k = (int)gpus_.size() / n; k < per_gpu; k++) {
-        if (k > 0 && warmup_.joinable()) warmup_.join();
-        std::vector<std::unique_ptr<Traps>> made(n);
-        std::vector<std::string> errs(n);
-        auto make = [&](int g) {
-            std::unique_ptr<Traps> t(new Traps);
-            t->SetSystem(C.GetString("posteriors", "system").c_str());
-            t->SetTrapLen(C.GetInt("posteriors", "length"));
-            t->SetHamming(C.GetBool("posteriors", "hamming"));
-            t->SetNBanks(nbanks_);
-            t->SetAddC0(C.GetBool("posteriors", "add_c0"));
-            t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
-            t->SetDevice(gpu_devices_[g]);
-            // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
-            t->SetHiddenSplit(1);
-            if (!(k == 0 ? t->Init(config_dir_.c_str()) : t->InitClone(*gpus_[g]))) { errs[g] = t->LastError() + "\n"; return; }
-            errs[g] = SetUpContext(*t);
-            if (errs[g].empty()) made[g] = std::move(t);
-        };
-        if (n == 1) {
-            make(0);
+    // context k of GPU g; k == 0 loads the model, the others clone it
+    auto make = [&](int g, int k, std::unique_ptr<Traps> &out, std::string &err) {
+        std::unique_ptr<Traps> t(new Traps);
+        t->SetSystem(C.GetString("posteriors", "system").c_str());
+        t->SetTrapLen(C.GetInt("posteriors", "length"));
+        t->SetHamming(C.GetBool("posteriors", "hamming"));
+        t->SetNBanks(nbanks_);
+        t->SetAddC0(C.GetBool("posteriors", "add_c0"));
+        t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
+        t->SetDevice(gpu_devices_[g]);
+        // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
+        t->SetHiddenSplit(1);
+        if (!(k == 0 ? t->Init(config_dir_.c_str()) : t->InitClone(*gpus_[g]))) { err = t->LastError() + "\n"; return; }
+        err = SetUpContext(*t);
+        if (err.empty()) out = std::move(t);
+    };
+    // Two rounds: the first context of every GPU (GPUs in parallel), then ALL the clones at once -- a clone is a stream,
+    // a few events and small tables, ~10 ms of mostly waiting inside the runtime each; one after the other they were
+    // 20-30 ms in front of every list.
+    const int have = (int)gpus_.size() / n;
+    for (int round = 0; round < 2; round++) {
+        const int k_lo = round == 0 ? have : std::max(have, 1), k_hi = round == 0 ? std::min(per_gpu, 1) : per_gpu;
+        if (k_hi <= k_lo) continue;
+        if (round == 1 && warmup_.joinable()) warmup_.join();
+        const int cnt = (k_hi - k_lo) * n;
+        std::vector<std::unique_ptr<Traps>> made((size_t)cnt);
+        std::vector<std::string> errs((size_t)cnt);
+        if (cnt == 1) {
+            make(0, k_lo, made[0], errs[0]);
         } else {
             std::vector<std::thread> th;
-            for (int g = 0; g < n; g++) th.emplace_back(make, g);
+            for (int i = 0; i < cnt; i++) th.emplace_back([&, i] { make(i % n, k_lo + i / n, made[(size_t)i], errs[(size_t)i]); });
             for (auto &t : th) t.join();
         }
-        for (int g = 0; g < n; g++) if (!made[g]) return Fail(errs[g]);
-        for (int g = 0; g < n; g++) gpus_.push_back(std::move(made[g]));
+        for (int i = 0; i < cnt; i++) if (!made[(size_t)i]) return Fail(errs[(size_t)i]);
+        for (int i = 0; i < cnt; i++) gpus_.push_back(std::move(made[(size_t)i]));      // (context g + k * n serves GPU g)
     }
     stats_.create_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return true;
@@ -838,6 +846,21 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         int poll_us = (int)gpus_.size() * 2 > UsableCpus() ? 50 : 0;
         if (const char *e = getenv("PHNREC_WAIT_POLL_US")) poll_us = std::max(0, atoi(e));
         for (auto &g : gpus_) g->SetWaitMode(poll_us);
+        // A list: every context's buffers for launches of batch_frames_, allocated here, all contexts at once, instead of
+        // inside each context's first launch (pinning 30 MB of posterior buffer is 5-10 ms, and the runtime lets other
+        // contexts' copies wait meanwhile: the first 40 ms of a list ran at a third of the steady rate).
+        if (!single_file && !getenv("PHNREC_NO_RESERVE")) {
+            long long wave_bytes = 0;
+            if ((gpu_frontend_ || gpu_energies_) && in == dfWaveform)
+                wave_bytes = ((long long)batch_frames_ * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
+                             (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
+            std::vector<std::string> errs(gpus_.size());
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < gpus_.size(); i++)
+                th.emplace_back([&, i] { if (!gpus_[i]->Reserve(batch_frames_, 256, wave_bytes)) errs[i] = gpus_[i]->LastError() + "\n"; });
+            for (auto &t : th) t.join();
+            for (const std::string &e : errs) if (!e.empty()) return Fail(e);
+        }
     }
     const auto t1 = clock::now();
     stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
@@ -869,9 +892,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     std::vector<std::string> trace_rows;
     auto trace = [&](int ctx, const char *what, long long a = 0, long long b = 0) {
         if (!trace_on) return;
-        char line[160];
-        snprintf(line, sizeof line, "%9.3f ms  ctx %d  %-18s %lld %lld\n",
-                 std::chrono::duration<double, std::milli>(clock::now() - t1).count(), ctx, what, a, b);
+        char line[200];
+        snprintf(line, sizeof line, "%9.3f ms  (%lld us, thread %ld)  ctx %d  %-18s %lld %lld\n",
+                 std::chrono::duration<double, std::milli>(clock::now() - t1).count(),
+                 (long long)std::chrono::duration<double, std::micro>(clock::now().time_since_epoch()).count() % 100000000LL,
+                 (long)(size_t)pthread_self() % 1000, ctx, what, a, b);
         std::lock_guard<std::mutex> l(trace_mu);
         trace_rows.emplace_back(line);
     };

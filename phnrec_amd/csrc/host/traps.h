@@ -132,6 +132,13 @@ public:
     {
         return lcrc_last_labels(ctx_, labels, first, count, n_utts) == LCRC_OK;
     }
+    // buffers for launches of up to this size, allocated ahead of the first one (lcrc_reserve)
+    bool Reserve(int max_rows, int max_utts, long long max_wave_bytes)
+    {
+        if (lcrc_reserve(ctx_, max_rows, max_utts, max_wave_bytes) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     // zero-copy waveform staging (lcrc_wave_stage_buffer / lcrc_wave_stage_run)
     bool WaveStageBuffer(long long capacity, unsigned char **bytes)
     {

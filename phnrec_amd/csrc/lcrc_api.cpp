@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
 #include <string>
 #include <thread>
 #include <time.h>
@@ -755,6 +756,30 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     return arm_kernel_done(c, s);
 }
 
+// label and count buffers of the decoder on the device (one label slot per frame, one count per utterance)
+int ensure_labels(lcrc_ctx *c, size_t n_rows, size_t n_utts)
+{
+    if (n_rows > c->cap_label_rows) {
+        const size_t cap = n_rows + n_rows / 4 + 64;
+        if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
+        c->d_labels = c->h_labels = nullptr;
+        c->cap_label_rows = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_labels, cap * sizeof(lcrc_label)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), kPinned));
+        c->cap_label_rows = cap;
+    }
+    if (n_utts > c->cap_label_utts) {
+        const size_t cap = n_utts + n_utts / 4 + 64;
+        if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
+        c->d_count = c->h_count = nullptr;
+        c->cap_label_utts = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_count, cap * sizeof(int)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), kPinned));
+        c->cap_label_utts = cap;
+    }
+    return LCRC_OK;
+}
+
 // Decoder behind the posterior kernel: labels and counts are copied to pinned memory on the same stream.
 // h_first: host copy of the utterance offsets (first label slot of each utterance).
 int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, int n_rows, const float *d_post,
@@ -763,24 +788,7 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
     c->label_utts = 0;
     if (c->dec_P <= 0 || n_rows <= 0) return LCRC_OK;
     if (c->out_be) return fail(c, LCRC_E_ARG, "the decoder needs posteriors in host byte order (lcrc_output_configure big_endian=0)");
-    if ((size_t)n_rows > c->cap_label_rows) {
-        const size_t cap = (size_t)n_rows + n_rows / 4 + 64;
-        if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
-        c->d_labels = c->h_labels = nullptr;
-        c->cap_label_rows = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_labels, cap * sizeof(lcrc_label)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), kPinned));
-        c->cap_label_rows = cap;
-    }
-    if ((size_t)n_utts > c->cap_label_utts) {
-        const size_t cap = (size_t)n_utts + n_utts / 4 + 64;
-        if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
-        c->d_count = c->h_count = nullptr;
-        c->cap_label_utts = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_count, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), kPinned));
-        c->cap_label_utts = cap;
-    }
+    { const int rc = ensure_labels(c, (size_t)n_rows, (size_t)n_utts); if (rc) return rc; }
     PhnDecParams p;
     memset(&p, 0, sizeof p);
     p.logpost = d_post; p.off = d_off; p.n_utts = n_utts; p.cols = c->nets[2].n_out;
@@ -1453,6 +1461,27 @@ int lcrc_frontend_frames(const lcrc_ctx *c, long long n_bytes)
     return len > c->fe.vector_size ? (int)((len - c->fe.vector_size) / c->fe.vector_step + 1) : 1;
 }
 
+// LCRC_TRACE_SLOW_US=N (diagnostic): a waveform call that takes longer than N microseconds prints where it spent them
+struct SlowTrace {
+    long threshold_us;
+    int n = 0;
+    const char *what[12];
+    std::chrono::steady_clock::time_point t[12];
+    SlowTrace() { static const long th = getenv("LCRC_TRACE_SLOW_US") ? atol(getenv("LCRC_TRACE_SLOW_US")) : 0; threshold_us = th; mark("enter"); }
+    void mark(const char *w) { if (threshold_us > 0 && n < 12) { what[n] = w; t[n++] = std::chrono::steady_clock::now(); } }
+    ~SlowTrace()
+    {
+        if (threshold_us <= 0 || n < 2) return;
+        const double total = std::chrono::duration<double, std::micro>(t[n - 1] - t[0]).count();
+        if (total < (double)threshold_us) return;
+        std::string line = "lcrc slow call at " + std::to_string((long long)std::chrono::duration<double, std::micro>(t[0].time_since_epoch()).count() % 100000000LL) +
+                           " us, thread " + std::to_string((long)(size_t)pthread_self() % 1000) + " (" + std::to_string((long)total) + " us):";
+        for (int i = 1; i < n; i++)
+            line += std::string(" ") + what[i] + " +" + std::to_string((long)std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count());
+        fprintf(stderr, "%s\n", line.c_str());
+    }
+};
+
 // Shared by the two waveform entry points: stage the bytes (each utterance at an even offset),
 // run the front-end into d_mel; on return *rows = total frames.
 // Capacity of the pinned / device byte buffers of the waveform entry
@@ -1469,25 +1498,43 @@ static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
     return LCRC_OK;
 }
 
+// per-utterance offsets and means of the waveform entry (2 * n_utts + 2 entries: sample starts and counts / frame and block offsets)
+static int ensure_fe_utts(lcrc_ctx *c, size_t n_utts)
+{
+    if (2 * n_utts + 2 <= c->cap_fe_utts) return LCRC_OK;
+    if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
+    c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
+    const size_t cap = 2 * n_utts + n_utts / 2 + 64;
+    HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), kPinned));
+    HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), kPinned));
+    HIP_TRY(c, hipMalloc((void **)&c->d_means, cap * 64 * sizeof(float)));
+    c->cap_fe_utts = cap;
+    return LCRC_OK;
+}
+
+// partial sums of the tree mean (lcrc_set_mean_order(0)), one 64-float row per block of rows
+static int ensure_mean_blocks(lcrc_ctx *c, size_t blocks)
+{
+    if (blocks <= c->cap_mean_blocks) return LCRC_OK;
+    if (c->d_mean_part) (void)hipFree(c->d_mean_part);
+    c->d_mean_part = nullptr; c->cap_mean_blocks = 0;
+    const size_t cap = blocks + blocks / 4 + 64;
+    HIP_TRY(c, hipMalloc((void **)&c->d_mean_part, cap * 64 * sizeof(float)));
+    c->cap_mean_blocks = cap;
+    return LCRC_OK;
+}
+
 // The front-end over utterances that already lie in the pinned byte buffer: utterance u = bytes
 // [start[u], start[u] + len[u]) of c->h_bytes.  Leaves the features in c->d_mel.
 static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long long *len, int n_utts,
-                               long long extent, int *frame_off, int *rows, bool raw_energies = false)
+                               long long extent, int *frame_off, int *rows, bool raw_energies = false, SlowTrace *st = nullptr)
 {
     long long total_frames = 0;
     for (int u = 0; u < n_utts; u++) total_frames += lcrc_frontend_frames(c, len[u]);
     if (total_frames > 0x7fffffffLL / 256) return fail(c, LCRC_E_ARG, "waveform entry: too many frames for one call");
-    if (2 * (size_t)n_utts + 2 > c->cap_fe_utts) {
-        if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
-        c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
-        const size_t cap = 2 * (size_t)n_utts + n_utts / 2 + 64;
-        HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), kPinned));
-        HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), kPinned));
-        HIP_TRY(c, hipMalloc((void **)&c->d_means, cap * 64 * sizeof(float)));
-        c->cap_fe_utts = cap;
-    }
+    { const int rc = ensure_fe_utts(c, (size_t)n_utts); if (rc) return rc; }
     const int unit = c->fe.wave_format == 1 ? 2 : 1;
     c->h_foff[0] = 0;
     int *const h_boff = c->h_foff + n_utts + 1;      // block offsets of the tree mean, behind the frame offsets
@@ -1500,19 +1547,15 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
         h_boff[u + 1] = h_boff[u] + meannorm_blocks(fr);
     }
     c->mean_blocks = h_boff[n_utts];
-    if ((size_t)c->mean_blocks > c->cap_mean_blocks) {
-        if (c->d_mean_part) (void)hipFree(c->d_mean_part);
-        c->d_mean_part = nullptr; c->cap_mean_blocks = 0;
-        const size_t cap = (size_t)c->mean_blocks + c->mean_blocks / 4 + 64;
-        HIP_TRY(c, hipMalloc((void **)&c->d_mean_part, cap * 64 * sizeof(float)));
-        c->cap_mean_blocks = cap;
-    }
+    { const int rc = ensure_mean_blocks(c, (size_t)c->mean_blocks); if (rc) return rc; }
     for (int u = 0; u < n_utts; u++) frame_off[u] = c->h_foff[u];
     if (n_utts >= 0) frame_off[n_utts] = c->h_foff[n_utts];
     *rows = (int)total_frames;
     if (total_frames == 0) return LCRC_OK;
+    if (st) st->mark("offsets");
     int rc = ensure_staging(c, (size_t)total_frames, (size_t)n_utts);
     if (rc) return rc;
+    if (st) st->mark("staging");
     // The energies entry keeps its two transfers out of the copy engine's queue, which every context of the device shares
     // in order: the samples are pulled by a kernel, the energies stored straight into the pinned feature buffer.  As copy
     // commands they stood behind other contexts' 24 MB of posteriors on their way back, which wait for those contexts'
@@ -1529,8 +1572,10 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)extent, hipMemcpyHostToDevice, c->stream));
     }
+    if (st) st->mark("bytes copy queued");
     HIP_TRY(c, hipMemcpyAsync(c->d_soff, c->h_soff, (size_t)(2 * n_utts) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(2 * n_utts + 2) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (st) st->mark("offset copies queued");
     FrontendParams p;
     memset(&p, 0, sizeof p);
     p.bytes = c->d_bytes; p.sample_start = c->d_soff; p.frame_off = c->d_foff; p.mel = mel_out;
@@ -1587,7 +1632,7 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
 }
 
 // the part of the waveform -> posteriors entries behind the front-end
-static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
+static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post, SlowTrace *st = nullptr)
 {
     const bool copy_post = c->readback || c->dec_P <= 0;
     if (c->fe.sent_mean_norm) {
@@ -1596,18 +1641,22 @@ static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post)
         HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, c->mean_sequential ? nullptr : c->d_foff + n_utts + 1, c->mean_blocks,
                                    c->d_mean_part, n_utts, rows, c->nbanks, c->d_means, longest, c->stream));
     }
+    if (st) st->mark("mean queued");
     int rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, c->d_post, c->stream, nullptr);
     if (rc) return rc;
+    if (st) st->mark("kernels queued");
     rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
     if (rc) return rc;
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
     if (copy_post) {
         rc = ensure_host_post(c);
         if (rc) return rc;
+        if (st) st->mark("host buffer");
         HIP_TRY(c, copy_back(c, post, c->h_post, c->d_post, nbytes));   // post == NULL: read them in place (lcrc_staged_posteriors)
     } else {
         HIP_TRY(c, wait_stream(c));
     }
+    if (st) st->mark("done");
     return LCRC_OK;
 }
 
@@ -1636,6 +1685,60 @@ int lcrc_wave_stage_buffer(lcrc_ctx *c, long long capacity, unsigned char **byte
     int rc = ensure_wave_bytes(c, capacity);
     if (rc) return rc;
     *bytes = c->h_bytes;
+    return LCRC_OK;
+}
+
+// Every buffer a later call of up to max_rows frames in max_utts utterances (and max_wave_bytes of waveform, 0: the
+// frame entries only) would allocate on demand, allocated now: device staging, pinned features and posteriors, byte
+// buffers, per-utterance offsets.  What on-demand growth costs is page pinning -- 744 B per HU frame, ~8 ms per
+// 32 768 frames -- inside the first call; a caller with a warm-up phase (the CLI, while its list is still being opened)
+// pays it there, all contexts at once.
+int lcrc_reserve(lcrc_ctx *c, int max_rows, int max_utts, long long max_wave_bytes)
+{
+    if (!c) return LCRC_E_ARG;
+    if (max_rows < 0 || max_utts < 0 || max_wave_bytes < 0) return fail(c, LCRC_E_ARG, "lcrc_reserve: negative size");
+    if (max_wave_bytes > 0 && !c->fe_ready) return fail(c, LCRC_E_ARG, "lcrc_reserve: waveform bytes asked for before lcrc_frontend_configure");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
+    if (rc) return rc;
+    if (c->readback || c->dec_P <= 0) {
+        rc = ensure_host_post(c);
+        if (rc) return rc;
+    }
+    if (c->system == SYS_LCRC && !c->d_part && c->split_hint != 1 && c->arith == 0) ensure_split_scratch(c);
+    if (c->dec_P > 0) {
+        rc = ensure_labels(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
+        if (rc) return rc;
+    }
+    if (max_wave_bytes > 0) {
+        rc = ensure_wave_bytes(c, max_wave_bytes);
+        if (rc) return rc;
+        rc = ensure_fe_utts(c, (size_t)max_utts);
+        if (rc) return rc;
+        rc = ensure_mean_blocks(c, (size_t)meannorm_blocks(max_rows) + (size_t)max_utts);
+        if (rc) return rc;
+    }
+    // The copy engines.  The runtime creates an SDMA queue the first time it uses an engine (~13 ms each, startup_probe:
+    // "first copy"), and picks a further engine whenever the ones it has are busy -- which, with several contexts copying
+    // bytes in and posteriors out at once, happened twice in the first 40 ms of every list, EVERY copy of the process waiting
+    // meanwhile (tools/pipeline_trace.py: hipMemcpyAsync blocking 13-15 ms).  So the buffers make a few round trips now, in
+    // both directions at once; contexts reserved from parallel threads overlap the way a list's launches will.
+    if (max_rows >= 4096) {
+        const size_t post_bytes = (size_t)max_rows * c->nets[2].n_out * sizeof(float);
+        const size_t mel_bytes = (size_t)max_rows * c->nbanks * sizeof(float);
+        for (int round = 0; round < 3; round++) {
+            if (max_wave_bytes > 0) HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)max_wave_bytes, hipMemcpyHostToDevice, c->stream));
+            else HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, mel_bytes, hipMemcpyHostToDevice, c->stream));
+            if (c->h_post) {                                   // in pieces, the way copy_back() queues them
+                const size_t step = ((post_bytes / kCopyPieces) + 255) & ~(size_t)255;
+                for (int k = 0; k < kCopyPieces; k++) {
+                    const size_t lo = (size_t)k * step, n = k + 1 == kCopyPieces ? post_bytes - lo : step;
+                    HIP_TRY(c, hipMemcpyAsync((char *)c->h_post + lo, (const char *)c->d_post + lo, n, hipMemcpyDeviceToHost, c->stream));
+                }
+            }
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return LCRC_OK;
 }
 
@@ -1681,9 +1784,11 @@ int lcrc_wave_stage_run(lcrc_ctx *c, const long long *start, const long long *n_
     }
     if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: beyond the capacity lcrc_wave_stage_buffer reserved");
     int rows = 0;
-    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows);
+    SlowTrace st;
+    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, false, &st);
     if (rc || rows == 0) { c->label_utts = 0; return rc; }
-    return wave_finish(c, n_utts, rows, post);
+    st.mark("front-end queued");
+    return wave_finish(c, n_utts, rows, post, &st);
 }
 
 int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty)

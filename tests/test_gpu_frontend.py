@@ -267,3 +267,43 @@ def test_zero_copy_waveform_staging(capi):
     assert bad == capi_mod.LCRC_E_ARG                          # overlap
     bad = ctx.L.lcrc_wave_stage_run(ctx.h, np.array([0], np.int64), np.array([1 << 30], np.int64), 1, post, foff)
     assert bad == capi_mod.LCRC_E_ARG                          # beyond the reserved capacity
+
+
+def test_reserve_allocates_ahead_and_changes_nothing(capi):
+    """lcrc_reserve: the buffers of later calls exist afterwards (the staging pointers handed out before a call of the
+    reserved size are the ones handed out after it), results are the same bits as without it, misuse is rejected"""
+    import ctypes as C
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    blobs = [raw, raw[:30001], raw[:4001]]
+    plain = capi.Lcrc(model_dir(system), 15)
+    with pytest.raises(capi.LcrcError):
+        plain.reserve(100, 4, 1000)                            # waveform bytes before lcrc_frontend_configure
+    with pytest.raises(capi.LcrcError):
+        plain.reserve(-1, 4)
+    fe = dict(wave_format="lin16", sample_freq=8000, vector_size=200, vector_step=80, lower_freq=64.0, higher_freq=4000.0,
+              sent_mean_norm=True)
+    plain.configure_frontend(**fe)
+    want, fw = plain.wave_to_posteriors_staged(blobs)
+    ctx = capi.Lcrc(model_dir(system), 15)
+    ctx.configure_frontend(**fe)
+    ctx.reserve(4096, 8, 400000)
+    buf0, buf1 = C.POINTER(C.c_ubyte)(), C.POINTER(C.c_ubyte)()
+    pm0, pp0, pm1, pp1 = (C.POINTER(C.c_float)() for _ in range(4))
+    assert ctx.L.lcrc_wave_stage_buffer(ctx.h, 1000, C.byref(buf0)) == 0
+    assert ctx.L.lcrc_stage_buffers(ctx.h, 16, C.byref(pm0), C.byref(pp0)) == 0
+    got, fg = ctx.wave_to_posteriors_staged(blobs)             # 1000+ frames, 150 kB: within what was reserved
+    assert np.array_equal(fw, fg) and np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert ctx.L.lcrc_wave_stage_buffer(ctx.h, 300000, C.byref(buf1)) == 0
+    assert ctx.L.lcrc_stage_buffers(ctx.h, 4096, C.byref(pm1), C.byref(pp1)) == 0
+    addr = lambda p: C.cast(p, C.c_void_p).value
+    assert addr(buf0) == addr(buf1) and addr(pm0) == addr(pm1) and addr(pp0) == addr(pp1)
+    ctx.reserve(0, 0)                                          # nothing to do
+    # the frame entry and the decoder's buffers
+    rng = np.random.default_rng(5)
+    mel = rng.standard_normal((500, 15)).astype(np.float32)
+    a = plain.posteriors(mel)
+    ctx.configure_decoder(45, 3, 21, -3.8)
+    ctx.reserve(4096, 8)
+    b = ctx.posteriors(mel)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
