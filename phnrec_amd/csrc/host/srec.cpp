@@ -1118,6 +1118,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     // libm and the normalisations follow here, in the pinned buffer the posterior kernel then reads in place
                     float *feat = nullptr;
                     if (!tr.WaveStageEnergies(bstart.data(), blen.data(), cnt, &feat, foff.data())) { abort_run(tr.LastError()); return; }
+                    trace(g, "energies back");
                     if (foff[cnt] > 0) {
                         const float shift = C.GetFloat("framenorm", "shift"), floor_ = C.GetFloat("framenorm", "min_floor");
                         pool_->ParallelFor(cnt, [&](int k) {
@@ -1133,8 +1134,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                         }, frame_grain(cnt, foff[cnt]));
                         float *h_mel = nullptr, *hp = nullptr;
                         if (!tr.StageBuffers(foff[cnt], &h_mel, &hp) || h_mel != feat) { abort_run("staging buffers moved under -E"); return; }
+                        trace(g, "features ready");
                         SlotHold hold(slots, tr);
+                        trace(g, "slot");
                         if (!tr.StageRun(foff.data(), cnt)) { abort_run(tr.LastError()); return; }
+                        trace(g, "run returned");
                         h_post = hp;
                     }
                 } else {

@@ -3,7 +3,7 @@
 PHNREC_TRACE_PIPELINE=1 (the workers' steps, time-stamped) and LCRC_TRACE_SLOW_US (library calls that took longer than
 that, with the step that took it), followed by the process wall clock with and without the set-up step that reserves the
 contexts' buffers (PHNREC_NO_RESERVE=1).
-usage: pipeline_trace.py [n_files]      env TRACE_CHARS: how much of the trace to print"""
+usage: pipeline_trace.py [n_files]      env TRACE_CHARS: how much of the trace to print; TRACE_FLAGS: "-F;-F -D;" (modes, ';'-separated)"""
 import os
 import subprocess
 import sys
@@ -20,7 +20,7 @@ mdir = os.path.join("tests", "golden", "models", bench.HU)
 n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 with tempfile.TemporaryDirectory(dir="/tmp") as td:
     lst, names, frames = bench.synthetic_list(td, n_files)
-    for flags in (["-F"], ["-F", "-D"], []):
+    for flags in [f.split() for f in os.environ.get("TRACE_FLAGS", "-F;-F -D;").split(";")]:
         for rep in range(2):
             env = dict(os.environ, PHNREC_STATS="1", PHNREC_TRACE_PIPELINE="1", LCRC_TRACE_SLOW_US=os.environ.get("LCRC_TRACE_SLOW_US", "5000"))
             p = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "o.mlf"), "-g", "1"] + flags, env=env, capture_output=True, text=True)
@@ -30,7 +30,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
     if os.environ.get("TRACE_ONLY"):
         sys.exit(0)
     print("===== process wall clock, best of 5 (list wall in brackets)")
-    for flags in (["-F"], ["-F", "-D"], []):
+    for flags in (["-F"], ["-F", "-D"], ["-E"], []):
         for extra in ({}, {"PHNREC_NO_RESERVE": "1"}):
             best = None
             for rep in range(5):
