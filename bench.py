@@ -339,10 +339,12 @@ def wave_path_leg(capi, mdir, nb, gpu, raw=None, wave_format="alaw", sent_mean_n
     # sentence mean in the reference's sequential order (the library's default) and as the opt-in tree
     for key, order in (("value", 1), ("tree_mean_value", 0)) if sent_mean_norm else (("value", 1),):
         ctx._check(ctx.L.lcrc_set_mean_order(ctx.h, order))
-        for _ in range(3):
+        # (50 untimed calls first, ~25 ms of load: the legs before this one leave the device idle for long enough that it
+        #  clocks down, and 30 calls straight after 3 warm-up calls measured its ramp -- 0.50 to 0.88 ms on the same box)
+        for _ in range(50):
             ctx._check(ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff))
         ts = []                                  # median of single calls: one hiccup of the host does not move it
-        for _ in range(30):
+        for _ in range(40):
             t0 = time.perf_counter()
             ctx.L.lcrc_wave_to_posteriors(ctx.h, rawb, off, 1, post, foff)
             ts.append(time.perf_counter() - t0)
@@ -840,7 +842,7 @@ def main():
                 #  its page faults -- 0.3 ms for 4.5 MB of posteriors -- to every call)
                 reps = 20
                 h_post = np.empty((args.batch, ctx.n_out), np.float32)
-                for _ in range(3):
+                for _ in range(10):
                     ctx._check(ctx.L.lcrc_posteriors(ctx.h, mel, args.batch, h_post))
                 ts = []
                 for _ in range(reps):
@@ -859,12 +861,14 @@ def main():
                 ctx._check(ctx.L.lcrc_stage_buffers(ctx.h, args.batch, C.byref(pm), C.byref(pp)))
                 C.memmove(pm, mel.ctypes.data, mel.nbytes)
                 one = np.array([0, args.batch], np.int32)
-                for _ in range(3):
+                for _ in range(10):
                     ctx._check(ctx.L.lcrc_stage_run(ctx.h, one, 1))
-                t0 = time.perf_counter()
+                ts = []
                 for _ in range(reps):
+                    t0 = time.perf_counter()
                     ctx.L.lcrc_stage_run(ctx.h, one, 1)
-                dt = (time.perf_counter() - t0) / reps
+                    ts.append(time.perf_counter() - t0)
+                dt = float(np.median(ts))
                 line["host_path_zero_copy"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
                                                "ms_per_call": round(dt * 1e3, 4),
                                                "what": "lcrc_stage_run() on the context's pinned buffers: kernel on the features in place (mapped) + D2H, "

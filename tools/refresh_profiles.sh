@@ -33,6 +33,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
 done
 echo "pmc done"
 python3 tools/stamp_profile.py > $OUT/phase_stamps.txt 2>&1
+# (the shipped plan since round 4: pairs of 16-frame workgroups per CU)
+LCRC_BM=16 python3 tools/stamp_profile.py PHN_CZ_SPDAT_LCRC_N1500 8192 >> $OUT/phase_stamps.txt 2>&1
 LCRC_BM=16 python3 tools/stamp_profile.py PHN_CZ_SPDAT_LCRC_N1500 4096 >> $OUT/phase_stamps.txt 2>&1
 python3 tools/stamp_profile.py PHN_EN_TIMIT_LCRC_N500 8192 >> $OUT/phase_stamps.txt 2>&1
 LCRC_BM=16 python3 tools/stamp_profile.py PHN_EN_TIMIT_LCRC_N500 4096 >> $OUT/phase_stamps.txt 2>&1

@@ -84,15 +84,19 @@ def main():
     ids = np.unique(cu)
     per_cu = np.array([(cu == c).sum() for c in ids])
     print("CUs used: %d; workgroups per CU: min %d max %d" % (len(ids), per_cu.min(), per_cu.max()))
-    ov, spans = [], []
+    ov, spans, start_gap, end_gap = [], [], [], []
     for c in ids:
         bb, ee = b[cu == c], e[cu == c]
         spans.append(ee.max() - bb.min())
         if len(bb) == 2:
             ov.append((min(ee) - max(bb)) / float(max(ee) - min(bb)))
+            start_gap.append(max(bb) - min(bb))
+            end_gap.append(max(ee) - min(ee))
     print("busy span per CU (first start -> last end): median %d max %d" % (np.median(spans), np.max(spans)))
     if ov:
         print("CUs with two workgroups: %d; overlap of their lifetimes: median %.2f min %.2f" % (len(ov), np.median(ov), np.min(ov)))
+        print("  second workgroup starts after the first by: median %d min %d max %d cycles; ends after it by: median %d min %d max %d"
+              % (np.median(start_gap), np.min(start_gap), np.max(start_gap), np.median(end_gap), np.min(end_gap), np.max(end_gap)))
     print("XCC ids seen:", sorted(set(((hw >> 32) & 0xF).tolist())), " sample HW_ID:", [hex(int(x & 0xFFFFFFFF)) for x in hw[:4]])
 
 
