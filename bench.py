@@ -477,6 +477,9 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         # (from two GPUs on the CLI called without flags computes the energies on the GPU by itself -- the same output bytes:
         #  `host_frontend` then IS the -E road; PHNREC_NO_AUTO_E=1 would keep the pure host front-end)
         out["host_frontend_takes_E_road"] = n_gpus >= 2
+        # (and from four GPUs on a list that ends in labels decodes on the GPUs by itself -- bit-identical labels, the
+        #  Viterbi off the host's cores: every mode below is then `... -D`; PHNREC_NO_AUTO_D=1 would keep the host decoder)
+        out["every_mode_decodes_on_the_gpu"] = n_gpus >= 4
         env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=",".join(str(d) for d in dmap))
         mlfs = {}
         for key, extra in (("host_frontend", []), ("gpu_energies_E", ["-E"]), ("gpu_frontend_F", ["-F"]),

@@ -138,7 +138,6 @@ int main(int argc, char **argv)
     if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     SR.SetGpus(gpus);
     if (batch > 0) SR.SetBatchFrames(batch);
-    else if (gpu_dec) SR.SetBatchFrames(65536);      // one decoder wave per utterance: twice the utterances per launch keep more SIMDs busy
     if (threads > 0) SR.SetHostThreads(threads);
     if (gpu_fe && gpu_en) Die("-F and -E are two forms of the GPU front-end: give one\n");
     SR.SetGpuFrontend(gpu_fe);

@@ -799,6 +799,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
     }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
+    bool auto_decoder = false;
     // A list over two or more GPUs, called as the reference is called (no -F, no -E): the host front-end's 0.36 us per
     // frame and core would feed 1.4 GPUs on 16 cores.  -E produces the same features bit for bit (tests compare dumps and
     // MLFs byte for byte) at a fifth of the CPU time, so it is switched on by itself there; one GPU is served faster by
@@ -806,6 +807,18 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     if (need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ && n_gpus_ >= 2 && gpus_.empty() &&
         wave_.noise_level == 0.0f && !getenv("PHNREC_NO_AUTO_E"))
         gpu_energies_ = true;
+    // A list over four or more GPUs that ends in labels: the decoder runs on the GPUs too (-D) by itself.  Its labels are the
+    // host decoder's bit for bit (tested), it costs a GPU 1-3 % of its rate and takes the Viterbi -- half of what is left
+    // of the host's work with -F, a third with -E -- off the cores that eight GPUs' lists otherwise bring to their limit
+    // (0.44-0.58 CPU-seconds per 8.9 M frames against the 0.6 that 16 cores have while eight GPUs compute them).
+    // PHNREC_NO_AUTO_D=1 keeps the host decoder.
+    if (need_gpu && !single_file && out == dfStrings && !gpu_decoder_ && n_gpus_ >= 4 && gpus_.empty() &&
+        !phn_names_.empty() && phn_names_.size() <= 64 && states_per_phn_ >= 1 && states_per_phn_ <= 4 && time_pruning_ >= 1 &&
+        time_pruning_ <= 63 && !getenv("PHNREC_NO_AUTO_D"))
+        gpu_decoder_ = auto_decoder = true;
+    // frames per launch: 32 768; with the decoder on the GPU 65 536 (one decoder wave per utterance and a launch as long as
+    // its longest utterance: twice the utterances per launch, half the launches); -b overrides
+    if (!batch_given_) batch_frames_ = need_gpu && gpu_decoder_ && out == dfStrings ? 65536 : 32768;
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
         // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the
@@ -824,6 +837,12 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             CPU_OR(&all, &all, &one);
         }
         if (every) pool_->SetAffinity(all);
+    }
+    // (a model the device decoder does not take -- more states than posterior outputs, say -- keeps the host decoder
+    //  when -D was this function's own idea)
+    if (auto_decoder && (int)phn_names_.size() * states_per_phn_ > n_out_) {
+        gpu_decoder_ = false;
+        if (!batch_given_) batch_frames_ = 32768;
     }
     const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
     std::vector<std::string> phn_names;

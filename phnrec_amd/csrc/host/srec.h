@@ -96,7 +96,7 @@ public:
     void SetWaveFormat(WaveFormat f) { wave_.format = f; }
     void SetWPenalty(float p) { wpenalty_ = p; wpenalty_set_ = true; }
     void SetGpus(int n) { n_gpus_ = n; }
-    void SetBatchFrames(int n) { batch_frames_ = n; }
+    void SetBatchFrames(int n) { batch_frames_ = n; batch_given_ = true; }
     void SetHostThreads(int n) { host_threads_ = n; }
     void SetGpuDecoder(bool v) { gpu_decoder_ = v; }     // -D: PhnDec on the GPU, posteriors never leave it
     void SetSplitF16(bool v) { split_f16_ = v; }         // -H: lcrc_set_arithmetic(LCRC_ARITH_SPLIT_F16)
@@ -148,6 +148,7 @@ private:
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_energies_ = false, gpu_decoder_ = false, split_f16_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
+    bool batch_given_ = false;           // -b: otherwise 32 768 frames per launch, 65 536 with the decoder on the GPU
     float wpenalty_ = -2.0f;
     bool wpenalty_set_ = false;
     int states_per_phn_ = 1, time_pruning_ = 40;

@@ -212,6 +212,28 @@ def test_two_gpus_called_as_the_reference_take_the_energies_road(tmp_path):
     assert stage1(b) < 0.5 * stage1(a) and stage1(c) > 0.5 * stage1(a)
 
 
+def test_four_gpus_decode_on_the_device_by_themselves(tmp_path):
+    """`phnrec -g 4 -l ... -m ...` (four logical GPUs on this box's one) switches the device decoder on by itself: no
+    Viterbi time on the host, the MLF the one `-g 1` writes with the host decoder, byte for byte; PHNREC_NO_AUTO_D=1 keeps
+    the host decoder; -b still decides the launch size"""
+    lst = _make_list(tmp_path, "hu", 150, seed=29)
+    one, four, four_host, four_b = tmp_path / "g1.mlf", tmp_path / "g4.mlf", tmp_path / "g4h.mlf", tmp_path / "g4b.mlf"
+    env4 = {"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0,0,0"}
+    a = run("-c", model_dir(HU), "-l", lst, "-m", one, "-F", env={"PHNREC_STATS": "1"})
+    b = run("-c", model_dir(HU), "-l", lst, "-m", four, "-F", "-g", 4, env=env4)
+    c = run("-c", model_dir(HU), "-l", lst, "-m", four_host, "-F", "-g", 4, env=dict(env4, PHNREC_NO_AUTO_D="1"))
+    d = run("-c", model_dir(HU), "-l", lst, "-m", four_b, "-g", 4, "-b", 5000, env=env4)       # (no -F: the -E road + decoder)
+    assert one.read_text() == four.read_text() == four_host.read_text()
+    host = tmp_path / "host.mlf"
+    run("-c", model_dir(HU), "-l", lst, "-m", host)
+    assert host.read_text() == four_b.read_text()
+
+    def viterbi(p):
+        line = [l for l in p.stderr.splitlines() if l.startswith("phnrec: files=")][-1]
+        return float(line.split("viterbi=")[1].split(")")[0])
+    assert viterbi(a) > 0 and viterbi(c) > 0 and viterbi(b) == 0 and viterbi(d) == 0
+
+
 def test_gpu_energies_flag_on_a_list(tmp_path):
     """-E over a list (150 synthetic files, several launches, two logical GPUs): the MLF equals the default mode's byte
     for byte, and so does every posterior dump"""
