@@ -93,6 +93,20 @@ def main():
             start_gap.append(max(bb) - min(bb))
             end_gap.append(max(ee) - min(ee))
     print("busy span per CU (first start -> last end): median %d max %d" % (np.median(spans), np.max(spans)))
+    if per_cu.min() == 2 and per_cu.max() == 2:
+        # the pair's two workgroups separately: phase by phase, the one that ends first and the one that ends last
+        first, last = [], []
+        for c in ids:
+            w = np.nonzero(cu == c)[0]
+            w = w[np.argsort(e[w])]
+            first.append(w[0]); last.append(w[1])
+        print("%-46s %12s %12s" % ("phase (slowest wave), pairs", "ends first", "ends last"))
+        for i, name in enumerate(NAMES):
+            per_wg = d[:, :, i].max(axis=1)
+            print("%-46s %12.0f %12.0f" % (name, np.median(per_wg[first]), np.median(per_wg[last])))
+        print("%-46s %12.0f %12.0f" % ("workgroup total", np.median(tot.max(axis=1)[first]), np.median(tot.max(axis=1)[last])))
+        lo = np.array([min(w) for w in zip(first, last)])
+        print("the workgroup that ends first is the one with the lower index in %d of %d pairs" % ((np.array(first) == lo).sum(), len(first)))
     if ov:
         print("CUs with two workgroups: %d; overlap of their lifetimes: median %.2f min %.2f" % (len(ov), np.median(ov), np.min(ov)))
         print("  second workgroup starts after the first by: median %d min %d max %d cycles; ends after it by: median %d min %d max %d"
