@@ -868,15 +868,20 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // A list: every context's buffers for launches of batch_frames_, allocated here, all contexts at once, instead of
         // inside each context's first launch (pinning 30 MB of posterior buffer is 5-10 ms, and the runtime lets other
         // contexts' copies wait meanwhile: the first 40 ms of a list ran at a third of the steady rate).
-        if (!single_file && !getenv("PHNREC_NO_RESERVE")) {
+        // (lists of at least ~100 entries, by the size of the list file: a short list's launches never fill such buffers and
+        //  its few files are done sooner than 3 x 40 MB are pinned)
+        if (!single_file && long_list_ && !getenv("PHNREC_NO_RESERVE")) {
+            // (a -b beyond 131 072 frames is reserved up to that: a short list would never fill the rest, the buffers grow
+            //  on demand as before)
+            const int rows = std::min(batch_frames_, 131072);
             long long wave_bytes = 0;
             if ((gpu_frontend_ || gpu_energies_) && in == dfWaveform)
-                wave_bytes = ((long long)batch_frames_ * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
+                wave_bytes = ((long long)rows * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
                              (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
             std::vector<std::string> errs(gpus_.size());
             std::vector<std::thread> th;
             for (size_t i = 0; i < gpus_.size(); i++)
-                th.emplace_back([&, i] { if (!gpus_[i]->Reserve(batch_frames_, 256, wave_bytes)) errs[i] = gpus_[i]->LastError() + "\n"; });
+                th.emplace_back([&, i] { if (!gpus_[i]->Reserve(rows, 256, wave_bytes)) errs[i] = gpus_[i]->LastError() + "\n"; });
             for (auto &t : th) t.join();
             for (const std::string &e : errs) if (!e.empty()) return Fail(e);
         }
@@ -1317,6 +1322,10 @@ bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string
 {
     FILE *fl = fopen(list.c_str(), "r");
     if (!fl) return Fail("Can not open the file list: " + list + "\n");
+    {
+        struct stat st;
+        long_list_ = fstat(fileno(fl), &st) == 0 && st.st_size >= 4096;
+    }
     FILE *mlf = nullptr;
     if (!mlf_path.empty()) {
         mlf = fopen(mlf_path.c_str(), "w");

@@ -148,6 +148,7 @@ private:
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_energies_ = false, gpu_decoder_ = false, split_f16_ = false;
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
+    bool long_list_ = false;             // the list file has >= 4 KB (~100 entries): buffers are reserved ahead of the first launch
     bool batch_given_ = false;           // -b: otherwise 32 768 frames per launch, 65 536 with the decoder on the GPU
     float wpenalty_ = -2.0f;
     bool wpenalty_set_ = false;
