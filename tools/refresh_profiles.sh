@@ -49,7 +49,7 @@ python3 tools/traps_bench.py > $OUT/traps_bench.txt 2>&1
 echo "sweeps done"
 for i in 1 2 3; do ./tools/ubench/hip_startup; done > $OUT/startup_probe.txt 2>&1
 for m in 0 1 2 3 4; do ./tools/ubench/hip_upload $m; done >> $OUT/startup_probe.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wave_stats -- python3 tools/frontend_bench.py > $OUT/frontend_bench.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wave_stats -- python3 tools/frontend_bench.py 400 > $OUT/frontend_bench.txt 2>&1      # (400 calls: all but the first ~50 at the steady clock)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/traps_stats -- python3 tools/traps_bench.py > $OUT/traps_prof.txt 2>&1
 # split-f16 arithmetic (opt-in): both arithmetics side by side, its own kernel stats
 python3 tools/split_f16_bench.py > $OUT/split_f16_bench.txt 2>&1
