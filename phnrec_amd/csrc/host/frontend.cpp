@@ -1,5 +1,6 @@
 // frontend.cpp -- see frontend.h
 #include "frontend.h"
+#include "veclog.h"
 
 #include "../meltables.h"
 
@@ -321,10 +322,8 @@ void MelBanks::Frame16(const float *s, float *out)
         if (b < nbanks_full_) _mm512_storeu_ps(en + 16 * b, _mm512_add_ps(_mm512_loadu_ps(en + 16 * b), _mm512_sub_ps(p, v)));
     }
     for (int f = 0; f < 16; f++)
-        for (int b = 0; b < nbanks_; b++) {
-            const float e = en[16 * b + f];
-            out[(size_t)f * nbanks_ + b] = e > 0.0f ? logf(e) : 0.0f;                    // sLn (libm's scalar logf)
-        }
+        for (int b = 0; b < nbanks_; b++) out[(size_t)f * nbanks_ + b] = en[16 * b + f];
+    LnInPlace(out, (size_t)16 * nbanks_);                // sLn: libm's logf, bit for bit, sixteen values at a time (veclog.cpp)
 }
 
 // MelBanks::ProcessFrame for the eight frames that start at s, s + step, ...: out[f * nbanks + b]
@@ -363,10 +362,8 @@ void MelBanks::Frame8(const float *s, float *out)
         if (b < nbanks_full_) _mm256_storeu_ps(en + 8 * b, _mm256_add_ps(_mm256_loadu_ps(en + 8 * b), _mm256_sub_ps(p, v)));
     }
     for (int f = 0; f < 8; f++)
-        for (int b = 0; b < nbanks_; b++) {
-            const float e = en[8 * b + f];
-            out[(size_t)f * nbanks_ + b] = e > 0.0f ? logf(e) : 0.0f;                    // sLn (libm's scalar logf)
-        }
+        for (int b = 0; b < nbanks_; b++) out[(size_t)f * nbanks_ + b] = en[8 * b + f];
+    LnInPlace(out, (size_t)8 * nbanks_);                 // sLn (veclog.cpp: libm's logf per value on hosts without AVX-512)
 }
 
 void MelBanks::Compute(std::vector<float> &samples, int n, std::vector<float> &out)

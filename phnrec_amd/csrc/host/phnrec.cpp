@@ -10,6 +10,7 @@
 #include <string>
 
 #include "srec.h"
+#include "veclog.h"
 
 using namespace phnrec;
 
@@ -87,6 +88,12 @@ int main(int argc, char **argv)
     WaveFormat wformat = WF_UNKNOWN;
 
     if (argc == 1) { Help(); return 1; }
+    if (argc == 2 && strcmp(argv[1], "--selftest-ln") == 0) {
+        // the host front-end's ln() over every non-negative float against this process's libm (veclog.cpp)
+        const long long bad = LnSelfTest(0);
+        printf("ln(): %s; %lld of 2^31 non-negative values (and a stride of the negative ones) differ from logf()\n", LnForm(), bad);
+        return bad == 0 ? 0 : 1;
+    }
     int ind = 0;
     for (;;) {
         const char *arg = nullptr;

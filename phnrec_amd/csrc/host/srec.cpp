@@ -1,5 +1,6 @@
 // srec.cpp -- see srec.h
 #include "srec.h"
+#include "veclog.h"
 
 #include <fcntl.h>
 #include <sched.h>
@@ -1150,7 +1151,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                             float *x = feat + (size_t)foff[k] * nbanks_;
                             const int fr = foff[k + 1] - foff[k];
                             const size_t nv = (size_t)fr * nbanks_;
-                            for (size_t i = 0; i < nv; i++) x[i] = x[i] > 0.0f ? logf(x[i]) : 0.0f;      // sLn, dspc.h:155-160
+                            LnInPlace(x, nv);                                                            // sLn, dspc.h:155-160 (veclog.cpp)
                             if (shift != 0.0f) for (size_t i = 0; i < nv; i++) x[i] += shift;            // srec.cpp:1594-1620
                             if (floor_ != -9999.9f) for (size_t i = 0; i < nv; i++) if (x[i] < floor_) x[i] = floor_;
                             if (fr > 0 && sent_mean_norm_) SentenceMeanNorm(x, fr, nbanks_);

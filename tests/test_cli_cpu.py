@@ -421,3 +421,15 @@ def test_front_end_eight_frames_in_lockstep_equals_the_plain_form(tmp_path, syst
                 outs.append(out.read_bytes())
             assert outs[0] == outs[1] == outs[2], (frames, fmt)
             assert read_htk_header(str(tmp_path / "o0.mel"))[0] == (frames if fmt == "lin16" else (2 * n - vs) // step + 1)
+
+
+def test_vector_ln_is_this_hosts_logf_everywhere():
+    """The host front-end's ln() (host/veclog.cpp: glibc's logf restated on AVX-512 registers, used only after a check
+    against this process's libm) equals logf() on EVERY non-negative float and a stride of the negative bit patterns:
+    `phnrec --selftest-ln` counts the differences.  On a host without AVX-512, or with a libm whose logf is another
+    algorithm, the vector form switches itself off and the count is trivially zero -- the line says which form ran."""
+    p = subprocess.run([BIN, "--selftest-ln"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 of 2^31" in p.stdout, p.stdout
+    q = subprocess.run([BIN, "--selftest-ln"], capture_output=True, text=True, env=dict(os.environ, PHNREC_NO_VECTOR_LN="1"))
+    assert q.returncode == 0 and "libm logf per value" in q.stdout, q.stdout
