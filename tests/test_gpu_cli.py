@@ -212,6 +212,13 @@ def test_two_gpus_called_as_the_reference_take_the_energies_road(tmp_path):
     assert stage1(b) < 0.5 * stage1(a) and stage1(c) > 0.5 * stage1(a)
 
 
+def test_vector_ln_on_this_boxs_host():
+    """the host's ln() (host/veclog.cpp) against libm's logf over every non-negative float, on the GPU box's own CPU and libm
+    (the CPU suite runs the same check in the build container)"""
+    p = subprocess.run([BIN, "--selftest-ln"], capture_output=True, text=True)
+    assert p.returncode == 0 and " 0 of 2^31" in p.stdout, p.stdout + p.stderr
+
+
 def test_four_gpus_decode_on_the_device_by_themselves(tmp_path):
     """`phnrec -g 4 -l ... -m ...` (four logical GPUs on this box's one) switches the device decoder on by itself: no
     Viterbi time on the host, the MLF the one `-g 1` writes with the host decoder, byte for byte; PHNREC_NO_AUTO_D=1 keeps
