@@ -10,8 +10,10 @@
 //   CalcInputFeaturesForMerger    traps.cpp:435-461  -> ln() + merger normalisation straight into the
 //                                                       merger's operand image in LDS
 //
-// Geometry.  A workgroup owns 16*FT consecutive frames (FT = 2 16-frame MFMA column
-// tiles when the launch fills the GPU that way, FT = 1 for smaller launches) and
+// Geometry.  A workgroup owns 16*FT consecutive frames (FT = 1 or 2 16-frame MFMA column
+// tiles: lcrc_launch runs whole rounds as PAIRS of 16-frame workgroups per CU where two
+// of them fit side by side -- every shipped shape --, one 32-frame workgroup per CU
+// otherwise, and smaller launches as one 16-frame workgroup per CU) and
 // has NW = 4 waves, one per SIMD, which split the HIDDEN dimension of a net: first
 // the two band classifiers side by side (waves 0,1: left context, waves 2,3: right
 // context -- they have the same shape and do not depend on each other), then the
