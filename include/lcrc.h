@@ -32,7 +32,9 @@ extern "C" {
 
 /* 2: lcrc_clone; sentence mean in the reference's order by default; split-f16 operand images built on request and
  *    scaled (any finite weights); lcrc_debug_fail_alloc needs LCRC_FAULT_INJECTION=1 in the environment */
-#define LCRC_ABI_VERSION 2
+/* 3: additions only (every version-2 caller links and behaves as before): lcrc_device_pci_bus_id,
+ *    lcrc_set_kernel_done_callback, lcrc_wave_stage_energies, lcrc_reserve */
+#define LCRC_ABI_VERSION 3
 
 enum {
     LCRC_OK        = 0,
