@@ -1112,6 +1112,9 @@ int lcrc_device_warmup(int device_id)
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
     HIP_TRY(nullptr, hipSetDevice(device_id));
     HIP_TRY(nullptr, hipFree(nullptr));                 // brings the device's primary context up
+    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights): LCRC_NO_PRELOAD=1
+    // leaves it to the first launch
+    if (!getenv("LCRC_NO_PRELOAD")) (void)lcrc_preload_code();
     return LCRC_OK;
 }
 

@@ -187,6 +187,7 @@ hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream);
 
 // launcher (lcrc_kernels.hip)
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);
+hipError_t lcrc_preload_code();
 // scratch the split-hidden path needs for `wgs` workgroups (bytes of part / gimg / cnt); 0,0,0 when the
 // model has no split kernels
 void lcrc_split_scratch(const NetDev *nets, int wgs, size_t *part_bytes, size_t *gimg_bytes, size_t *cnt_bytes);

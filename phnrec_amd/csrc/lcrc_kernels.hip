@@ -926,4 +926,12 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     return hipSuccess;
 }
 
+// Brings this file's code object onto the current device (the runtime loads a file's kernels the first time one of them is
+// asked about or launched: 10-25 ms for this one, which otherwise falls into a process's first launch).
+hipError_t lcrc_preload_code()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, kVariants[0].fn[0]);
+}
+
 }  // namespace phnrec
