@@ -155,8 +155,9 @@ int lcrc_posteriors_rows(lcrc_ctx *ctx, const float *mel, int n_rows, int row_fi
  * (this repository's SpeechRec does): lcrc_stage_buffers returns pinned host buffers owned
  * by the context with room for `rows` frames (valid until the next lcrc_stage_buffers call
  * with a larger size, or lcrc_destroy); the caller writes mel[rows][nbanks] into *mel,
- * calls lcrc_stage_run (H2D, kernel, D2H, synchronous) and reads post[rows][n_out] from
- * *post.  `rows` of lcrc_stage_run is off[n_utts]. */
+ * calls lcrc_stage_run (synchronous: the kernel reads the features where they lie and stores
+ * the posteriors straight into *post, both over PCIe while it runs -- no copy commands) and
+ * reads post[rows][n_out] from *post.  `rows` of lcrc_stage_run is off[n_utts]. */
 int lcrc_stage_buffers(lcrc_ctx *ctx, int rows, float **mel, float **post);
 int lcrc_stage_run(lcrc_ctx *ctx, const int *off, int n_utts);
 
