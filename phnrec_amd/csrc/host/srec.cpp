@@ -871,11 +871,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // contexts' copies wait meanwhile: the first 40 ms of a list ran at a third of the steady rate).
         // (lists of at least ~100 entries, by the size of the list file: a short list's launches never fill such buffers and
         //  its few files are done sooner than 3 x 40 MB are pinned)
-        // Opt-in since the posteriors of a list's launches are stored straight into the pinned buffer (lcrc_stage_run /
-        // lcrc_wave_stage_run): without 24 MB of copy-back per launch in the copy queue the step no longer shortens the list
-        // loop (0.293 / 0.303 / 0.333 / 0.315 s with it against 0.296 / 0.325 / 0.323 / 0.312 s for -F / -F -D / -E / host
-        // front-end) and it costs the process 15-70 ms of set-up.  PHNREC_RESERVE=1 switches it on.
-        if (!single_file && long_list_ && getenv("PHNREC_RESERVE")) {
+        // (With the posteriors of a list's launches stored straight into the pinned buffer -- no copy-backs -- the step is
+        //  worth less than before and nothing on some boxes: list loop 0.285 / 0.305 / 0.308 / 0.273 s with it against
+        //  0.302 / 0.327 / 0.325 / 0.289 s without on one box, -F / -F -D / -E / host front-end, 0.293 / 0.303 / 0.333 / 0.315
+        //  against 0.296 / 0.325 / 0.323 / 0.312 on another; the process takes as long either way.  PHNREC_NO_RESERVE=1: off.)
+        if (!single_file && long_list_ && !getenv("PHNREC_NO_RESERVE")) {
             // (a -b beyond 131 072 frames is reserved up to that: a short list would never fill the rest, the buffers grow
             //  on demand as before)
             const int rows = std::min(batch_frames_, 131072);
