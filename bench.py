@@ -874,8 +874,8 @@ def main():
                 dt = float(np.median(ts))
                 line["host_path_zero_copy"] = {"value": round(args.batch / dt, 1), "unit": "frames/s",
                                                "ms_per_call": round(dt * 1e3, 4),
-                                               "what": "lcrc_stage_run() on the context's pinned buffers: kernel on the features in place (mapped) + D2H, "
-                                                       "synchronous"}
+                                               "what": "lcrc_stage_run() on the context's pinned buffers: the kernel reads the features and stores the "
+                                                       "posteriors in place (mapped, over PCIe while it runs: no copy commands), synchronous"}
             if ranks.world == 1 and not args.no_extras:
                 en_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_EN_TIMIT_LCRC_N500")
                 for key, leg in (("small_launches", lambda: small_launch_legs(capi, modelgen, dev, stream)),
