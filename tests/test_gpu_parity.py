@@ -1087,3 +1087,24 @@ def test_split_f16_keeps_its_precision_for_small_and_large_weights(capi, tmp_pat
     err16 = float(np.abs(g.posteriors(mel) - want).max())
     assert err16 < TOL and err16 <= 4.0 * err32 + 2e-7, (err16, err32)
     g.close()
+
+
+def test_large_calls_in_two_launches_equal_their_utterances_alone(capi):
+    """lcrc_posteriors_batch from 8192 rows on computes the rows in two launches that store straight into the pinned buffer
+    (two_part_output, lcrc_api.cpp): a ragged batch of 10 001 rows in seven utterances -- the cut between the launches falls
+    inside an utterance -- equals every utterance computed alone, bit for bit, and the one-utterance form equals itself
+    computed as the front part of a longer call"""
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    nb = modelgen.SYSTEMS[system]["nbanks"]
+    ctx = capi.Lcrc(model_dir(system), nb)
+    ctx.set_hidden_split(1)
+    lens = [1, 977, 3000, 16, 2999, 2900, 108]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    assert off[-1] == 10001
+    mel = modelgen.synth_mel(int(off[-1]), nb, seed=91)
+    got = ctx.posteriors_batch(mel, off)
+    for u in range(len(lens)):
+        alone = ctx.posteriors(mel[off[u]:off[u + 1]])
+        assert np.array_equal(got[off[u]:off[u + 1]].view(np.uint32), alone.view(np.uint32)), u
+    whole = ctx.posteriors(mel)                      # one utterance of 10 001 rows: two launches too
+    assert np.array_equal(whole[:4000].view(np.uint32), ctx.posteriors(mel[:4100])[:4000].view(np.uint32))
