@@ -220,21 +220,65 @@ def split_f16_leg(capi, ctx, stream, d_mel, d_post, n, flops_frame, f32_post, f3
     return leg, post
 
 
-SMALL_PREHEAT = 600     # launches in front of each timed small-launch leg (stated in the line)
+PREHEAT_MS = 150.0      # time-based pre-heat in front of every timed small-launch / systems entry (stated in the line)
+WINDOWS, PER_WINDOW = 7, 40
+
+
+def heat(ctx, stream, d_mel, d_post, n, ms=PREHEAT_MS):
+    """back-to-back launches of n frames for at least `ms` milliseconds of device time (the clock follows LOAD TIME, not a
+    launch count: 600 launches of a 0.034 ms kernel are 20 ms, and the legs in between leave the device idle)"""
+    import torch
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(50):
+            ctx.posteriors_device(d_mel.data_ptr(), n, d_post.data_ptr(), stream=stream.cuda_stream)
+        done += 50
+        stream.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= ms:
+            return done
+
+
+def time_windows(ctx, stream, d_mel, d_post, n, windows=WINDOWS, per=PER_WINDOW):
+    """`windows` consecutive windows of `per` launches, all enqueued back to back (no host sync in between: the device
+    never idles), one HIP event between windows on the launch stream -> ms per launch of every window"""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(windows + 1)]
+    ev[0].record(stream)
+    for w in range(windows):
+        for _ in range(per):
+            ctx.posteriors_device(d_mel.data_ptr(), n, d_post.data_ptr(), stream=stream.cuda_stream)
+        ev[w + 1].record(stream)
+    stream.synchronize()
+    return [ev[w].elapsed_time(ev[w + 1]) / per for w in range(windows)]
+
+
+def launch_entry(ctx, stream, d_mel, d_post, n, fpf):
+    """one entry of `small_launches` / `systems`: time-based pre-heat, then median / min / max over the windows"""
+    heated = heat(ctx, stream, d_mel, d_post, n)
+    ws = sorted(time_windows(ctx, stream, d_mel, d_post, n))
+    ms = ws[len(ws) // 2]
+    frac = lambda t: round(n * fpf / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    return {"kernel_ms": round(ms, 4), "kernel_ms_min": round(ws[0], 4), "kernel_ms_max": round(ws[-1], 4),
+            "frames_per_s": round(n / ms * 1e3, 1), "frac": frac(ms), "frac_min": frac(ws[-1]), "frac_max": frac(ws[0]),
+            "flops_per_frame": fpf, "kernel": ctx.kernel_name,
+            "windows": "%d x %d launches back to back, median (min / max beside it)" % (len(ws), PER_WINDOW),
+            "preheat": "%d launches = >= %.0f ms of back-to-back load of this size" % (heated, PREHEAT_MS)}
 
 
 def small_launch_legs(capi, modelgen, dev, stream):
     """The small-launch regime, beside the headline: roofline fraction of 2048- and 4096-frame launches (the
     launcher picks 16-frame workgroups and, below half of the CUs, the split-hidden kernels), for CZ and for EN
-    at its own BASELINE size (configs[1]); and the streaming entry (Traps::CalcFeaturesBunched semantics,
-    traps.cpp:518-535) at the shipped bunch_size=5 (PHN_*/config:11) and at 512."""
+    at its own BASELINE size (configs[1]); every shipped system at the headline's 8192 frames; and -- LAST, they leave
+    the device idle between calls -- the streaming entry (Traps::CalcFeaturesBunched semantics, traps.cpp:518-535) at the
+    shipped bunch_size=5 (PHN_*/config:11) and at 512."""
     import ctypes as C
     import torch
     out = {}
     # sizes per system: CZ and EN in the small-launch regime (EN 4096 = configs[1]); HU (configs[3]'s system), RU and EN
     # also at the headline's 8192 frames, so that every shipped system's roofline fraction is in the driver-run line
     sizes = {"cz": (2048, 4096), "en": (2048, 4096, 8192), "hu": (8192,), "ru": (8192,)}
-    for system in ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500", "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"):
+    # EN first: its entries are the ones the previous round's driver run disagreed about
+    for system in ("PHN_EN_TIMIT_LCRC_N500", "PHN_CZ_SPDAT_LCRC_N1500", "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"):
         mdir = os.path.join(ROOT, "tests", "golden", "models", system)
         if not os.path.isdir(mdir):
             continue
@@ -248,39 +292,37 @@ def small_launch_legs(capi, modelgen, dev, stream):
         d_mel = torch.from_numpy(modelgen.synth_mel(n_max, nb, seed=7, mean_norm=spec["sent_mean_norm"])).to(dev)
         d_post = torch.empty((n_max, ctx.n_out), dtype=torch.float32, device=dev)
         for n in sizes[tag]:
-            # its own disclosed pre-heat: the legs before this one leave the device idle between calls, and 30 launches
-            # of 0.05-0.1 ms do not bring the clock back up (it takes ~25 ms of load, see --preheat)
-            time_launches(ctx, stream, d_mel, d_post, n, SMALL_PREHEAT)
-            ms = time_launches(ctx, stream, d_mel, d_post, n, 200)
-            out["%s_%d" % (tag, n)] = {"kernel_ms": round(ms, 4), "frames_per_s": round(n / ms * 1e3, 1),
-                                       "frac": round(n * fpf / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                       "flops_per_frame": fpf, "kernel": ctx.kernel_name,
-                                       "preheat_launches": SMALL_PREHEAT}
-        if tag == "cz":
-            # streaming: raw ctypes calls on preallocated buffers (what a C caller pays), wall clock
-            L, h = ctx.L, ctx.h
-            push = L.lcrc_push
-            push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-            for bunch in (5, 512):
-                mel = modelgen.synth_mel(bunch * 64, nb, seed=11)
-                post = np.empty((bunch, ctx.n_out), np.float32)
-                ptrs = [mel[i * bunch:].ctypes.data for i in range(64)]
-                ctx.reset()
-                push(h, mel.ctypes.data, 15, None, 0)
-                for i in range(32):
-                    push(h, ptrs[i], bunch, post.ctypes.data, 1)
-                calls, t0 = 0, time.perf_counter()
-                while time.perf_counter() - t0 < 1.0:
-                    for i in range(64):
-                        if push(h, ptrs[i], bunch, post.ctypes.data, 1) != 0:
-                            raise RuntimeError("lcrc_push failed")
-                    calls += 64
-                dt = time.perf_counter() - t0
-                out["push_bunch%d" % bunch] = {"value": round(calls * bunch / dt, 1), "unit": "frames/s",
-                                               "us_per_call": round(dt / calls * 1e6, 2),
-                                               "what": "lcrc_reset/lcrc_push(n=%d, needed=1): host frames in, host "
-                                                       "posteriors out, synchronous (PCIe-inclusive)" % bunch}
-            push.argtypes = [C.c_void_p, capi._f32p, C.c_int, C.c_void_p, C.c_int]
+            out["%s_%d" % (tag, n)] = launch_entry(ctx, stream, d_mel, d_post, n, fpf)
+        ctx.close()
+    mdir = os.path.join(ROOT, "tests", "golden", "models", SYSTEM)
+    if os.path.isdir(mdir):
+        nb = modelgen.SYSTEMS[SYSTEM]["nbanks"]
+        ctx = capi.Lcrc(mdir, nb, device=dev.index)
+        ctx.set_timing(False)
+        # streaming: raw ctypes calls on preallocated buffers (what a C caller pays), wall clock
+        L, h = ctx.L, ctx.h
+        push = L.lcrc_push
+        push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        for bunch in (5, 512):
+            mel = modelgen.synth_mel(bunch * 64, nb, seed=11)
+            post = np.empty((bunch, ctx.n_out), np.float32)
+            ptrs = [mel[i * bunch:].ctypes.data for i in range(64)]
+            ctx.reset()
+            push(h, mel.ctypes.data, 15, None, 0)
+            for i in range(32):
+                push(h, ptrs[i], bunch, post.ctypes.data, 1)
+            calls, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:
+                for i in range(64):
+                    if push(h, ptrs[i], bunch, post.ctypes.data, 1) != 0:
+                        raise RuntimeError("lcrc_push failed")
+                calls += 64
+            dt = time.perf_counter() - t0
+            out["push_bunch%d" % bunch] = {"value": round(calls * bunch / dt, 1), "unit": "frames/s",
+                                           "us_per_call": round(dt / calls * 1e6, 2),
+                                           "what": "lcrc_reset/lcrc_push(n=%d, needed=1): host frames in, host "
+                                                   "posteriors out, synchronous (PCIe-inclusive)" % bunch}
+        push.argtypes = [C.c_void_p, capi._f32p, C.c_int, C.c_void_p, C.c_int]
         ctx.close()
     return out
 
@@ -690,6 +732,9 @@ def main():
     ap.add_argument("--list-files", type=int, default=10000,
                     help="files of the sharded_list leg (BASELINE configs[3]: 10 000; 0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the small-launch / push / wave / CLI legs")
+    ap.add_argument("--kernel-only", action="store_true",
+                    help="nothing but the headline launches (PMC passes: every lcrc_fused_kernel dispatch of the process is then "
+                         "one of the 8192-row launches; implies --no-extras --no-cpu --list-files 0 and skips the host-pointer legs)")
     ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
@@ -699,6 +744,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.kernel_only:
+        args.no_extras, args.no_cpu, args.list_files = True, True, 0
 
     from phnrec_amd import distrun
 
@@ -783,7 +830,8 @@ def main():
         cold_ms = time_launches(ctx, stream, d_mel, d_post, args.batch, 20)
         if args.preheat > 0:
             time_launches(ctx, stream, d_mel, d_post, args.batch, args.preheat)
-        elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=red_dev)
+        timing = {}
+        elapsed = distrun.timed_steps(ranks, step, sync, args.steps, args.warmup, device=red_dev, detail=timing)
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         kernel_ms = ranks.max_float(kernel_ms, device=red_dev)
         total_frames = args.batch * args.steps * max(1, ranks.world)
@@ -809,6 +857,9 @@ def main():
                 "n_gpus": len(set(dmap)), "steps": args.steps, "warmup": args.warmup,
                 "preheat_launches": args.preheat,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                # (the contract's bracket: barrier + synchronise on both sides; beside it each rank's clock at its own
+                #  synchronise, MAX over ranks -- what the closing collective adds at N > 1)
+                "ms_per_step_before_closing_barrier": round(timing["before_closing_barrier"] / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s, batch=%d frames per GPU per step (BASELINE configs[2]), "
@@ -838,7 +889,13 @@ def main():
                              "hbm_gbps": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),
                              "hbm_frac_of_8TBps": (round(traffic / (kernel_ms * 1e-3) / 8e12, 4) if traffic else None)},
             }
-            if ranks.world == 1:
+            if ranks.world == 1 and not args.kernel_only:
+                # the spread of the headline's launches, outside the timed region: median / min / max over windows
+                ws = sorted(time_windows(ctx, stream, d_mel, d_post, args.batch))
+                line["roofline"]["windows"] = {"kernel_ms_median": round(ws[len(ws) // 2], 4), "kernel_ms_min": round(ws[0], 4),
+                                               "kernel_ms_max": round(ws[-1], 4),
+                                               "what": "%d x %d further launches back to back behind the timed region" % (len(ws), PER_WINDOW)}
+            if ranks.world == 1 and not args.kernel_only:
                 # the host-pointer entry point (pageable buffers in, pageable out): PCIe-inclusive,
                 # reported beside `value`, never as it
                 # (the C entry point on the caller's own, reused buffers: a fresh numpy array per call would add
@@ -903,7 +960,8 @@ def main():
                         line["systems"] = {k: line["small_launches"].pop(k) for k in sys_keys}
                         line["systems"]["what"] = ("roofline fraction (algorithmic FLOP of the system's three nets / f32 MFMA "
                                                    "peak) of %d-frame launches of the other shipped systems, each behind its own "
-                                                   "disclosed pre-heat; CZ at this size is `roofline`" % BATCH)
+                                                   "time-based pre-heat, median of %d windows with min / max; CZ at this size is "
+                                                   "`roofline`" % (BATCH, WINDOWS))
             if args.list_files > 0:
                 # the thing north_star asks to scale: the sharded file list through the CLI, -g N over the ranks' GPUs
                 # (the other ranks idle at the barrier below; their contexts hold no work)

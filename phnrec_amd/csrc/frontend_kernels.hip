@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
     // (a workgroup's latency).  The search for a frame's utterance was seven or eight DEPENDENT L2 round trips in a
     // list's launch (36-150 utterances): the offsets now come into LDS with one coalesced load and the search runs there;
     // the filter weights of the tail's bin sums come along (they were a global load per bin, in a dependent loop).
-    constexpr int kOffLds = 1024;
+    // (LDS per workgroup: FFT 256 8 + 2 + 4 + 0.5 = 14.5 KiB, eight and more per CU; FFT 512 16 + 4 + 1 + 1 = 22 KiB = seven
+    //  per CU -- 20 KiB of it are the FFT's own buffers, so the offsets get 256 entries there (a list's launch carries
+    //  36-150 utterances; longer offset tables are searched in global memory as before))
+    constexpr int kOffLds = FFT >= 512 ? 256 : 1024;
     __shared__ int off_s[kOffLds];
     __shared__ float coef_s[FFT / 2];
     const bool off_in_lds = p.n_utts + 1 <= kOffLds;

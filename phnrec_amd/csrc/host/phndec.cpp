@@ -30,6 +30,8 @@ bool PhnDec::LoadPhnList(const std::string &path)
     return true;
 }
 
+namespace { constexpr int kPackMaxPhonemes = 127; }
+
 void PhnDec::Init()
 {
     const int P = (int)phn_.size(), W = S_ + 1;
@@ -43,7 +45,9 @@ void PhnDec::Init()
     halpha_.assign(prune_ + 1, -1.0f);
     hpos_ = 0;
     for (int i = 0; i < P; i++) alpha_[i] = wpen_;               // entry state carries the penalty
-    packed_ = S_ == 3 && UseAvx512();
+    // (the packed form carries (winner + 1) << 24 | length in a signed word: at most 127 phonemes; beyond that the AVX2
+    //  form, which like the plain one and the reference has no limit)
+    packed_ = S_ == 3 && P <= kPackMaxPhonemes && UseAvx512();
     if (packed_) pk_.assign((size_t)W * Pp_, 0);                 // (winner -1, length 0) everywhere
     entry_a_ = wpen_;
     entry_prev_ = -1;
@@ -185,6 +189,7 @@ void FillEntryAvx2(int n, float *a, int *pv, int *ln, float entry, int bi)
 //   * the entry row is not stored at all: after PropagateInNetwork every phoneme's entry slot holds the same token
 //     (score best + penalty, winner bi, length 0; phndec.cpp:121-144), so it is three scalars that are broadcast.
 constexpr int kPackLenBits = 24;
+static_assert(((long long)(kPackMaxPhonemes) << kPackLenBits) <= 0x7fffffffLL, "winner + 1 must fit above the length bits");
 struct Frame512 {
     __m512 exit_max, inner_max;
 };

@@ -374,12 +374,24 @@ SpeechRec::~SpeechRec()
     if (warmup_.joinable()) warmup_.join();
 }
 
+// Whether lcrc_frontend_configure would take this configuration (its own limits, restated: lin16 / A-law, frames of
+// 129..512 samples = FFT 256 / 512, nbanks_full within [max(3, nbanks), 64]).  Asked before -E is switched on by itself.
+bool SpeechRec::GpuFrontendTakesConfig()
+{
+    if (wave_.format != WF_LIN16 && wave_.format != WF_ALAW) return false;
+    const int vs = C.GetInt("melbanks", "vector_size"), step = C.GetInt("melbanks", "vector_step");
+    if (vs < 129 || vs > 512 || step < 1 || C.GetInt("source", "sample_freq") < 1) return false;
+    int nbf = C.GetInt("melbanks", "nbanks_full");
+    if (nbf == -1) nbf = nbanks_;
+    return nbf >= 3 && nbf >= nbanks_ && nbf <= 64;
+}
+
 // One-off set-up of a context behind Init / InitClone: arithmetic, GPU front-end.  Returns "" or the error text
 // (called from one thread per GPU, so it does not touch err_).
 std::string SpeechRec::SetUpContext(Traps &t)
 {
     if (split_f16_ && !t.SetArithmetic(LCRC_ARITH_SPLIT_F16)) return t.LastError() + "\n";
-    if (gpu_frontend_ || gpu_energies_) {
+    if (gpu_frontend_ || EnergiesOn()) {
         if (wave_.noise_level != 0.0f) return "source/noise_level needs the host front-end (libc rand()); drop -F / -E\n";
         lcrc_frontend fe;
         fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
@@ -393,8 +405,8 @@ std::string SpeechRec::SetUpContext(Traps &t)
         fe.scale = wave_.scale;
         fe.dc_shift = wave_.dc_shift;
         fe.z_mean_source = C.GetBool("melbanks", "z_mean_source") ? 1 : 0;
-        fe.sent_mean_norm = sent_mean_norm_ && !gpu_energies_ ? 1 : 0;      // (-E: every normalisation runs on the host)
-        if (!gpu_energies_) {
+        fe.sent_mean_norm = sent_mean_norm_ && !EnergiesOn() ? 1 : 0;      // (-E: every normalisation runs on the host)
+        if (!EnergiesOn()) {
             if (C.GetFloat("framenorm", "shift") != 0.0f || C.GetFloat("framenorm", "min_floor") != -9999.9f)
                 return "framenorm/* needs the host front-end; drop -F (or use -E)\n";
             if (sent_max_norm_ || sent_chmax_norm_)
@@ -491,7 +503,7 @@ static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
 void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
 {
     char msg[1200];
-    if (in == dfWaveform && (gpu_frontend_ || gpu_energies_) && out != dfParams) {
+    if (in == dfWaveform && (gpu_frontend_ || EnergiesOn()) && out != dfParams) {
         // -F: only the size is needed to plan the launches; the GPU worker reads the file straight into
         // its context's pinned byte buffer
         struct stat st;
@@ -800,26 +812,27 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
     }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
-    bool auto_decoder = false;
     // A list over two or more GPUs, called as the reference is called (no -F, no -E): the host front-end's 0.36 us per
     // frame and core would feed 1.4 GPUs on 16 cores.  -E produces the same features bit for bit (tests compare dumps and
-    // MLFs byte for byte) at a fifth of the CPU time, so it is switched on by itself there; one GPU is served faster by
-    // the host front-end and keeps it.  PHNREC_NO_AUTO_E=1 keeps the host front-end whatever -g says.
-    if (need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ && n_gpus_ >= 2 && gpus_.empty() &&
-        wave_.noise_level == 0.0f && !getenv("PHNREC_NO_AUTO_E"))
-        gpu_energies_ = true;
-    // A list over four or more GPUs that ends in labels: the decoder runs on the GPUs too (-D) by itself.  Its labels are the
-    // host decoder's bit for bit (tested), it costs a GPU 1-3 % of its rate and takes the Viterbi -- half of what is left
-    // of the host's work with -F, a third with -E -- off the cores that eight GPUs' lists otherwise bring to their limit
-    // (0.44-0.58 CPU-seconds per 8.9 M frames against the 0.6 that 16 cores have while eight GPUs compute them).
-    // PHNREC_NO_AUTO_D=1 keeps the host decoder.
-    if (need_gpu && !single_file && out == dfStrings && !gpu_decoder_ && n_gpus_ >= 4 && gpus_.empty() &&
-        !phn_names_.empty() && phn_names_.size() <= 64 && states_per_phn_ >= 1 && states_per_phn_ <= 4 && time_pruning_ >= 1 &&
-        time_pruning_ <= 63 && !getenv("PHNREC_NO_AUTO_D"))
-        gpu_decoder_ = auto_decoder = true;
+    // MLFs byte for byte) at a fifth of the CPU time, so it is switched on by itself there -- where the GPU front-end takes
+    // the configuration at all (GpuFrontendTakesConfig: the limits lcrc_frontend_configure enforces; anything else keeps
+    // the host front-end as before) --; one GPU is served faster by the host front-end and keeps it.
+    // PHNREC_NO_AUTO_E=1 keeps the host front-end whatever -g says.  The choice lives in auto_energies_ / auto_decoder_:
+    // what the caller set (SetGpuEnergies, SetGpuDecoder) is never overwritten.
+    if (gpus_.empty()) {
+        auto_energies_ = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ && n_gpus_ >= 2 &&
+                         wave_.noise_level == 0.0f && GpuFrontendTakesConfig() && !getenv("PHNREC_NO_AUTO_E");
+        // A list over four or more GPUs that ends in labels: the decoder runs on the GPUs too (-D) by itself.  Its labels are
+        // the host decoder's bit for bit (tested), it costs a GPU 1-3 % of its rate and takes the Viterbi -- half of what is
+        // left of the host's work with -F, a third with -E -- off the cores that eight GPUs' lists otherwise bring to their
+        // limit.  PHNREC_NO_AUTO_D=1 keeps the host decoder.
+        auto_decoder_ = need_gpu && !single_file && out == dfStrings && !gpu_decoder_ && n_gpus_ >= 4 && !phn_names_.empty() &&
+                        phn_names_.size() <= 64 && states_per_phn_ >= 1 && states_per_phn_ <= 4 && time_pruning_ >= 1 &&
+                        time_pruning_ <= 63 && !getenv("PHNREC_NO_AUTO_D");
+    }
     // frames per launch: 32 768; with the decoder on the GPU 65 536 (one decoder wave per utterance and a launch as long as
     // its longest utterance: twice the utterances per launch, half the launches); -b overrides
-    if (!batch_given_) batch_frames_ = need_gpu && gpu_decoder_ && out == dfStrings ? 65536 : 32768;
+    if (!batch_given_) batch_frames_ = need_gpu && DecoderOn() && out == dfStrings ? 65536 : 32768;
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
         // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the
@@ -827,7 +840,15 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // From four GPUs on: two -- on one GPU the third is worth 0-2 %, while every context costs ~10 ms of start-up that
         // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
         // list that eight GPUs finish in a tenth of a second are a loss.
-        if (!EnsureGpus(single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3)) return false;
+        const int per_gpu = single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3;
+        if (!EnsureGpus(per_gpu)) {
+            // -E was this function's own idea and the contexts did not take the front-end after all: the host front-end
+            // serves the list as it did before the automatic choice existed
+            if (!(auto_energies_ && gpus_.empty())) return false;
+            auto_energies_ = false;
+            err_.clear();
+            if (!EnsureGpus(per_gpu)) return false;
+        }
     }
     if (need_gpu && !single_file && pool_->Size() > 0) {
         cpu_set_t all, one;
@@ -837,15 +858,18 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             if (!GpuNodeCpus(d, &one)) { every = false; break; }
             CPU_OR(&all, &all, &one);
         }
-        if (every) pool_->SetAffinity(all);
+        // (only where those nodes hold at least as many usable CPUs as the pool has threads: the pool is sized from every
+        //  socket's CPUs, and on a two-socket host with one GPU and the host front-end -- the CPU-bound stage there -- N
+        //  threads confined to N/2 cores beside the spinning GPU workers would halve it)
+        if (every && CPU_COUNT(&all) >= pool_->Size()) pool_->SetAffinity(all);
     }
     // (a model the device decoder does not take -- more states than posterior outputs, say -- keeps the host decoder
     //  when -D was this function's own idea)
-    if (auto_decoder && (int)phn_names_.size() * states_per_phn_ > n_out_) {
-        gpu_decoder_ = false;
-        if (!batch_given_) batch_frames_ = 32768;
+    if (auto_decoder_ && (int)phn_names_.size() * states_per_phn_ > n_out_) {
+        auto_decoder_ = false;
+        if (!batch_given_ && !gpu_decoder_) batch_frames_ = 32768;
     }
-    const bool dev_dec = need_gpu && gpu_decoder_ && out == dfStrings;
+    const bool dev_dec = need_gpu && DecoderOn() && out == dfStrings;
     std::vector<std::string> phn_names;
     if (need_gpu) {
         // posterior writer path: both softening functions and the dump's byte order run in the posterior
@@ -880,7 +904,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             //  on demand as before)
             const int rows = std::min(batch_frames_, 131072);
             long long wave_bytes = 0;
-            if ((gpu_frontend_ || gpu_energies_) && in == dfWaveform)
+            if ((gpu_frontend_ || EnergiesOn()) && in == dfWaveform)
                 wave_bytes = ((long long)rows * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
                              (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
             std::vector<std::string> errs(gpus_.size());
@@ -1098,7 +1122,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             const auto l0 = clock::now();
             const float *h_post = nullptr;
             std::vector<int> foff;
-            if ((gpu_frontend_ || gpu_energies_) && in == dfWaveform) {
+            if ((gpu_frontend_ || EnergiesOn()) && in == dfWaveform) {
                 // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the three nets all run
                 // on the device; the files go straight into the context's pinned byte buffer (read in parallel)
                 std::vector<long long> bstart(cnt), blen(cnt);
@@ -1142,7 +1166,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     off.resize((size_t)b + 1);
                 }
                 foff.resize(cnt + 1);          // posteriors stay in the context's pinned output buffer
-                if (gpu_energies_) {
+                if (EnergiesOn()) {
                     // -E: the GPU stops at the mel-bank energies (bit for bit the host front-end's); ln() with this host's
                     // libm and the normalisations follow here, in the pinned buffer the posterior kernel then reads in place
                     float *feat = nullptr;
@@ -1223,7 +1247,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // Jobs whose stage 1 is next to nothing (-F: a stat(); the file is read when its launch is assembled) go to the pool
     // in chunks; the others one by one (a file's read + front-end is a task worth a thread by itself).
     // (the others too once their measured stage 1 turns out short -- lists of very short files: a chunk is sized to ~200 us)
-    const bool cheap_stage1 = need_gpu && (gpu_frontend_ || gpu_energies_) && in == dfWaveform;
+    const bool cheap_stage1 = need_gpu && (gpu_frontend_ || EnergiesOn()) && in == dfWaveform;
     auto chunk_max = [&]() -> size_t {
         if (single_file) return 1;
         if (cheap_stage1) return 32;

@@ -113,6 +113,15 @@ public:
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
     bool ProcessFileList(DataFormat in, DataFormat out, const std::string &list, const std::string &mlf);
     const std::string &LastError() const { return err_; }
+    // the device path the last list took: "host" | "E" | "F", "+D" with the decoder on the GPU, ",auto" behind what
+    // RunPipeline chose by itself (PHNREC_STATS prints it)
+    std::string ModeString() const
+    {
+        std::string m = gpu_frontend_ ? "F" : EnergiesOn() ? "E" : "host";
+        if (DecoderOn()) m += "+D";
+        if ((auto_energies_ && !gpu_frontend_) || auto_decoder_) m += ",auto";
+        return m;
+    }
     const RunStats &Stats() const { return stats_; }
     Config C;
 
@@ -146,6 +155,11 @@ private:
     std::string config_dir_, err_;
     bool sent_max_norm_ = false, sent_chmax_norm_ = false;
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_energies_ = false, gpu_decoder_ = false, split_f16_ = false;
+    // what RunPipeline switched on by itself for the contexts it built (-g >= 2: -E, -g >= 4: -D); the members above stay the caller's
+    bool auto_energies_ = false, auto_decoder_ = false;
+    bool EnergiesOn() const { return gpu_energies_ || auto_energies_; }
+    bool DecoderOn() const { return gpu_decoder_ || auto_decoder_; }
+    bool GpuFrontendTakesConfig();
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     bool long_list_ = false;             // the list file has >= 4 KB (~100 entries): buffers are reserved ahead of the first launch

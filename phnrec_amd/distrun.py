@@ -192,14 +192,15 @@ def shard_by_frames(lengths, world):
     return owner
 
 
-def timed_steps(ranks, step, sync, steps, warmup, device=None):
+def timed_steps(ranks, step, sync, steps, warmup, device=None, detail=None):
     """The bench contract: W untimed steps, then EXACTLY K steps bracketed by a barrier
     and a device synchronise on both sides; the elapsed time is the MAX over ranks.
 
-    Each rank's clock stops at its OWN device synchronise behind step K; the closing barrier follows (it still
-    brackets the region: nobody reports before everybody is done) and the MAX over ranks of those local times is the
-    job's time.  With the barrier inside the clock, an N > 1 run paid one RCCL collective (30-100 us) per timed region
-    that the N = 1 run (no process group) never pays -- 1-3 % of a 20 x 0.2 ms region charged to "scaling"."""
+    Returned (= `ms_per_step`, `value`): the contract's bracket -- the clock stops behind the closing barrier and the
+    synchronise that follows it, on every rank, and the MAX over ranks is taken.  `detail` (a dict), when given, also
+    receives "before_closing_barrier": the MAX over ranks of each rank's clock at its OWN synchronise behind step K, i.e.
+    without the closing collective (30-100 us of RCCL at N > 1 that an N = 1 run, which has no process group, never pays:
+    1-3 % of a 20 x 0.2 ms region).  Disclosed beside the contract's figure, never in place of it."""
     import time
     for _ in range(warmup):
         step()
@@ -210,7 +211,10 @@ def timed_steps(ranks, step, sync, steps, warmup, device=None):
     for _ in range(steps):
         step()
     sync()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
     ranks.barrier()
     sync()
+    dt = time.perf_counter() - t0
+    if detail is not None:
+        detail["before_closing_barrier"] = ranks.max_float(dt_own, device=device)
     return ranks.max_float(dt, device=device)

@@ -337,7 +337,9 @@ def test_list_pipeline_many_settings_no_hang(tmp_path):
 
 
 @pytest.mark.parametrize("P,S,prune", [(5, 1, 40), (17, 2, 12), (40, 3, 40), (62, 3, 40), (33, 4, 25), (64, 3, 7), (8, 3, 40),
-                                       (16, 3, 40), (47, 3, 3), (61, 3, 40)])
+                                       (16, 3, 40), (47, 3, 3), (61, 3, 40),
+                                       # around the packed AVX-512 form's limit ((winner + 1) << 24 in a signed word: <= 127 phonemes)
+                                       (127, 3, 40), (128, 3, 40), (130, 3, 12), (200, 3, 40)])
 def test_host_decoder_vector_and_plain_forms_vs_the_decoder_oracle(tmp_path, P, S, prune):
     """The host Viterbi runs state-major: sixteen phonemes at a time on AVX-512 where the CPU has it (three states per
     phoneme: the whole frame in one pass, packed tokens, the entry row as scalars), eight on AVX2 (PHNREC_NO_AVX512=1),

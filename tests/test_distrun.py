@@ -130,7 +130,7 @@ def test_bench_eight_ranks_in_the_drivers_exact_form():
     command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
     bench.py --gpus 8 --steps 20 --warmup 5` -- with --stub in place of the GPU step (gloo instead of RCCL; a one-GPU box
     admits six processes on its card, so eight GPU ranks cannot be rehearsed there either).  Everything else is the real
-    path: rendezvous, the barriers around the timed region, the clock that stops at the rank's own synchronise, MAX over
+    path: rendezvous, the barriers around the timed region (the contract's bracket: the clock stops behind the closing barrier), MAX over
     ranks, SUM of the frames, one line from rank 0 -- well inside the driver's 600 s."""
     import time
     port = _free_port()
@@ -147,7 +147,7 @@ def test_bench_eight_ranks_in_the_drivers_exact_form():
     assert line["ranks"]["world"] == 8 and line["ranks"]["launcher"] == "torch.distributed.run"
     assert line["ranks"]["device_map"] == list(range(8)) and line["steps"] == 20 and line["warmup"] == 5
     assert line["frames_all_ranks"] == 8 * (20 + 5) * 8192
-    # rank 7 sleeps 16 ms per step: MAX over ranks; the closing barrier is outside the clock (timed_steps)
+    # rank 7 sleeps 16 ms per step: MAX over ranks, the contract's bracket (closing barrier inside the clock)
     assert 16.0 * 0.9 <= line["ms_per_step"] < 16.0 * 1.5
     assert dt < 300, "took %.0f s" % dt
 

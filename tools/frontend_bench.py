@@ -51,6 +51,22 @@ def main():
     dt = (time.perf_counter() - t0) / reps
     print("waveform -> posteriors, %d frames (%d bytes A-law): %.3f ms per call incl. H2D/D2H = %.2f M frames/s; "
           "rows sum to 1: %s" % (frames, len(raw), dt * 1e3, frames / dt / 1e6, bool(np.abs(post.sum(1) - 1).max() < 1e-5)))
+    ctx.close()
+    # the FFT-512 form of melbank_kernel (EN: 16 kHz lin16, 400-sample frames; 22 KiB of LDS per workgroup, seven per CU)
+    import bench
+    system = "PHN_EN_TIMIT_LCRC_N500"
+    raw = bench.config1_lin16_signal(8192)
+    ctx = capi.Lcrc(os.path.join(ROOT, "tests", "golden", "models", system), modelgen.SYSTEMS[system]["nbanks"])
+    ctx.configure_frontend(wave_format="lin16", sent_mean_norm=False, sample_freq=16000, vector_size=400, vector_step=160,
+                           lower_freq=0.0, higher_freq=8000.0)
+    assert ctx.frontend_frames(len(raw)) == 8192
+    ctx.wave_to_posteriors([raw])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        post, foff = ctx.wave_to_posteriors([raw])
+    dt = (time.perf_counter() - t0) / reps
+    print("EN (FFT 512) waveform -> posteriors, 8192 frames (%d bytes lin16): %.3f ms per call incl. H2D/D2H = %.2f M frames/s; "
+          "rows sum to 1: %s" % (len(raw), dt * 1e3, 8192 / dt / 1e6, bool(np.abs(post.sum(1) - 1).max() < 1e-5)))
 
 
 if __name__ == "__main__":

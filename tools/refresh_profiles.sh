@@ -29,7 +29,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i + 1))
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 bench.py --steps 5 --warmup 2 --preheat 0 --no-cpu --no-extras --list-files 0 > $OUT/pmc_$i.log 2>&1
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -- python3 bench.py --kernel-only --steps 100 --warmup 20 --preheat 100 > $OUT/pmc_$i.log 2>&1
 done
 echo "pmc done"
 python3 tools/stamp_profile.py > $OUT/phase_stamps.txt 2>&1
