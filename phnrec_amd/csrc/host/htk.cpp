@@ -32,6 +32,19 @@ bool SaveHTKRaw(const std::string &path, const void *be_words, int rows, int col
     return fclose(f) == 0 && ok;
 }
 
+FILE *BeginHTKRaw(const std::string &path, int rows, int cols)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (f && !write_header(f, rows, cols)) { fclose(f); f = nullptr; }
+    return f;
+}
+
+bool AppendHTKRaw(FILE *f, const void *be_words, int rows, int cols)
+{
+    const size_t n = (size_t)rows * cols;
+    return fwrite(be_words, 4, n, f) == n;
+}
+
 bool SaveHTK(const std::string &path, const float *data, int rows, int cols)
 {
     FILE *f = fopen(path.c_str(), "wb");

@@ -12,6 +12,9 @@ namespace phnrec {
 bool SaveHTK(const std::string &path, const float *data, int rows, int cols);
 // `be_words` already holds big-endian 32-bit words (the device wrote them that way)
 bool SaveHTKRaw(const std::string &path, const void *be_words, int rows, int cols);
+// the same dump written in pieces (a file longer than one launch): header for `rows` rows, then row ranges as they come
+FILE *BeginHTKRaw(const std::string &path, int rows, int cols);
+bool AppendHTKRaw(FILE *f, const void *be_words, int rows, int cols);
 bool LoadHTK(const std::string &path, std::vector<float> &data, int *rows, int *cols);
 
 }  // namespace phnrec

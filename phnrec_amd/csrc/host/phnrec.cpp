@@ -10,6 +10,8 @@
 #include <string>
 
 #include "srec.h"
+
+#include <sys/resource.h>
 #include "veclog.h"
 
 using namespace phnrec;
@@ -68,6 +70,13 @@ static int NextOpt(int argc, char **argv, const char *options, int &ind, const c
 }
 
 static SpeechRec *g_sr = nullptr;
+
+// peak resident set of this process so far (PHNREC_STATS prints it: pinned buffers count)
+static double MaxRssMb()
+{
+    struct rusage ru;
+    return getrusage(RUSAGE_SELF, &ru) == 0 ? ru.ru_maxrss / 1024.0 : 0.0;
+}
 
 static void Die(const std::string &msg)
 {
@@ -179,13 +188,13 @@ int main(int argc, char **argv)
         // launch call of the run (code-object load, cold clock) -- part of wall_s; main_s: since main() was entered
         fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f "
                         "(front_end_s=%.3f setup_s=%.3f create_s=%.3f first_launch_s=%.3f config_s=%.3f main_s=%.3f) "
-                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d mode=%s\n",
+                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d mode=%s max_rss_mb=%.1f\n",
                 s.files, s.frames, s.seconds, s.seconds > 0 ? s.frames / s.seconds : 0.0,
                 s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds,
                 s.create_seconds, s.first_launch_seconds, config_s,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
                 s.cpu_stage1 + s.cpu_read + s.cpu_gather + s.cpu_stage3, s.cpu_stage1, s.cpu_read, s.cpu_gather, s.cpu_stage3, s.cpu_viterbi,
-                s.host_threads, SR.ModeString().c_str());
+                s.host_threads, SR.ModeString().c_str(), MaxRssMb());
     }
     // Every output file is closed by now.  Leave without tearing the HIP runtime down piece by piece (contexts, streams,
     // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.

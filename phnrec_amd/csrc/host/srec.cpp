@@ -500,10 +500,10 @@ static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
     return ok;
 }
 
-void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job)
+void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job, bool host_features)
 {
     char msg[1200];
-    if (in == dfWaveform && (gpu_frontend_ || EnergiesOn()) && out != dfParams) {
+    if (in == dfWaveform && (gpu_frontend_ || EnergiesOn()) && out != dfParams && !host_features) {
         // -F: only the size is needed to plan the launches; the GPU worker reads the file straight into
         // its context's pinned byte buffer
         struct stat st;
@@ -1113,9 +1113,88 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             }, 16);
             return true;
         };
+        // A file longer than one launch (-b frames; take_launch hands it over alone).  Its posteriors are computed as
+        // consecutive row ranges of at most -b frames, each with the window's reach (15 frames) of context on either side
+        // -- a frame's posteriors depend on its 31-frame window only, which is all ProcessOffline's prime / main / flush
+        // calls establish (srec.cpp:1035-1059) --, and consumed in order: the decoder takes a range frame by frame, a dump
+        // appends it.  Pinned memory and the device buffers stay those of ONE launch whatever the file's length (a 10-hour
+        // file as one launch pinned 2.7 GB of posteriors); the features of the whole file live in pageable memory, as the
+        // reference's do (srec.cpp:1384-1422 reads whole files).  Same bytes out as the one-launch form (tested).  With -F /
+        // -E the file was only stat()ed so far: its features come from the host front-end, i.e. the -E road's bits.
+        auto long_job = [&](Item *it) -> bool {
+            Job &j = it->job;
+            if (j.mel.empty() && in == dfWaveform) {
+                CpuTimer tm(stage1_us);
+                Stage1(in, out, j, true);
+            }
+            if (!j.ok) {                                  // unreadable by now: the list stops at this file
+                std::lock_guard<std::mutex> l(mu);
+                if (stop_seq < 0 || it->seq < stop_seq) stop_seq = it->seq;
+                it->slot.state = 3;
+                cv_work.notify_all(); cv_feed.notify_all();
+                drain();
+                return true;
+            }
+            const int N = j.frames, B = batch_frames_, sh = tr.GetTrapShift();
+            std::vector<float> post((size_t)std::min(N, B) * n_out_);
+            PhnDec dec;
+            FILE *dump = nullptr;
+            if (out == dfStrings) {
+                dec.SetPhonemes(phn_names_);
+                dec.SetStatesPerPhn(states_per_phn_);
+                dec.SetTimePruning(time_pruning_);
+                dec.SetWPenalty(wpenalty_);
+                dec.Init();
+                if (n_out_ < dec.NumPhonemes() * states_per_phn_) {
+                    j.ok = false;
+                    j.err = "posterior vectors are shorter than the phoneme list needs\n";
+                }
+            } else if (!(dump = BeginHTKRaw(j.tgt, N, n_out_))) {
+                j.ok = false;
+                j.err = "Can not create file: " + j.tgt + "\n";
+            }
+            for (int r0 = 0; r0 < N && j.ok; r0 += B) {
+                const int rows = std::min(B, N - r0), s0 = std::max(0, r0 - sh), s1 = std::min(N, r0 + rows + sh);
+                {
+                    SlotHold hold(slots, tr);
+                    if (!tr.CalcRows(j.mel.data() + (size_t)s0 * nbanks_, s1 - s0, r0 - s0, rows, post.data())) {
+                        if (dump) fclose(dump);
+                        abort_run(tr.LastError());
+                        return false;
+                    }
+                }
+                kms[g] += tr.LastKernelMs();
+                trace(g, "rows done", r0, rows);
+                CpuTimer tm(stage3_us);
+                if (dump) {
+                    if (!AppendHTKRaw(dump, post.data(), rows, n_out_)) { j.ok = false; j.err = "Can not create file: " + j.tgt + "\n"; }
+                } else {
+                    const long long v0 = ThreadCpuNs();
+                    for (int r = 0; r < rows; r++) dec.ProcessFrame(post.data() + (size_t)r * n_out_);
+                    viterbi_ns_ += ThreadCpuNs() - v0;
+                }
+            }
+            if (dump && fclose(dump) != 0 && j.ok) { j.ok = false; j.err = "Can not create file: " + j.tgt + "\n"; }
+            if (!dump && j.ok) {
+                CpuTimer tm(stage3_us);
+                dec.Done();
+                EmitLabels(j, mlf != nullptr, dec.Labels());
+            }
+            std::vector<float>().swap(j.mel);
+            j.cols = n_out_;
+            std::lock_guard<std::mutex> l(mu);
+            it->slot.state = 3;
+            drain();
+            return true;
+        };
+        const bool row_ranges = tr.HasRowRanges() && !getenv("PHNREC_NO_ROW_RANGES");
         trace(g, "worker up");
         while (take_launch(items)) {
             int cnt = (int)items.size();
+            if (cnt == 1 && row_ranges && items[0]->job.frames > batch_frames_) {
+                if (!long_job(items[0])) return;
+                continue;
+            }
             off.assign(1, 0);
             for (int k = 0; k < cnt; k++) off.push_back(off.back() + items[k]->job.frames);
             trace(g, "took launch", cnt, off.back());

@@ -140,7 +140,8 @@ private:
     bool ParseLine(const std::string &line, DataFormat out, bool mlf, Job &job);
     // next(job): 1 = a job, 0 = end of the list, -1 = invalid line (LastError() says which)
     bool RunPipeline(DataFormat in, DataFormat out, const std::function<int(Job &)> &next, FILE *mlf, bool single_file);
-    void Stage1(DataFormat in, DataFormat out, Job &job);              // load [+ front-end] [+ sentence norm]
+    // load [+ front-end] [+ sentence norm]; host_features: the host front-end even where -F / -E would only stat() the file
+    void Stage1(DataFormat in, DataFormat out, Job &job, bool host_features = false);
     // soft funcs, decode / dump; `post` = job.frames x cols posteriors (writable)
     // device_done: softening (and, for dumps, the big-endian byte order) already applied by the GPU
     void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done = false);

@@ -80,6 +80,15 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // whether CalcRows exists for this context (the fused LCRC kernels; not the other systems / general geometries)
+    bool HasRowRanges() const { return ctx_ && system_ == "LCRC" && std::string(lcrc_kernel_name(ctx_)) != "lcrc_general"; }
+    // a row range of a strip (lcrc_posteriors_rows): chunks of a file longer than one launch, cut with their halos
+    bool CalcRows(const float *strip, int n_rows, int row_first, int row_count, float *post)
+    {
+        if (lcrc_posteriors_rows(ctx_, strip, n_rows, row_first, row_count, post) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
     bool CalcBatch(const float *mel, const int *off, int n_utts, float *post)
     {
         if (lcrc_posteriors_batch(ctx_, mel, off, n_utts, post) == LCRC_OK) return true;

@@ -128,23 +128,18 @@ constexpr bool lcrc_early_requests(int ks1, int ksm, int n_ot, bool exact, bool 
 
 // ARITH = 1: split-f16 arithmetic (mlp_dev.h HalfLoop) -- the operand images hold (high, low) f16 pairs in 32-deep k-steps;
 //            an image's size is counted in 1-KiB units per frame tile like the f32 images' k-groups: nkq = 2 * k-steps.
-// NH = NW: the 512-thread form for launches of ONE workgroup per CU (at most n_cu 16-frame tiles): a second wave per SIMD
-//          that stays out of the hidden loops (mlp_dev.h run_net) -- a frame's bits are those of the other forms -- and
-//          shares the stages outside them: staging, projection, the band nets' softmax / ln() epilogue, the last store.
-template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false, int ARITH = 0, int NH = 0>
-__global__ __launch_bounds__((NW + NH) * 64) void lcrc_fused_kernel(const LcrcParams p)
+template <int KS1, int KSM, int NOT, int NW, bool EXACT, int FT, bool SPLIT, bool PROBES = false, int ARITH = 0>
+__global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
 {
     static_assert(ARITH == 0 || (EXACT && !SPLIT && !PROBES), "split-f16 arithmetic: the fused kernel of the shipped shapes");
-    static_assert(NH == 0 || (NH == NW && FT == 1 && !SPLIT && !PROBES && ARITH == 0), "helper waves: the fused f32 kernel on 16-frame tiles");
     constexpr int NS1 = (4 * KS1 + 31) / 32, NSM = (4 * KSM + 31) / 32;     // 32-deep k-steps (ARITH = 1)
     constexpr int BM = 16 * FT;                 // frames per workgroup
     constexpr int kTileRows = BM + 2 * kShift;  // mel rows staged
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = (NW + NH) * 64;          // all threads: the stages outside the hidden loops
+    constexpr int NT = NW * 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool looper = NH == 0 || wave < NW;   // this wave runs hidden loops
     const int nb = p.nbanks;
     // k-groups per frame tile of the operand images.  Run-time shapes use their CLASS's counts as well (groups past the
     // net's own hold zeros): image addresses are then compile-time offsets in the hidden loops (mlp_dev.h RingLoop);
@@ -182,12 +177,10 @@ __global__ __launch_bounds__((NW + NH) * 64) void lcrc_fused_kernel(const LcrcPa
     RingLoop<KS1, NOT, FT, EXACT, BKQ1> band_loop;
     RingLoop<KSM, NOT, FT, EXACT, BKQM> merger_loop;
     if constexpr (EARLY) {
-        if (looper) {
-            const int grp = wave / 2, wig = wave % 2;
-            const NetDev &nd = p.net[grp];
-            band_loop.setup(nd, reinterpret_cast<const f4 *>(xf) + (size_t)grp * (FT * nkq1 * 64), lane);
-            band_loop.begin(wig * ((nd.nht + 1) / 2));
-        }
+        const int grp = wave / 2, wig = wave % 2;
+        const NetDev &nd = p.net[grp];
+        band_loop.setup(nd, reinterpret_cast<const f4 *>(xf) + (size_t)grp * (FT * nkq1 * 64), lane);
+        band_loop.begin(wig * ((nd.nht + 1) / 2));
     }
 
     LCRC_STAMP(p, wave, lane, 0);
@@ -347,10 +340,9 @@ __global__ __launch_bounds__((NW + NH) * 64) void lcrc_fused_kernel(const LcrcPa
                 }
             };
             float xw[NN][FT][4], xn[NN][FT][4], mk[NN], dk[NN], mkn[NN], dkn[NN];
-            constexpr int NWA = NW + NH;             // every wave takes bands
             gather(wave, xw, mk, dk);
-            for (int b = wave; b < nb; b += NWA) {
-                gather(b + NWA, xn, mkn, dkn);
+            for (int b = wave; b < nb; b += NW) {
+                gather(b + NW, xn, mkn, dkn);
                 const int k = b * kNCoef + cc;
                 f4 acc[NN][FT];
 #pragma unroll
@@ -532,15 +524,15 @@ __global__ __launch_bounds__((NW + NH) * 64) void lcrc_fused_kernel(const LcrcPa
         // (the sequential alternative -- one band net after the other on four waves -- was 1.6-3 % slower in
         //  same-GPU A/B runs, profiles/r01_ab_runs.txt)
         if constexpr (EARLY) {
-            auto begin_merger = [&]() {              // (loop waves only: run_net calls the hook from their path)
+            auto begin_merger = [&]() {
                 merger_loop.setup(nm, reinterpret_cast<const f4 *>(gf), lane);
                 merger_loop.begin(wave * ((nm.nht + NW - 1) / NW));
             };
-            run_net<KS1, NOT, NW, EXACT, FT, 2, true, BKQ1, 0, NH>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+            run_net<KS1, NOT, NW, EXACT, FT, 2, true, BKQ1>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi,
                                                       &band_loop, begin_merger);
         } else {
-            run_net<KS1, NOT, NW, EXACT, FT, 2, false, 0, ARITH, NH>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
+            run_net<KS1, NOT, NW, EXACT, FT, 2, false, 0, ARITH>(p, 2, p.net, reinterpret_cast<const f4 *>(xf), FT * nkq1 * 64, slab,
                                                                  reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         }
         LCRC_STAMP(p, wave, lane, 3);           // softmax + ln() done
@@ -560,10 +552,10 @@ __global__ __launch_bounds__((NW + NH) * 64) void lcrc_fused_kernel(const LcrcPa
         for (int i = 0; i < 3; i++) { epi.c0[i] = p.out_c[0][i]; epi.c1[i] = p.out_c[1][i]; }
         for (int i = 0; i < 2; i++) { epi.l0[i] = p.out_l[0][i]; epi.l1[i] = p.out_l[1][i]; }
         if constexpr (EARLY)
-            run_net<KSM, NOT, NW, EXACT, FT, 1, true, BKQM, 0, NH>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+            run_net<KSM, NOT, NW, EXACT, FT, 1, true, BKQM>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
                                                       reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi, &merger_loop);
         else
-            run_net<KSM, NOT, NW, EXACT, FT, 1, false, 0, ARITH, NH>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
+            run_net<KSM, NOT, NW, EXACT, FT, 1, false, 0, ARITH>(p, 8, &nm, reinterpret_cast<const f4 *>(gf), 0, slab,
                                                                  reinterpret_cast<f4 *>(smem + lp.slab23), n_ot, lane, wave, epi);
         LCRC_STAMP(p, wave, lane, 9);
         const int rows = min(BM, p.row_end - r0);
@@ -673,7 +665,6 @@ struct Variant {
     const void *split_band, *split_merger;   // split-hidden path, 16-frame tiles
     const void *probe;     // 16-frame workgroups with the stage probes (lcrc_posteriors_probe)
     const void *h2[2];     // split-f16 arithmetic, [FT - 1] (shipped shapes only)
-    const void *h8;        // 16-frame workgroups with helper waves (512 threads; shipped shapes only)
 };
 
 #define LCRC_KERNEL(KS1, KSM, NOT, EX) \
@@ -685,16 +676,15 @@ struct Variant {
 
 #define LCRC_KERNEL_H2(KS1, KSM, NOT) \
     {reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 1, false, false, 1>), \
-     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 2, false, false, 1>)}, \
-    reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 1, false, false, 0, kNW>)
+     reinterpret_cast<const void *>(&lcrc_fused_kernel<KS1, KSM, NOT, kNW, true, 2, false, false, 1>)}
 
 const Variant kVariants[] = {
     {"cz_42_69_9", 42, 69, 9, true, LCRC_KERNEL(42, 69, 9, true), LCRC_KERNEL_H2(42, 69, 9)},
     {"hu_42_93_12", 42, 93, 12, true, LCRC_KERNEL(42, 93, 12, true), LCRC_KERNEL_H2(42, 93, 12)},
     {"ru_42_80_10", 42, 80, 10, true, LCRC_KERNEL(42, 80, 10, true), LCRC_KERNEL_H2(42, 80, 10)},
     {"en_64_60_8", 64, 60, 8, true, LCRC_KERNEL(64, 60, 8, true), LCRC_KERNEL_H2(64, 60, 8)},
-    {"generic_44_72_9", kGenSKS1, kGenSKSM, kGenSNOT, false, LCRC_KERNEL(kGenSKS1, kGenSKSM, kGenSNOT, false), {nullptr, nullptr}, nullptr},
-    {"generic_64_104_13", kGenKS1, kGenKSM, kGenNOT, false, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false), {nullptr, nullptr}, nullptr},
+    {"generic_44_72_9", kGenSKS1, kGenSKSM, kGenSNOT, false, LCRC_KERNEL(kGenSKS1, kGenSKSM, kGenSNOT, false), {nullptr, nullptr}},
+    {"generic_64_104_13", kGenKS1, kGenKSM, kGenNOT, false, LCRC_KERNEL(kGenKS1, kGenKSM, kGenNOT, false), {nullptr, nullptr}},
 };
 constexpr int kNVariants = sizeof kVariants / sizeof kVariants[0];
 
@@ -747,7 +737,7 @@ namespace {
 // (atomics: several host threads launch on their own contexts; the worst case is a repeated grant)
 hipError_t grant_lds(const void *fn, int vi, int slot, int dev)
 {
-    static std::atomic<bool> granted[kNVariants][8][64] = {};
+    static std::atomic<bool> granted[kNVariants][7][64] = {};
     const bool cached = dev >= 0 && dev < 64;
     if (cached && granted[vi][slot][dev]) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -925,19 +915,12 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
         // 32-frame workgroups load every weight fragment once per 32 frames; 16-frame workgroups twice as often, but
         // there are twice as many of them: they win while the 32-frame grid would leave at least half of the CUs idle
         const int ft = pt.ft;
-        // one 16-frame workgroup per CU at most (no second workgroup to run beside it): the 512-thread form, whose helper
-        // waves share the stages outside the hidden loops; same bits
-#ifdef LCRC_NO_HELPER_WAVES      // A/B build (tools/build_ab_lib.sh)
-        const bool helpers = false;
-#else
-        const bool helpers = ft == 1 && !probes && v->h8 && tiles16 <= n_cu;
-#endif
-        const void *fn = probes ? v->probe : helpers ? v->h8 : v->fn[ft - 1];
-        e = grant_lds(fn, vi, probes ? 4 : helpers ? 7 : ft - 1, dev);
+        const void *fn = probes ? v->probe : v->fn[ft - 1];
+        e = grant_lds(fn, vi, probes ? 4 : ft - 1, dev);
         if (e != hipSuccess) return e;
         const LdsPlan lp = lcrc_lds_plan(ft, p.nbanks, k1, km, lcrc_n_ot_slab(p.net));
         const int bm = 16 * ft;
-        e = hipLaunchKernel(fn, dim3((pt.count + bm - 1) / bm), helpers ? dim3(2 * kNW * 64) : block, kargs, lp.total, stream);
+        e = hipLaunchKernel(fn, dim3((pt.count + bm - 1) / bm), block, kargs, lp.total, stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -761,18 +761,11 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
                                              int lane, int wave, Epi epi)
 {
     constexpr int BM = 16 * FT;
-    constexpr int LPF_ALL = NW * 64 / (GROUPS * BM);
-    constexpr int LPF = LPF_ALL > 16 ? 16 : LPF_ALL;   // lanes cooperating on one row (a DPP row at most)
+    constexpr int LPF = NW * 64 / (GROUPS * BM);   // lanes cooperating on one row
     constexpr int NV = 16 * NOT / LPF;             // values per lane
     static_assert(LPF == 4 || LPF == 8 || LPF == 16, "softmax lane groups are 4, 8 or 16 wide");
     static_assert(NPART == 1 || NPART == 2 || NPART == 4, "1, 2 or 4 partial slabs");
     const int tid = wave * 64 + lane;
-    if constexpr (LPF_ALL > 16) {                  // more threads than rows x 16 (helper waves): whole waves have no row
-        if (wave * 64 >= GROUPS * BM * LPF) {
-            __syncthreads();                       // the one barrier of this function
-            return;
-        }
-    }
     const int row = tid / LPF, part = tid % LPF;
     const int rg = GROUPS == 1 ? 0 : row / BM;     // wave-uniform: a wave's rows belong to one net
     const int frame = GROUPS == 1 ? row : row % BM;
@@ -840,11 +833,7 @@ __device__ __forceinline__ void softmax_rows(const Params &prm, const NetDev *ne
 // EARLY: `early` is this wave's loop, set up and begun by the caller (RingLoop::begin) -- its first fragments are already
 // travelling.  hook() runs right after the partial tiles are published, before the softmax (a place to begin() the
 // NEXT net's loop).
-// NH: helper waves (wave >= NW; 0 or NW of them: a second wave per SIMD).  They take no part in the hidden loops -- a
-// net's summation order is that of its NW loop waves whatever NH is -- and wait at the barriers meanwhile; in the
-// softmax and the epilogue (and in the caller's staging / projection stages) they are threads like the others, so
-// those latency-bound stages run two waves per SIMD.  For launches of one workgroup per CU.
-template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, int BKQ = 0, int ARITH = 0, int NH = 0,
+template <int KS, int NOT, int NW, bool EXACT, int FT, int GROUPS, bool EARLY = false, int BKQ = 0, int ARITH = 0,
           typename Params, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const NetDev *nets,
                                         const f4 *__restrict__ XFbase, int xf_stride, f4 *__restrict__ slab01,
@@ -852,17 +841,13 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
                                         RingLoop<KS, NOT, FT, EXACT, BKQ> *early = nullptr, Hook hook = Hook())
 {
     constexpr int WPG = NW / GROUPS;             // waves per net
-    const bool looper = NH == 0 || wave < NW;
-    const int lw = looper ? wave : 0;            // (helpers: any valid value, unused)
-    const int grp = GROUPS == 1 ? 0 : lw / WPG, wig = GROUPS == 1 ? lw : lw % WPG;
+    const int grp = GROUPS == 1 ? 0 : wave / WPG, wig = GROUPS == 1 ? wave : wave % WPG;
     const NetDev &nd = nets[grp];
     const int n_ot = EXACT ? NOT : nd.n_ot;
     const int slab_f4 = FT * n_ot_slab * 64;    // float4 per slab
     const f4 *XF = XFbase + (size_t)grp * xf_stride;
     const int g = lane >> 4;
 
-    static_assert(ARITH == 0 || (EXACT && !EARLY), "split-f16 arithmetic: compile-time shapes");
-    auto loops_and_publish = [&]() {
     // (this is hidden_range() + store_partial(), spelled out: as calls they compile to the same arithmetic
     //  but hipcc's register allocation of the 32-frame variants gets worse -- 57 instead of 1 AGPR copies
     //  for cz_42_69_9, accvgpr moves inside the merger's loop, 2 % slower in same-GPU A/B runs)
@@ -877,6 +862,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         for (int f = 0; f < FT; f++) acc[ot][f] = b;
     }
 
+    static_assert(ARITH == 0 || (EXACT && !EARLY), "split-f16 arithmetic: compile-time shapes");
     const int units = ARITH ? nd.npairs : nd.nht;        // what the waves share: hidden tiles, or tile pairs
     const int tpw = (units + WPG - 1) / WPG;
     const int ht0 = wig * tpw;
@@ -926,24 +912,13 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
         __syncthreads();
     }
     hook();
-    };
-    if constexpr (NH == 0) {
-        loops_and_publish();
-    } else {
-        if (looper) {
-            loops_and_publish();
-        } else {                               // helper waves: the loop waves' barriers, nothing else
-            if (GROUPS == 2) __syncthreads();
-            __syncthreads();
-        }
-    }
     LCRC_STAMP(prm, wave, lane, 12);           // partial tiles published (last net's value survives)
     const float *s01 = reinterpret_cast<const float *>(slab01), *s23 = reinterpret_cast<const float *>(slab23);
     constexpr int OVALID = EXACT ? 16 * (NOT - 1) : 0;
     if constexpr (GROUPS == 2)
-        softmax_rows<NOT, NW + NH, FT, 2, 2, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s01, s01, s23, s23 + slab_f4 * 4, lane, wave, epi);
+        softmax_rows<NOT, NW, FT, 2, 2, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s01, s01, s23, s23 + slab_f4 * 4, lane, wave, epi);
     else
-        softmax_rows<NOT, NW + NH, FT, 1, 4, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi);
+        softmax_rows<NOT, NW, FT, 1, 4, OVALID>(prm, nets, s01, s01 + slab_f4 * 4, s23, s23 + slab_f4 * 4, s01, s01, lane, wave, epi);
     __syncthreads();
 }
 

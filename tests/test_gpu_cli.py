@@ -697,3 +697,63 @@ def test_four_systems_at_once(tmp_path):
         gold = [l.split() for l in open(os.path.join(GOLD, "rec", system + ".rec")) if len(l.split()) == 4]
         assert [(int(x[0]), int(x[1]), x[2]) for x in entry] == [(int(x[0]), int(x[1]), x[2]) for x in gold], system
         assert max(abs(float(x[3]) - float(y[3])) for x, y in zip(entry, gold)) < 1e-2
+
+
+def _cli_peak_rss_mb(args):
+    """one CLI run; its own peak resident set (PHNREC_STATS: getrusage of the process, pinned buffers included)"""
+    p = run(*args, env={"PHNREC_STATS": "1"})
+    line = [ln for ln in p.stderr.splitlines() if ln.startswith("phnrec: files=")][-1]
+    return float(line.split("max_rss_mb=")[1].split()[0])
+
+
+def test_long_file_runs_as_row_ranges_with_bounded_pinned_memory(tmp_path):
+    """SURVEY 5 'long-context': a file longer than -b frames is computed as consecutive row ranges with 15-frame halos
+    (lcrc_posteriors_rows; srec.cpp:1035-1059's prime / main / flush is the halo rule) and decoded range by range.  A
+    1.2 M-frame file (3.3 hours of 8 kHz audio, as a parameter file: 72 MB) with -b 32768 gives the MLF entry of the
+    same file run as ONE launch (-b 2000000) byte for byte, and without the 660 MB of pinned posteriors of that launch:
+    peak resident set stated and compared."""
+    from tests.util import write_htk
+    from phnrec_amd import modelgen
+    n = 1200000
+    base = modelgen.synth_mel(40000, 15, seed=21, mean_norm=True)
+    mel = np.tile(base, (n // len(base), 1))
+    src = tmp_path / "long.mel"
+    write_htk(str(src), mel)
+    lst = tmp_path / "l.txt"
+    lst.write_text("%s\n" % src)
+    a, b = tmp_path / "chunked.mlf", tmp_path / "one.mlf"
+    rss_chunked = _cli_peak_rss_mb(["-c", model_dir(CZ), "-s", "par", "-l", lst, "-m", a, "-b", 32768])
+    rss_one = _cli_peak_rss_mb(["-c", model_dir(CZ), "-s", "par", "-l", lst, "-m", b, "-b", 2000000])
+    ta, tb = a.read_text(), b.read_text()
+    assert ta == tb and ta.count("\n") > 1000
+    print("peak RSS: %.0f MB as row ranges of 32768 frames, %.0f MB as one launch" % (rss_chunked, rss_one))
+    # features of the file (72 MB, twice while the parameter file is unpacked) + one launch's buffers + the HIP runtime
+    assert rss_chunked < 900.0
+    assert rss_one > rss_chunked + 400.0                 # 1.2 M x 552 B of posteriors, pinned
+
+
+@pytest.mark.parametrize("system,fmt", [(CZ, "lin16"), (EN, "lin16")])
+def test_long_waveform_row_ranges_every_mode_and_the_dump(system, fmt, tmp_path):
+    """the same through the front-end, on a 100 000-frame waveform with -b 8192: labels and the posterior dump equal the
+    one-launch form byte for byte; with -F / -E the long file's features come from the host front-end (the -E road's
+    bits = the default mode's), so those modes write the default mode's bytes; -D decodes such a file on the host"""
+    rate = 16000 if system == EN else 8000
+    rng = np.random.default_rng(9)
+    n = 99999 * (rate // 100) + rate // 40
+    t = np.arange(16 * rate) / float(rate)
+    sig = sum(0.06 * 32767 * np.sin(2 * np.pi * f * t) for f in (200, 700, 1300, 2100, 3400)) + rng.normal(0, 1000, len(t))
+    raw = np.tile(np.clip(sig, -32768, 32767).astype("<i2"), n // len(t) + 1)[:n]
+    src = tmp_path / "long.raw"
+    raw.tofile(str(src))
+    one = tmp_path / "one.rec"
+    run("-c", model_dir(system), "-i", src, "-o", one, "-b", 200000)
+    for k, flags in enumerate([(), ("-E",), ("-F",), ("-F", "-D"), ("-g", "2")]):
+        rec = tmp_path / ("c%d.rec" % k)
+        run("-c", model_dir(system), "-i", src, "-o", rec, "-b", 8192, *flags,
+            env={"PHNREC_DEVICE_MAP": "0,0"} if "-g" in flags else None)
+        assert rec.read_text() == one.read_text(), flags
+    lop1, lop2 = tmp_path / "one.lop", tmp_path / "c.lop"
+    run("-c", model_dir(system), "-i", src, "-t", "post", "-o", lop1, "-b", 200000)
+    run("-c", model_dir(system), "-i", src, "-t", "post", "-o", lop2, "-b", 8192)
+    assert lop1.read_bytes() == lop2.read_bytes()
+    assert read_htk(str(lop2)).shape[0] == 100000
