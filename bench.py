@@ -440,7 +440,10 @@ def run_cli(exe, args, env, timeout=600):
             "setup_s": float(kv["setup_s"]), "create_s": float(kv.get("create_s", 0)),
             "first_launch_s": float(kv.get("first_launch_s", 0)), "main_s": float(kv.get("main_s", 0)),
             "host_cpu_s": float(kv.get("host_cpu_s", 0)), "host_threads": int(kv.get("host_threads", 0)),
-            "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write", "viterbi") if k in kv}}, pr
+            "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write", "viterbi") if k in kv},
+            # the whole process (exec to exit: start-up, model load, list loop) -- what a caller of the CLI waits for
+            "process_frames_per_s": round(float(kv["frames"]) / wall, 1), "mode": kv.get("mode"),
+            "max_rss_mb": float(kv.get("max_rss_mb", 0))}, pr
 
 
 def single_file_leg(mdir, gpu):
@@ -497,6 +500,10 @@ def single_file_leg(mdir, gpu):
 
 
 HU = "PHN_HU_SPDAT_LCRC_N1500"
+# the CLI's roads over a list: host front-end; -E (mel energies on the GPU, ln() and the normalisations on the host: the host
+# front-end's bits); -F (whole front-end on the GPU); each with the decoder on the host or on the GPU (-D)
+LIST_MODES = (("host_frontend", []), ("gpu_energies_E", ["-E"]), ("gpu_energies_decoder_E_D", ["-E", "-D"]),
+              ("gpu_frontend_F", ["-F"]), ("gpu_frontend_decoder_F_D", ["-F", "-D"]))
 
 
 def sharded_list_leg(n_gpus, dmap, n_files):
@@ -510,7 +517,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         return {"error": "CLI or %s model directory missing" % HU}
     cores = usable_cpus()
     out = {"system": HU, "files": n_files, "gpus": n_gpus, "device_map": dmap, "cores_usable": cores,
-           "what": "phnrec -c HU -l list -m out.mlf -g N [-E | -F | -F -D] (PHNREC_DEVICE_MAP = the ranks' GPUs): raw lin16 8 kHz files of "
+           "what": "phnrec -c HU -l list -m out.mlf -g N [-E | -E -D | -F | -F -D] (PHNREC_DEVICE_MAP = the ranks' GPUs): raw lin16 8 kHz files of "
                    "3-15 s -> MLF on disk; frames/s of the list loop as the CLI reports it (process start-up and model load "
                    "excluded; process_wall_s includes them)"}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -524,8 +531,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         out["every_mode_decodes_on_the_gpu"] = n_gpus >= 4
         env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=",".join(str(d) for d in dmap))
         mlfs = {}
-        for key, extra in (("host_frontend", []), ("gpu_energies_E", ["-E"]), ("gpu_frontend_F", ["-F"]),
-                           ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+        for key, extra in LIST_MODES:
             mlf = os.path.join(td, key + ".mlf")
             try:
                 best = None
@@ -541,25 +547,59 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                 out[key] = {"error": repr(e)}
         if isinstance(out.get("gpu_frontend_F"), dict) and "value" in out["gpu_frontend_F"]:
             out["frames_per_s"] = out["gpu_frontend_F"]["value"]
-        if n_gpus > 1:
-            # N GPUs finish the 10 000 files in 0.32 s / N of list loop: at N = 8 that is 40 ms, most of it the ramp until
-            # every context has its first launch -- nothing a scaling curve can be read from.  So beside it: the same files
-            # listed N times (fixed work per GPU, nothing more to generate; the MLF repeats its entries), `-F` and `-F -D`.
-            rep_lst = os.path.join(td, "list_x%d.scp" % n_gpus)
-            with open(rep_lst, "w") as f:
-                for _ in range(n_gpus):
-                    f.write("".join(n + "\n" for n in names))
-            weak = {"files": n_files * n_gpus, "frames": frames * n_gpus,
-                    "what": "the same list with every file listed %d times: fixed work per GPU" % n_gpus}
-            for key, extra in (("gpu_frontend_F", ["-F"]), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
-                try:
-                    r, _pr = run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", os.path.join(td, "weak.mlf"), "-g", str(n_gpus)] + extra, env)
-                    weak[key] = r
-                    if "error" not in r and r.get("host_cpu_s", 0) > 0:
-                        weak[key]["host_ceiling_frames_per_s"] = round(frames * n_gpus * cores / r["host_cpu_s"], 1)
-                except Exception as e:
-                    weak[key] = {"error": repr(e)}
-            out["weak_list"] = weak
+            out["process_frames_per_s"] = out["gpu_frontend_F"]["process_frames_per_s"]
+        # N GPUs finish the 10 000 files in 0.3 s / N of list loop behind 0.45 s of process start-up: at N = 8 the loop is
+        # 40 ms, most of it the ramp until every context has its first launch -- nothing a scaling curve, or a host
+        # ceiling, can be read from.  So beside it the SAME files listed 8 x N times (fixed work per GPU, nothing more to
+        # generate; the MLF repeats its entries): a list loop of >= 2 s per GPU, every mode, one run each.  The criteria
+        # of the N-GPU plan are taken from these runs: per mode the host ceiling (frames x cores / host CPU seconds of the
+        # run) over 8 x the per-GPU rate, and -F -D against -F.
+        reps = 8 * n_gpus
+        import shutil
+        while reps > n_gpus and 40e6 * reps * (n_files / 10000.0) > shutil.disk_usage(td).free / 2:      # (the MLF: ~30 MB per 10 000 files)
+            reps //= 2
+        rep_lst = os.path.join(td, "list_x%d.scp" % reps)
+        with open(rep_lst, "w") as f:
+            for _ in range(reps):
+                f.write("".join(n + "\n" for n in names))
+        weak = {"files": n_files * reps, "frames": frames * reps,
+                "what": "the same list with every file listed %d times (8 x N GPUs: fixed work per GPU, list loop >= 2 s); "
+                        "value = frames/s of the list loop, process_frames_per_s = frames / process wall clock (exec to "
+                        "exit); host_ceiling_frames_per_s = frames x cores_usable / host_cpu_s of the same run; "
+                        "ceiling_over_8_gpus = that / (8 x value / N)" % reps}
+        wmlf = os.path.join(td, "weak.mlf")
+
+        def weak_run(extra, g, e):
+            r, _pr = run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", wmlf, "-g", str(g)] + extra, e, timeout=900)
+            if "error" not in r and r.get("host_cpu_s", 0) > 0:
+                r["host_ceiling_frames_per_s"] = round(frames * reps * cores / r["host_cpu_s"], 1)
+                r["ceiling_over_8_gpus"] = round(r["host_ceiling_frames_per_s"] / (8.0 * r["value"] / n_gpus), 3)
+            return r
+        for key, extra in LIST_MODES:
+            try:
+                weak[key] = weak_run(extra, n_gpus, env)
+            except Exception as e:
+                weak[key] = {"error": repr(e)}
+        if n_gpus == 1:
+            # What `phnrec -g 8 -l ... -m ...`, called as the reference is called (no flags), selects by itself -- -E and,
+            # from four GPUs on, -D; two contexts per GPU; sleeping waits -- with all eight logical GPUs mapped onto this
+            # box's one device: the per-GPU rate is that of ONE GPU behind sixteen contexts, the host CPU seconds are
+            # those the auto-selected path costs per frame.
+            try:
+                e8 = dict(env, PHNREC_DEVICE_MAP=",".join([str(dmap[0])] * 8))
+                r = weak_run([], 8, e8)
+                if "ceiling_over_8_gpus" in r:       # (eight logical GPUs, ONE device: value is one GPU's rate)
+                    r["ceiling_over_8_gpus"] = round(r["host_ceiling_frames_per_s"] / (8.0 * r["value"]), 3)
+                r["what"] = ("PHNREC_DEVICE_MAP=%s phnrec -g 8 without -F / -E / -D: the mode the CLI picks by itself ('mode'), "
+                             "eight logical GPUs on one device" % e8["PHNREC_DEVICE_MAP"])
+                weak["as_g8_default"] = r
+            except Exception as e:
+                weak["as_g8_default"] = {"error": repr(e)}
+        try:
+            weak["F_D_over_F"] = round(weak["gpu_frontend_decoder_F_D"]["value"] / weak["gpu_frontend_F"]["value"], 4)
+        except Exception:
+            pass
+        out["weak_list"] = weak
         # the headline's system (CZ) through the same list and modes (round 3's cli_e2e leg timed a 0.06-0.1 s loop of
         # 2000 files: inside the start-up ramp this list exists to amortise)
         cz_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_CZ_SPDAT_LCRC_N1500")
@@ -578,6 +618,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             out["mlf_entries"] = a.count('"\n') if a else 0
             # -E's features are the host front-end's bit for bit: so is its MLF
             out["mlf_E_equals_host_frontend"] = open(mlfs["gpu_energies_E"]).read() == open(mlfs["host_frontend"]).read()
+            out["mlf_E_D_equals_host_frontend"] = open(mlfs["gpu_energies_decoder_E_D"]).read() == open(mlfs["host_frontend"]).read()
         except Exception:
             pass
         # ---- what the host alone can do on this list ----
@@ -588,7 +629,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
                         "file reads into pinned memory, gather, host Viterbi, label / MLF formatting -- summed over the "
                         "pool's threads); the rate the host side of `phnrec -g N` cannot exceed on this box however many "
                         "GPUs serve it"}
-        for key in ("host_frontend", "gpu_energies_E", "gpu_frontend_F", "gpu_frontend_decoder_F_D"):
+        for key, _extra in LIST_MODES:
             r = out.get(key)
             if isinstance(r, dict) and r.get("host_cpu_s", 0) > 0:
                 ceil[key] = {"frames_per_s": round(frames * cores / r["host_cpu_s"], 1), "host_cpu_s": r["host_cpu_s"],
@@ -647,6 +688,87 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         except Exception as e:
             ceil["per_file_serial_error"] = repr(e)
         out["host_ceiling"] = ceil
+    return out
+
+
+def four_systems_leg(n_gpus, dmap, n_files=2500):
+    """BASELINE configs[4]: all four LCRC systems at once, two GPUs each, mixed 8 / 16 kHz lists, end to end.
+    tools/run_four_systems.sh starts four `phnrec -g 2` processes (CZ, HU, RU on 8 kHz lin16 files, EN on 16 kHz), each on its
+    GPU pair; the pairs come from the ranks' device map -- 8 GPUs: 0,1 2,3 4,5 6,7; fewer: the pairs wrap around; ONE GPU:
+    all four systems' eight logical GPUs on device 0 ("oversubscribed": the figure is then what one MI355X does for four
+    systems at once, not the 8-GPU arrangement's).  xRT = wall clock / seconds of audio (one frame = 10 ms)."""
+    import subprocess
+    script = os.path.join(ROOT, "tools", "run_four_systems.sh")
+    systems = ("PHN_CZ_SPDAT_LCRC_N1500", "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500", "PHN_EN_TIMIT_LCRC_N500")
+    dirs = [os.path.join(ROOT, "tests", "golden", "models", x) for x in systems]
+    exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
+    if not os.path.exists(exe) or not all(os.path.isdir(d) for d in dirs):
+        return {"error": "CLI or a model directory missing"}
+    pairs = ["%d,%d" % (dmap[(2 * i) % len(dmap)], dmap[(2 * i + 1) % len(dmap)]) for i in range(4)]
+    out = {"systems": list(systems), "files_per_system": n_files, "gpu_pairs": pairs,
+           "oversubscribed": len(set(dmap)) < 8,
+           "what": "tools/run_four_systems.sh: four concurrent `phnrec -c SYS -l list -m mlf -g 2` processes, one per system, on "
+                   "the GPU pairs named (with fewer than 8 GPUs the pairs share devices: oversubscribed); raw lin16 files of "
+                   "3-15 s, 8 kHz for CZ / HU / RU (the same files, one list each) and 16 kHz for EN; per system the CLI's own "
+                   "list-loop figures, in sum frames / wall clock of the whole script (process start-up, model loads, "
+                   "list loops, MLFs on disk) and xRT = that wall clock / seconds of audio"}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        d8, d16 = os.path.join(td, "k8"), os.path.join(td, "k16")
+        os.mkdir(d8)
+        os.mkdir(d16)
+        _l8, names8, _f8 = synthetic_list(d8, n_files, seed=1240, rate=8000)
+        lst16, _n16, _f16 = synthetic_list(d16, n_files, seed=1241, rate=16000)
+        lists = []
+        for k, x in enumerate(systems):
+            if x.startswith("PHN_EN"):
+                lists.append(lst16)
+            else:
+                # (one list file per system -- the script writes each MLF next to its list --, and one file fewer per system
+                #  down the line so that the four stats lines can be told apart by their file counts)
+                p = os.path.join(td, "%s.scp" % x[4:6].lower())
+                with open(p, "w") as f:
+                    f.write("".join(n + "\n" for n in names8[:n_files - 1 - k]))
+                lists.append(p)
+        env = dict(os.environ, PHNREC_GPU_PAIRS=" ".join(pairs), PHNREC_BIN=exe)
+        env.pop("PHNREC_DEVICE_MAP", None)
+        args = [a for pr in zip(dirs, lists) for a in pr]
+        for key, extra in (("default_flags", []), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+            best = None
+            for _ in range(2):               # the better of two runs (the first warms the page cache)
+                t0 = time.perf_counter()
+                pr = subprocess.run(["bash", script] + args + extra, env=env, capture_output=True, text=True, timeout=900)
+                wall = time.perf_counter() - t0
+                stats = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")]
+                if pr.returncode != 0 or len(stats) != 4:
+                    best = {"error": "rc=%d %s" % (pr.returncode, pr.stderr.strip()[-300:])}
+                    break
+                per, tot = {}, 0
+                for ln in stats:
+                    kv = dict(tok.split("=", 1) for tok in ln.replace("(", "").replace(")", "").split() if "=" in tok)
+                    nf = int(kv["files"])
+                    name = systems[3] if nf == n_files else systems[n_files - 1 - nf]
+                    per[name] = {"files": nf, "frames": int(kv["frames"]), "frames_per_s": float(kv["frames_per_s"]),
+                                 "list_wall_s": float(kv["wall_s"]), "main_s": float(kv["main_s"]), "xrt": float(kv["xRT"]),
+                                 "mode": kv.get("mode"), "host_cpu_s": float(kv["host_cpu_s"])}
+                    tot += int(kv["frames"])
+                r = {"per_system": per, "frames": tot, "process_wall_s": round(wall, 3),
+                     "value": round(tot / wall, 1), "unit": "frames/s (four systems in sum, whole script)",
+                     "xrt": round(wall / (tot * 0.01), 8),
+                     "list_loops_frames_per_s": round(tot / max(p["list_wall_s"] for p in per.values()), 1)}
+                if best is None or r["value"] > best["value"]:
+                    best = r
+            out[key] = best
+        # the MLFs of the last four-system run against each system run alone on one GPU (same flags)
+        try:
+            same = {}
+            for d, l, x in zip(dirs, lists, systems):
+                solo = os.path.join(td, x + ".solo.mlf")
+                e1 = dict(os.environ, PHNREC_DEVICE_MAP=str(dmap[0]))
+                subprocess.run([exe, "-c", d, "-l", l, "-m", solo, "-F", "-D"], env=e1, check=True, capture_output=True, timeout=600)
+                same[x] = open(solo).read() == open(l[:-4] + ".mlf").read()
+            out["mlf_equals_single_system_run"] = same
+        except Exception as e:
+            out["mlf_check_error"] = repr(e)
     return out
 
 
@@ -969,6 +1091,11 @@ def main():
                     line["sharded_list"] = sharded_list_leg(ranks.world, dmap, args.list_files)
                 except Exception as e:
                     line["sharded_list"] = {"error": repr(e)}
+                # BASELINE configs[4]: the four systems at once on the ranks' GPUs (one GPU: all on it, labelled)
+                try:
+                    line["four_systems"] = four_systems_leg(ranks.world, dmap, max(4, args.list_files // 4))
+                except Exception as e:
+                    line["four_systems"] = {"error": repr(e)}
             split_post = None
             gpu_post = d_post.cpu().numpy() if ranks.world == 1 else None
             if ranks.world == 1 and not args.no_extras:

@@ -610,14 +610,12 @@ void SpeechRec::Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols
         // behind it are not issued early enough to hide their latency.  Requested kAhead frames ahead, they are:
         // 10 000-file HU list on an EPYC 9575F, Viterbi CPU seconds 1.0-1.1 -> 0.28-0.30 (33 ns per frame, the rate of
         // the cache-resident micro-benchmark; gpurun_out/r04_exp_prefetch.txt; 4 / 8 / 16 / 32 frames ahead alike).
-        static const int kAhead = getenv("PHNREC_DEC_PREFETCH") ? atoi(getenv("PHNREC_DEC_PREFETCH")) : 8;
+        constexpr int kAhead = 8;
         const size_t row_bytes = (size_t)cols * sizeof(float);
         const char *base = reinterpret_cast<const char *>(post), *end = base + (size_t)job.frames * row_bytes;
         for (int r = 0; r < job.frames; r++) {
-            if (kAhead > 0) {
-                const char *q = base + (size_t)(r + kAhead) * row_bytes;
-                for (const char *e = q + row_bytes; q < e && q < end; q += 64) __builtin_prefetch(q, 0, 3);
-            }
+            const char *q = base + (size_t)(r + kAhead) * row_bytes;
+            for (const char *e = q + row_bytes; q < e && q < end; q += 64) __builtin_prefetch(q, 0, 3);
             dec.ProcessFrame(post + (size_t)r * cols);
         }
         dec.Done();
@@ -752,11 +750,10 @@ long long ThreadCpuNs()
 // CPUs of a GPU's NUMA node -- the node its PCIe root hangs on -- that the process may use.  The thread that feeds and
 // waits for GPU g keeps to them (it touches g's pinned staging buffers, allocated next to the GPU, and its doorbells),
 // and the pool keeps to the nodes of the GPUs in use.  Only where the node is known and has CPUs inside the process's
-// affinity mask, and PHNREC_NO_PIN is unset; silently nothing otherwise.
+// affinity mask; silently nothing otherwise.
 bool GpuNodeCpus(int device, cpu_set_t *want)
 {
     CPU_ZERO(want);
-    if (getenv("PHNREC_NO_PIN")) return false;
     char bus[64] = {0};
     if (lcrc_device_pci_bus_id(device, bus, sizeof bus) != 0 || !bus[0]) return false;
     for (char *q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
@@ -898,8 +895,8 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // (With the posteriors of a list's launches stored straight into the pinned buffer -- no copy-backs -- the step is
         //  worth less than before and nothing on some boxes: list loop 0.285 / 0.305 / 0.308 / 0.273 s with it against
         //  0.302 / 0.327 / 0.325 / 0.289 s without on one box, -F / -F -D / -E / host front-end, 0.293 / 0.303 / 0.333 / 0.315
-        //  against 0.296 / 0.325 / 0.323 / 0.312 on another; the process takes as long either way.  PHNREC_NO_RESERVE=1: off.)
-        if (!single_file && long_list_ && !getenv("PHNREC_NO_RESERVE")) {
+        //  against 0.296 / 0.325 / 0.323 / 0.312 on another; the process takes as long either way.)
+        if (!single_file && long_list_) {
             // (a -b beyond 131 072 frames is reserved up to that: a short list would never fill the rest, the buffers grow
             //  on demand as before)
             const int rows = std::min(batch_frames_, 131072);
@@ -1034,9 +1031,8 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         }
     };
 
-    // launch slots per PHYSICAL device (logical GPUs mapped onto one device share its slots); PHNREC_GPU_SLOTS=0: none
-    int slots_per_gpu = 2;
-    if (const char *e = getenv("PHNREC_GPU_SLOTS")) slots_per_gpu = std::max(0, atoi(e));
+    // two launch slots per PHYSICAL device (logical GPUs mapped onto one device share its slots)
+    const int slots_per_gpu = 2;
     std::map<int, std::unique_ptr<DeviceSlots>> dev_slots;
     if (need_gpu && slots_per_gpu > 0 && !single_file)
         for (int d : gpu_devices_)
@@ -1187,7 +1183,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             drain();
             return true;
         };
-        const bool row_ranges = tr.HasRowRanges() && !getenv("PHNREC_NO_ROW_RANGES");
+        const bool row_ranges = tr.HasRowRanges();
         trace(g, "worker up");
         while (take_launch(items)) {
             int cnt = (int)items.size();

@@ -108,7 +108,6 @@ struct lcrc_ctx {
     size_t cap_bytes = 0, cap_fe_utts = 0, cap_mean_blocks = 0;
     int mean_blocks = 0;                 // blocks of the last staged batch (tree mean)
     bool mean_sequential = true;         // lcrc_set_mean_order: the reference's order unless the caller opts out
-    bool direct_out = getenv("LCRC_NO_DIRECT_OUT") == nullptr;   // in-place consumers: posteriors stored straight into the pinned host buffer
     // streaming state (lcrc_push): the pushed frames live in a pinned, device-mapped strip whose last 30 rows
     // are the history (Traps::be_mat minus its newest slot); the kernel reads the strip and writes the
     // posteriors of a push in place (zero-copy), so a push costs no allocation and no copy command
@@ -579,12 +578,12 @@ int ensure_host_post(lcrc_ctx *c)
 // 0.378 -> 0.314 ms (the copy was 82 us at PCIe's rate plus its hand-over); lists: the same rate within their noise
 // (-F 31.3 -> 31.9 M frames/s), with 24 MB per launch less in the copy queue that all contexts of a device share.  Not for
 // callers that get the posteriors copied into their own buffer: there the copy-back's pieces overlap that host copy
-// (lcrc_posteriors 0.47 -> 0.50 ms with direct output).  LCRC_NO_DIRECT_OUT=1: always copy.  *out = where the launch stores.
+// (lcrc_posteriors 0.47 -> 0.50 ms with direct output).  *out = where the launch stores.
 int output_target(lcrc_ctx *c, bool copy_post, bool in_place, float **out, bool *direct)
 {
     *out = c->d_post;
     *direct = false;
-    if (!c->direct_out || !in_place || !copy_post || c->dec_P > 0) return LCRC_OK;      // (the decoder on the device reads d_post)
+    if (!in_place || !copy_post || c->dec_P > 0) return LCRC_OK;      // (the decoder on the device reads d_post)
     const int rc = ensure_host_post(c);
     if (rc) return rc;
     HIP_TRY(c, hipHostGetDevicePointer((void **)out, c->h_post, 0));
@@ -831,9 +830,9 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
 // *done = false: not applicable, the caller takes the ordinary road.
 int two_part_output(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n, float *post, bool *done)
 {
-    static const long kMinRows = getenv("LCRC_TWO_PART_ROWS") ? atol(getenv("LCRC_TWO_PART_ROWS")) : 8192;
+    constexpr long kMinRows = 8192;
     *done = false;
-    if (!post || c->system != SYS_LCRC || c->dec_P > 0 || !c->direct_out || n < kMinRows) return LCRC_OK;
+    if (!post || c->system != SYS_LCRC || c->dec_P > 0 || n < kMinRows) return LCRC_OK;
     int rc = ensure_host_post(c);
     if (rc) return rc;
     float *out = nullptr;
@@ -1178,9 +1177,8 @@ int lcrc_device_warmup(int device_id)
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
     HIP_TRY(nullptr, hipSetDevice(device_id));
     HIP_TRY(nullptr, hipFree(nullptr));                 // brings the device's primary context up
-    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights): LCRC_NO_PRELOAD=1
-    // leaves it to the first launch
-    if (!getenv("LCRC_NO_PRELOAD")) (void)lcrc_preload_code();
+    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights)
+    (void)lcrc_preload_code();
     return LCRC_OK;
 }
 

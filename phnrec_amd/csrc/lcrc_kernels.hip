@@ -53,15 +53,10 @@
 
 namespace phnrec {
 
-// ln() of a band posterior on its way into the merger (sLn, dspc.h:155-160).
-// (A/B switch, tools/build_ab_lib.sh: v_log_f32 * ln 2 -- 2 instructions instead of logf's ~25; -0.4 % on every shape, not
-//  adopted: 2 ulp instead of 1, and v_log_f32 takes a DENORMAL posterior for zero (-inf into the merger's operand image
-//  where the reference's logf gives -90...-103), so the switch would need logf's own rescaling branch back)
-#ifdef LCRC_FAST_LN
-__device__ __forceinline__ float band_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
-#else
+// ln() of a band posterior on its way into the merger (sLn, dspc.h:155-160): the device library's logf (1 ulp; a
+// v_log_f32 form was measured at -0.4 % and not adopted -- 2 ulp, and a DENORMAL posterior becomes -inf where the
+// reference's logf gives -90...-103: profiles/r04_ab_runs.txt 9)
 __device__ __forceinline__ float band_ln(float x) { return logf(x); }
-#endif
 
 // The last-arriver seam of the split-hidden path (guide recipe, write-through form: the partial tiles are stored
 // sc1 -- straight through the XCD's L2, so no release fence (an L2 write-back, ~6 us under load) is needed --,
@@ -141,6 +136,11 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = p.nbanks;
+    // Issue priority above the default: with -D the decoder kernel's waves (phndec_kernels.hip: one per SIMD of the CUs they
+    // land on, ~250 dependent VALU instructions per frame for ~2 ms) sit beside this kernel's waves, and a SIMD issues one
+    // VALU-class instruction -- MFMA or not -- per cycle: at equal priority the arbiter gives the decoder wave every
+    // other turn.  The decoder fills the turns these waves leave (waits for weights, barriers).  No effect among this kernel's own waves.
+    __builtin_amdgcn_s_setprio(2);
     // k-groups per frame tile of the operand images.  Run-time shapes use their CLASS's counts as well (groups past the
     // net's own hold zeros): image addresses are then compile-time offsets in the hidden loops (mlp_dev.h RingLoop);
     // only the staging of the normalisation vectors knows the net's own sizes (nkq1_net, nkqm_net).
@@ -839,9 +839,8 @@ hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **var
     // CZ 8192 rows 0.1945 -> 0.1925 ms, 32768 0.7738 -> 0.7622; HU 32768 0.9379 -> 0.9253; RU 0.7825 -> 0.7670; EN 8192
     // 0.0803 -> 0.0786, 32768 0.3151 -> 0.3056 (0.731 -> 0.754 of peak).  (Rounds 1 and 2 found the opposite: the weight
     // loads' 64-bit per-lane addresses then cost twice as much per MFMA in 16-frame workgroups; with scalar-base loads they
-    // do not.)  LCRC_NO_PAIR16=1 keeps the 32-frame rounds (A/B).
-    static const bool no_pair16 = getenv("LCRC_NO_PAIR16") != nullptr;
-    const bool pair16 = !no_pair16 && 2u * lcrc_lds_plan(1, p.nbanks, k1, km, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
+    // do not.)
+    const bool pair16 = 2u * lcrc_lds_plan(1, p.nbanks, k1, km, lcrc_n_ot_slab(p.net)).total <= 160u * 1024u;
     const int ft_round = pair16 ? 1 : 2;
     const int tiles16_all = (rows + 15) / 16;
     const bool small_splits = p.tile_frames != 32 && choose_split(p, tiles16_all, n_cu) > 1;

@@ -36,17 +36,9 @@ struct IntTag { static constexpr int value = V; };
 #define LCRC_STAMP(p, wave, lane, idx) do { } while (0)
 #endif
 
-#ifndef LCRC_DBG
-#define LCRC_DBG 0
-#endif
 __device__ __forceinline__ f4 mfma16x16x4(float a, float b, f4 c)
 {
-#if (LCRC_DBG & 8)      // ablation: one 4-cycle FMA in place of the 32-cycle MFMA (what the weight stream alone allows)
-    c[0] = __builtin_fmaf(a, b, c[0]);
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
 }
 
 // ---- FEXP (fexp.h:14-21) ----------------------------------------------------------
@@ -279,12 +271,6 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
     img[((f * nkq + kq) * 64 + l) * 4 + j] = v;
 }
 
-// compile-time ablation switches of the diagnostic build (make stamps DBG=n): 1 = every
-// weight load from tile 0 (L1-resident), 2 = no sigmoid arithmetic, 4 = no in-loop loads, 8 = no MFMAs
-#ifndef LCRC_DBG
-#define LCRC_DBG 0
-#endif
-
 // ---- hidden loop, ring form ----------------------------------------------------------------
 // One wave per SIMD (a second one does not pay: DESIGN.md 3, "What bounds it").  The weight fragments stream
 // through a RING of R registers-quads instead of one buffer per layer.  Per hidden tile t the
@@ -298,9 +284,6 @@ __device__ __forceinline__ void xf_store(float *img, int nkq, int frame, int k, 
 // are in flight, so the in-order vmcnt waits never drain more than the one fragment needed.
 constexpr int lcrc_ring_size(int f, int n_ot = 0)
 {
-#ifdef LCRC_RING_FIXED      // A/B switch (tools/ab_kernel.py)
-    return LCRC_RING_FIXED;
-#endif
     int best = 8, pad = 1 << 30;
     // (12 or more output tiles: at most 10 slots -- with 12 the 32-frame variants spill accumulators to AGPRs)
     for (int r = n_ot >= 12 ? 10 : 12; r >= 7; r--) {             // least padding; ties -> the deeper ring
@@ -368,8 +351,6 @@ struct RingLoop {
     template <int MODE>
     __device__ __forceinline__ void pass(f4 (&acc)[NOT][FT], f4 (&pre)[FT], f4 &bias, int t)
     {
-        constexpr bool kSkipSig = (LCRC_DBG & 2) != 0;
-        constexpr bool kSkipLd = (LCRC_DBG & 4) != 0;
         const int g = lane >> 4;
         // run-time shapes: the bounds are re-materialised per pass (an empty asm the optimiser cannot see through), so the
         // ~80 comparisons against them are redone on the scalar unit in every pass instead of being hoisted out of the
@@ -380,16 +361,14 @@ struct RingLoop {
         if (MODE != PRO) {
             SigTile<FT> sg;
             sg.begin(pre);
-            if (!kSkipSig) {
 #pragma unroll
-                for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
-            }
+            for (int k = 0; k < SigTile<FT>::kStages; k++) sg.stage(k);
             sg.finish(s);
         }
 #pragma unroll
         for (int f = 0; f < FT; f++) nxt[f] = bias;
         __builtin_amdgcn_sched_barrier(0);
-        if (MODE != LAST && !kSkipLd)              // bias of the tile after next: requested first, so
+        if (MODE != LAST)                          // bias of the tile after next: requested first, so
             bias = *reinterpret_cast<const f4 *>(b1 + 16 * min(t + 2, hlast) + 4 * g);   // it is old when needed
         f4 xb[2][FT];
         // The B image's row stride is the CLASS's k-groups (NKQ) for run-time shapes too: every read below is then the
@@ -422,7 +401,7 @@ struct RingLoop {
                     }
             }
             const int e = (i + R) % FP, dt = (i + R) / FP;
-            if (!kSkipLd && (MODE != LAST || (dt == 0 && e < NOT))) request(i % R, e, t + dt, nkq, n_ot);
+            if (MODE != LAST || (dt == 0 && e < NOT)) request(i % R, e, t + dt, nkq, n_ot);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE != LAST) {
@@ -472,7 +451,7 @@ struct RingLoop {
     {
         w1 = reinterpret_cast<const f4 *>(nd.w1p); w2 = reinterpret_cast<const f4 *>(nd.w2p);
         b1 = nd.b1; XF = xf_image; lane = lane_;
-        hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+        hlast = nd.nht - 1;
         ks = nd.ksteps; nkq = nd.nkq; n_ot = nd.n_ot;
         z1 = w1 + (size_t)nd.nht * nd.nkq * 64; z2 = w2 + (size_t)nd.nht * nd.n_ot * 64;
         zi1 = nd.nht * nd.nkq; zi2 = nd.nht * nd.n_ot;
@@ -526,11 +505,7 @@ __device__ __forceinline__ void h2_img_store(void *img, int ofs, int lo_ofs, flo
 // layer-1 MFMAs' issue gaps (which the f16 MFMA, unlike the f32 one, leaves to the VALU) it gained nothing (A/B run 18).
 constexpr int h2_ring_size()
 {
-#ifdef LCRC_H2_RING      // A/B switch (tools/build_ab_lib.sh)
-    return LCRC_H2_RING;
-#else
     return 8;
-#endif
 }
 
 // Hidden loop on tile PAIRS (32 hidden units): the layer-1 results of two 16-row tiles are, lane for lane, the B
@@ -575,10 +550,8 @@ struct HalfLoop {
         if (MODE != PRO) {
             SigTile<2 * FT> sg;
             sg.begin(pre);
-            if (!(LCRC_DBG & 2)) {
 #pragma unroll
-                for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k, sig_mul);
-            }
+            for (int k = 0; k < SigTile<2 * FT>::kStages; k++) sg.stage(k, sig_mul);
             f4 s[2 * FT];
             sg.finish(s);
 #pragma unroll
@@ -637,7 +610,7 @@ struct HalfLoop {
                 }
             }
             const int e = (i + R) % FP, dp = (i + R) / FP;
-            if ((MODE != LAST || (dp == 0 && e < NOT)) && !(LCRC_DBG & 4)) request(i % R, e, P + dp);
+            if ((MODE != LAST || (dp == 0 && e < NOT))) request(i % R, e, P + dp);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (MODE != LAST) {
@@ -678,7 +651,7 @@ struct HalfLoop {
         w1 = reinterpret_cast<const f4 *>(nd.w1h); w2 = reinterpret_cast<const f4 *>(nd.w2h);
         b1 = nd.b1h; XF = xf_image; lane = lane_;
         sig_mul = SigTile<1>::kFexpA * (double)nd.h2_sig_descale;
-        plast = (LCRC_DBG & 1) ? 0 : nd.npairs - 1;
+        plast = nd.npairs - 1;
     }
 };
 
@@ -708,7 +681,7 @@ __device__ __forceinline__ void hidden_range(const NetDev &nd, const f4 *XF, int
     loop.w1 = reinterpret_cast<const f4 *>(nd.w1p);
     loop.w2 = reinterpret_cast<const f4 *>(nd.w2p);
     loop.b1 = nd.b1; loop.XF = XF; loop.lane = lane;
-    loop.hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+    loop.hlast = nd.nht - 1;
     loop.ks = nd.ksteps; loop.nkq = nd.nkq; loop.n_ot = nd.n_ot;
     loop.z1 = loop.w1 + (size_t)nd.nht * nd.nkq * 64; loop.z2 = loop.w2 + (size_t)nd.nht * nd.n_ot * 64;
     loop.zi1 = nd.nht * nd.nkq; loop.zi2 = nd.nht * nd.n_ot;
@@ -871,7 +844,7 @@ __device__ __forceinline__ void run_net(const Params &prm, int stamp0, const Net
     const f4 *const w1 = reinterpret_cast<const f4 *>(nd.w1p);
     const f4 *const w2 = reinterpret_cast<const f4 *>(nd.w2p);
     const float *const b1 = nd.b1;
-    const int hlast = (LCRC_DBG & 1) ? 0 : nd.nht - 1;
+    const int hlast = nd.nht - 1;
 
     if constexpr (ARITH == 1) {
         HalfLoop<KS, NOT, FT> loop;

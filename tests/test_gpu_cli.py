@@ -630,6 +630,17 @@ def test_bench_line_carries_every_leg():
     assert sl["host_ceiling"]["frames_per_s"] > 0 and sl["host_ceiling"]["gpu_frontend_F"]["host_cpu_s"] > 0
     assert sl["cz_same_list"]["host_frontend"]["value"] > 50000 and sl["cz_same_list"]["gpu_frontend_F"]["value"] > 50000
     assert sl["host_ceiling"]["per_file_serial"]["files_per_s"] > 20000      # (round 3's pipeline: 80 k on these hosts; now ~400 k)
+    assert sl["gpu_energies_decoder_E_D"]["value"] > 50000 and sl["mlf_E_D_equals_host_frontend"] is True
+    # the fixed-work-per-GPU form (every file listed 8 times), every mode, and what `-g 8` picks by itself on this one device
+    wl = sl["weak_list"]
+    assert wl["files"] == 8 * 120 and all(wl[k]["value"] > 50000 and wl[k]["ceiling_over_8_gpus"] > 0 for k in (
+        "host_frontend", "gpu_energies_E", "gpu_energies_decoder_E_D", "gpu_frontend_F", "gpu_frontend_decoder_F_D"))
+    assert wl["as_g8_default"]["mode"] == "E+D,auto" and wl["as_g8_default"]["value"] > 50000
+    # configs[4]: the four systems at once (here: all on this box's one GPU), MLFs those of each system run alone
+    fs = d["four_systems"]
+    assert fs["oversubscribed"] is True and set(fs["default_flags"]["per_system"]) == set(fs["systems"])
+    assert fs["default_flags"]["value"] > 50000 and fs["gpu_frontend_decoder_F_D"]["value"] > 50000
+    assert all(fs["mlf_equals_single_system_run"].values()) and len(fs["mlf_equals_single_system_run"]) == 4
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
@@ -653,8 +664,11 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert sl["gpus"] == 2 and sl["device_map"] == [0, 0] and sl["files"] == 150
     # ... and the fixed-work-per-GPU form of the list (every file listed N times)
     wl = sl["weak_list"]
-    assert wl["files"] == 300 and wl["frames"] == 2 * sl["frames"]
+    assert wl["files"] == 16 * 150 and wl["frames"] == 16 * sl["frames"]
     assert wl["gpu_frontend_F"]["value"] > 50000 and wl["gpu_frontend_decoder_F_D"]["value"] > 50000
+    assert wl["host_frontend"]["mode"] == "E,auto" and wl["gpu_energies_decoder_E_D"]["value"] > 50000
+    fs = line["four_systems"]
+    assert fs["gpu_pairs"] == ["0,0"] * 4 and fs["oversubscribed"] is True and fs["default_flags"]["value"] > 50000
     assert sl["frames_per_s"] > 50000 and sl["host_ceiling"]["frames_per_s"] > 0 and sl["cores_usable"] >= 1
 
 
@@ -726,9 +740,18 @@ def test_long_file_runs_as_row_ranges_with_bounded_pinned_memory(tmp_path):
     rss_one = _cli_peak_rss_mb(["-c", model_dir(CZ), "-s", "par", "-l", lst, "-m", b, "-b", 2000000])
     ta, tb = a.read_text(), b.read_text()
     assert ta == tb and ta.count("\n") > 1000
-    print("peak RSS: %.0f MB as row ranges of 32768 frames, %.0f MB as one launch" % (rss_chunked, rss_one))
-    # features of the file (72 MB, twice while the parameter file is unpacked) + one launch's buffers + the HIP runtime
-    assert rss_chunked < 900.0
+    # the floor of any run of this CLI on this box (HIP runtime, code objects, three contexts): a 1000-frame file, same flags
+    small = tmp_path / "small.mel"
+    write_htk(str(small), base[:1000])
+    lst2 = tmp_path / "l2.txt"
+    lst2.write_text("%s\n" % small)
+    rss_floor = _cli_peak_rss_mb(["-c", model_dir(CZ), "-s", "par", "-l", lst2, "-m", tmp_path / "small.mlf", "-b", 32768])
+    print("peak RSS: %.0f MB as row ranges of 32768 frames, %.0f MB as one launch, %.0f MB for a 1000-frame file"
+          % (rss_chunked, rss_one, rss_floor))
+    # above that floor: the features of the file (72 MB, up to three times while the parameter file is unpacked and
+    # copied) + one launch's buffers (32768 x (60 + 552) B pinned, 18 MB of pageable posteriors): bound 450 MB, of which
+    # only the features grow with the file
+    assert rss_chunked < rss_floor + 450.0
     assert rss_one > rss_chunked + 400.0                 # 1.2 M x 552 B of posteriors, pinned
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a CLI list run's wall clock goes on the GPU: runs `phnrec` on the configs[3] list under rocprofv3 --kernel-trace
 and reports, per kernel, calls / total / average, and the UNION of the kernels' busy intervals against the span from the
-first launch to the last (idle share = the host could not keep the device fed).  usage: cli_timeline.py [files] [flags...]"""
+first launch to the last (idle share = the host could not keep the device fed).  usage: cli_timeline.py [files] [flags...]
+env TIMELINE_REPS=n: every file listed n times (a list loop of seconds); TIMELINE_ROWS=k: the first k launches one by one."""
 import csv
 import glob
 import os
@@ -21,6 +22,13 @@ def main():
     mdir = os.path.join(ROOT, "tests", "golden", "models", bench.HU)
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         lst, names, frames = bench.synthetic_list(td, n_files)
+        reps = int(os.environ.get("TIMELINE_REPS", "1"))
+        if reps > 1:
+            lst = os.path.join(td, "rep.scp")
+            with open(lst, "w") as f:
+                for _ in range(reps):
+                    f.write("".join(n + "\n" for n in names))
+            frames *= reps
         out = os.path.join(td, "prof")
         env = dict(os.environ, PHNREC_STATS="1", TMPDIR="/tmp")
         subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "w.mlf")] + flags, env=env, capture_output=True)   # page cache
@@ -60,6 +68,24 @@ def main():
               % (span / 1e6, busy / 1e6, 100.0 * busy / span, sum(c[1] for c in per.values()) / 1e6))
         for n, (calls, tot) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             print("  %-62s calls %5d  total %8.2f ms  avg %8.1f us" % (n, calls, tot / 1e6, tot / calls / 1e3))
+        # the posterior kernel alone: how much of the span at least one / exactly one / two or more of its launches run, and how
+        # much of its running time a decoder kernel runs beside it
+        ev = []
+        for s, e, n in iv:
+            kind = 0 if "lcrc_fused_kernel" in n else 1 if "phndec" in n else -1
+            if kind >= 0:
+                ev += [(s, 0, kind), (e, 1, kind)]
+        ev.sort()
+        cnt, last, acc = [0, 0], ev[0][0] if ev else 0, {}
+        for t, typ, kind in ev:
+            key = (min(cnt[0], 2), min(cnt[1], 1))
+            acc[key] = acc.get(key, 0) + t - last
+            last = t
+            cnt[kind] += 1 if typ == 0 else -1
+        tot = float(sum(acc.values())) or 1.0
+        print("  posterior kernels in flight x decoder kernel in flight, share of the span between the first and last of them:")
+        for key in sorted(acc):
+            print("    posterior %s, decoder %s: %7.1f ms = %4.1f %%" % (("0", "1", ">=2")[key[0]], ("no", "yes")[key[1]], acc[key] / 1e6, 100.0 * acc[key] / tot))
 
 
 if __name__ == "__main__":

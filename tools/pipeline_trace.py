@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Where the first milliseconds of a list go: `phnrec -l` on BASELINE configs[3]'s list (HU, 10 000 files) with
 PHNREC_TRACE_PIPELINE=1 (the workers' steps, time-stamped) and LCRC_TRACE_SLOW_US (library calls that took longer than
-that, with the step that took it), followed by the process wall clock with and without the set-up step that reserves the
-contexts' buffers (PHNREC_NO_RESERVE=1).
+that, with the step that took it), followed by the process wall clock of each mode.
 usage: pipeline_trace.py [n_files]      env TRACE_CHARS: how much of the trace to print; TRACE_FLAGS: "-F;-F -D;" (modes, ';'-separated)"""
 import os
 import subprocess
@@ -31,7 +30,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
         sys.exit(0)
     print("===== process wall clock, best of 5 (list wall in brackets)")
     for flags in (["-F"], ["-F", "-D"], ["-E"], []):
-        for extra in ({}, {"PHNREC_NO_RESERVE": "1"}):
+        for extra in ({},):
             best = None
             for rep in range(5):
                 env = dict(os.environ, PHNREC_STATS="1", **extra)

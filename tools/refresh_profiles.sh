@@ -69,11 +69,10 @@ print(json.dumps({k: r[k] for k in ('host_frontend', 'gpu_frontend_F', 'gpu_fron
 TIMELINE_ROWS=40 python3 tools/cli_timeline.py 10000 -F > $OUT/cli_timeline.txt 2>&1
 python3 tools/cli_timeline.py 10000 -F -D >> $OUT/cli_timeline.txt 2>&1
 python3 tools/cli_timeline.py 10000 >> $OUT/cli_timeline.txt 2>&1
-python3 tools/cli_sweep.py 10000 "2,3,0;0,3,0;2,4,0" > $OUT/cli_sweep.txt 2>&1
+python3 tools/cli_sweep.py 10000 "3,0;2,0;4,0" > $OUT/cli_sweep.txt 2>&1
 python3 tools/host_decoder_probe.py > $OUT/host_decoder_probe.txt 2>&1
-# the first milliseconds of a list: the workers' steps and the library's slow calls, with and without the set-up step
+# the first milliseconds of a list: the workers' steps and the library's slow calls
 TRACE_CHARS=5000 python3 tools/pipeline_trace.py > $OUT/pipeline_trace.txt 2>&1
-PHNREC_NO_RESERVE=1 TRACE_CHARS=5000 TRACE_ONLY=1 python3 tools/pipeline_trace.py > $OUT/pipeline_trace_no_reserve.txt 2>&1
 ./tools/ubench/pinned_read 256 16 > $OUT/pinned_read.txt 2>&1
 ./tools/ubench/pinned_read 256 1 >> $OUT/pinned_read.txt 2>&1
 ls -R $OUT | head -80

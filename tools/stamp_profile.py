@@ -27,9 +27,7 @@ ORDER = [0, 1, 10, 2, 3, 8, 9, 11]     # stamp indices in program order
 def main():
     system = sys.argv[1] if len(sys.argv) > 1 else "PHN_CZ_SPDAT_LCRC_N1500"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-    dbg = os.environ.get("LCRC_DBG", "0")
-    capi.LIB_PATH = os.path.join(ROOT, "phnrec_amd", "lib",
-                                 "libphnrec_lcrc_stamps%s.so" % ("" if dbg == "0" else "_dbg" + dbg))
+    capi.LIB_PATH = os.path.join(ROOT, "phnrec_amd", "lib", "libphnrec_lcrc_stamps.so")
     L = capi.load()
     L.lcrc_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     spec = modelgen.SYSTEMS[system]
@@ -38,7 +36,6 @@ def main():
         mdir = "/tmp/stamp_model_" + system
         modelgen.write_system(mdir, system, seed=1)
     ctx = capi.Lcrc(mdir, spec["nbanks"])
-    print("ablation build LCRC_DBG =", dbg)
     mel = torch.from_numpy(modelgen.synth_mel(n, spec["nbanks"], seed=1)).cuda()
     post = torch.empty((n, ctx.n_out), device="cuda")
     bm = int(os.environ.get("LCRC_BM", "32"))                 # frames per workgroup (forced below)
