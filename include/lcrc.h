@@ -34,7 +34,8 @@ extern "C" {
  *    scaled (any finite weights); lcrc_debug_fail_alloc needs LCRC_FAULT_INJECTION=1 in the environment */
 /* 3: additions only (every version-2 caller links and behaves as before): lcrc_device_pci_bus_id,
  *    lcrc_set_kernel_done_callback, lcrc_wave_stage_energies, lcrc_reserve */
-#define LCRC_ABI_VERSION 3
+/* 4: additions only: lcrc_set_decoder_overlap, lcrc_prev_labels, lcrc_set_launch_order */
+#define LCRC_ABI_VERSION 4
 
 enum {
     LCRC_OK        = 0,
@@ -273,6 +274,25 @@ int lcrc_decoder_configure(lcrc_ctx *ctx, int n_phonemes, int states_per_phn, in
 int lcrc_set_posterior_readback(lcrc_ctx *ctx, int enabled);
 /* labels of utterance u: labels[first[u]] .. labels[first[u] + count[u] - 1]; valid until the next call */
 int lcrc_last_labels(lcrc_ctx *ctx, const lcrc_label **labels, const int **first, const int **count, int *n_utts);
+/* For callers that run list after list of staged calls (this repository's SpeechRec): the decoder of a call runs BESIDE the
+ * next call's front-end and posterior kernels instead of in front of them.  With lcrc_set_decoder_overlap(ctx, 1) -- and the
+ * decoder configured, read-back off -- lcrc_stage_run and lcrc_wave_stage_run(post = NULL) return as soon as their
+ * posterior kernels are done; the decoder kernel follows on a second stream of the context, on the
+ * call's own copies of the posteriors, offsets and label buffers (two sets alternate).  The labels of a call are then
+ * fetched AFTER the next call has returned: lcrc_prev_labels waits for the decoder of the call before the most recent
+ * one and returns its labels (valid until the next staged call but one); lcrc_last_labels does the same for the most
+ * recent call (after the last call of a list).  Same labels as without the overlap (tested); every other entry point
+ * keeps decoding synchronously.  Has no reference counterpart (the reference decodes frame by frame on the host,
+ * srec.cpp:1089-1104). */
+int lcrc_set_decoder_overlap(lcrc_ctx *ctx, int enabled);
+/* Several contexts of one process on one device (the CLI's three per GPU): with lcrc_set_launch_order(ctx, 1) on each of
+ * them, the POSTERIOR kernels of their calls run one after the other on the device, in the order the calls queued them --
+ * each launch waits, on the device, for an event behind the posterior kernels of the launch queued before it --, while
+ * everything else of a call (uploads, front-end kernels, decoder) still runs beside other contexts' work.  Two posterior
+ * kernels that share the device finish together and later than they would one after the other; the order only removes
+ * that, no result changes.  Default 0.  No reference counterpart. */
+int lcrc_set_launch_order(lcrc_ctx *ctx, int ordered);
+int lcrc_prev_labels(lcrc_ctx *ctx, const lcrc_label **labels, const int **first, const int **count, int *n_utts);
 
 /* ---- streaming form (Traps semantics) -----------------------------------------
  * lcrc_reset == Traps::Reset (traps.cpp:174-177).

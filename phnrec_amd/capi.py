@@ -20,7 +20,7 @@ SYMBOLS = [
     "lcrc_stage_buffers", "lcrc_stage_run",
     "lcrc_frontend_configure", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_reserve", "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
-    "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels",
+    "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels", "lcrc_set_decoder_overlap", "lcrc_prev_labels", "lcrc_set_launch_order",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
     "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_kernel_done_callback", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
 ]
@@ -134,6 +134,9 @@ def load():
     L.lcrc_set_posterior_readback.argtypes = [vp, C.c_int]
     L.lcrc_last_labels.argtypes = [vp, C.POINTER(C.POINTER(Label)), C.POINTER(C.POINTER(C.c_int)),
                                    C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.c_int)]
+    L.lcrc_prev_labels.argtypes = L.lcrc_last_labels.argtypes
+    L.lcrc_set_decoder_overlap.argtypes = [vp, C.c_int]
+    L.lcrc_set_launch_order.argtypes = [vp, C.c_int]
     L.lcrc_frontend_frames.argtypes = [vp, C.c_longlong]
     _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -268,11 +271,20 @@ class Lcrc:
     def set_posterior_readback(self, on):
         self._check(self.L.lcrc_set_posterior_readback(self.h, int(on)))
 
-    def last_labels(self):
+    def set_decoder_overlap(self, on):
+        """staged calls return when their posterior kernels are done; their labels come from prev_labels() after the next
+        call, or last_labels() after the last one (lcrc_set_decoder_overlap)"""
+        self._check(self.L.lcrc_set_decoder_overlap(self.h, int(on)))
+
+    def prev_labels(self):
+        """labels of the staged call BEFORE the most recent one (lcrc_prev_labels)"""
+        return self.last_labels(fn=self.L.lcrc_prev_labels)
+
+    def last_labels(self, fn=None):
         """labels of the most recent host-synchronous call: one list of (start, end, phn, score) per utterance"""
         lab, first, cnt = C.POINTER(Label)(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
         n = C.c_int()
-        self._check(self.L.lcrc_last_labels(self.h, C.byref(lab), C.byref(first), C.byref(cnt), C.byref(n)))
+        self._check((fn or self.L.lcrc_last_labels)(self.h, C.byref(lab), C.byref(first), C.byref(cnt), C.byref(n)))
         out = []
         for u in range(n.value):
             out.append([(lab[first[u] + k].start, lab[first[u] + k].end, lab[first[u] + k].phn, lab[first[u] + k].score)
@@ -335,6 +347,30 @@ class Lcrc:
         self._check(self.L.lcrc_wave_stage_run(self.h, np.array(start, np.int64), np.array([len(b) for b in blobs], np.int64),
                                                len(blobs), out, foff))
         return out, foff
+
+    def wave_decode_staged(self, blobs):
+        """lcrc_wave_stage_run with post = NULL: the posteriors stay on the device (decoder configured, read-back off);
+        returns the frame offsets.  Labels: last_labels(), or prev_labels() under set_decoder_overlap"""
+        blobs = [bytes(b) for b in blobs]
+        start, pos = [], 0
+        for b in blobs:
+            start.append(pos)
+            pos += len(b) + (len(b) & 1)
+        buf = C.POINTER(C.c_ubyte)()
+        self._check(self.L.lcrc_wave_stage_buffer(self.h, max(pos, 16), C.byref(buf)))
+        for s, b in zip(start, blobs):
+            C.memmove(C.addressof(buf.contents) + s, b, len(b))
+        foff = np.zeros(len(blobs) + 1, np.int32)
+        i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+        fn = self.L.lcrc_wave_stage_run
+        keep = fn.argtypes
+        fn.argtypes = [C.c_void_p, i64p, i64p, C.c_int, C.c_void_p, _i32p]
+        try:
+            self._check(fn(self.h, np.array(start, np.int64).reshape(-1), np.array([len(b) for b in blobs], np.int64).reshape(-1),
+                           len(blobs), None, foff))
+        finally:
+            fn.argtypes = keep
+        return foff
 
     def wave_energies_staged(self, blobs):
         """lcrc_wave_stage_buffer / lcrc_wave_stage_energies: mel-bank energies (before ln) of raw files, as a COPY of the

@@ -832,12 +832,16 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     if (!batch_given_) batch_frames_ = need_gpu && DecoderOn() && out == dfStrings ? 65536 : 32768;
     if (need_gpu) {
         if (!traps_enabled_) return Fail("The 'traps' module have to be enabled for generating posteriors\n");
-        // a list: three contexts per GPU -- while one's kernel runs, another copies its posteriors back (as long as the
-        // kernel itself at 186 outputs per frame) and the third's utterances are decoded (profiles/r03_cli_contexts.txt).
-        // From four GPUs on: two -- on one GPU the third is worth 0-2 %, while every context costs ~10 ms of start-up that
-        // the HIP runtime serialises (stream, 30 MB of pinned staging) and a waiting thread; 24 of them in front of a
-        // list that eight GPUs finish in a tenth of a second are a loss.
-        const int per_gpu = single_file ? 1 : std::max(1, n_gpus_) >= 4 ? 2 : 3;
+        // a list: three contexts per GPU -- while one's kernel runs, another reads its files and runs its front-end and
+        // the third's utterances are decoded (on the host, or by the decoder kernel behind its posterior kernel: that
+        // kernel's 2 ms are part of its context's chain).  Measured on the configs[3] list x 4, one GPU (profiles/
+        // r05_ab_runs.txt 3): 2 / 3 / 4 contexts -F 30.3 / 32.2 / 32.1, -F -D 24.9 / 31.4 / 29.3, -E -D 22.7 / 26.3 / 26.9 M
+        // frames/s -- with two contexts the device has no posterior kernel to run for 16 % of a -F -D list, with three for
+        // 0.9 %.  Every context costs ~8 ms of start-up that the HIP runtime serialises (stream, 30 MB of pinned staging):
+        // from four GPUs on a list gets three per GPU only if it is long enough to pay for them -- 128 KB of list file per
+        // GPU, some 4000 files, a tenth of a second of work per GPU --, otherwise two.
+        const bool worth_three = std::max(1, n_gpus_) < 4 || list_bytes_ / std::max(1, n_gpus_) >= (128 << 10);
+        const int per_gpu = single_file ? 1 : worth_three ? 3 : 2;
         if (!EnsureGpus(per_gpu)) {
             // -E was this function's own idea and the contexts did not take the front-end after all: the host front-end
             // serves the list as it did before the automatic choice existed
@@ -867,6 +871,23 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         if (!batch_given_ && !gpu_decoder_) batch_frames_ = 32768;
     }
     const bool dev_dec = need_gpu && DecoderOn() && out == dfStrings;
+    // With the decoder on the device a GPU's contexts run their posterior kernels one after the other, in the order their
+    // launches were queued (lcrc_set_launch_order), instead of sharing the device: two that share it end together -- and then
+    // decode together while the device has no posterior kernel to run.  Measured on the configs[3] list x 4, one GPU, three
+    // contexts (profiles/r05_ab_runs.txt 3): -F -D 28.5 -> 30.9, -E -D 23.3 -> 27.7 M frames/s.  Without the decoder the
+    // launches are half as long and their kernels store 744 B per frame into pinned HOST memory while they run: there two
+    // kernels sharing the device came out ahead (-F 31.3 against 29.4 in order) and those modes keep the shared device.
+    // PHNREC_LAUNCH_ORDER=0/1 overrides (experiments).
+    bool launch_order = dev_dec && !single_file;
+    if (const char *e = getenv("PHNREC_LAUNCH_ORDER")) launch_order = need_gpu && !single_file && atoi(e) != 0;
+    // Two contexts per GPU (a short list over four or more GPUs): the decoder kernel of a launch (2 ms, as long as its longest
+    // utterance) runs beside the NEXT launch's kernels of the same context instead of in front of them (lcrc_set_decoder_overlap:
+    // two sets of posterior / label buffers per context alternate) -- with two contexts the decoder's latency is otherwise
+    // what the device waits for (-F -D 25.6 -> 27.8, -E -D 22.7 -> 23.7); three contexts hide it by themselves and do better
+    // without (31.0 against 27.3, 27.7 against 25.6).
+    // PHNREC_DECODER_OVERLAP=0/1 overrides (experiments).
+    bool dec_overlap = dev_dec && !single_file && (int)gpus_.size() <= 2 * std::max(1, n_gpus_);
+    if (const char *e = getenv("PHNREC_DECODER_OVERLAP")) dec_overlap = dev_dec && !single_file && atoi(e) != 0;
     std::vector<std::string> phn_names;
     if (need_gpu) {
         // posterior writer path: both softening functions and the dump's byte order run in the posterior
@@ -879,6 +900,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         for (auto &g : gpus_)
             if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
                 return Fail(g->LastError() + "\n");
+        for (auto &g : gpus_) {
+            if (!g->SetDecoderOverlap(dec_overlap)) return Fail(g->LastError() + "\n");
+            g->SetLaunchOrder(launch_order);
+        }
         // Every context has a thread waiting for it.  Spinning (the default) is the fastest way to notice a finished
         // launch and costs a core each: fine for one GPU's three on 16 cores (sleeping waits lose 15 % with -F there,
         // profiles/r03_ab_runs.txt 14), not when the waiting threads of many GPUs would take more than half of the cores
@@ -1095,9 +1120,12 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             if (fatal.empty()) fatal = msg + "\n";
             cv_work.notify_all(); cv_feed.notify_all(); cv_idle.notify_all();
         };
-        auto device_labels = [&](int cnt) -> bool {
+        // labels of a launch the device decoded -> label text of its jobs.  With the decoder overlapped (lists) a launch's
+        // labels are fetched after the NEXT staged call has returned (`prev`), or after the last one.
+        auto device_labels = [&](const std::vector<Item *> &its, bool prev) -> bool {
+            const int cnt = (int)its.size();
             const lcrc_label *lab; const int *lfirst, *lcount; int nu = 0;
-            if (!tr.LastLabels(&lab, &lfirst, &lcount, &nu) || nu != cnt) return false;
+            if (!(prev ? tr.PrevLabels(&lab, &lfirst, &lcount, &nu) : tr.LastLabels(&lab, &lfirst, &lcount, &nu)) || nu != cnt) return false;
             pool_->ParallelFor(cnt, [&](int k) {
                 CpuTimer tm(stage3_us);
                 std::vector<Label> v((size_t)lcount[k]);
@@ -1105,8 +1133,20 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     const lcrc_label &lb = lab[lfirst[k] + i];
                     v[i] = Label{lb.start, lb.end, phn_names[lb.phn], lb.score};
                 }
-                EmitLabels(items[k]->job, mlf != nullptr, v);
+                EmitLabels(its[k]->job, mlf != nullptr, v);
             }, 16);
+            return true;
+        };
+        // the launch whose decoder is still running beside the next launch's kernels (lcrc_set_decoder_overlap)
+        std::vector<Item *> pending;
+        auto finish_pending = [&](bool prev) -> bool {
+            if (pending.empty()) return true;
+            if (!device_labels(pending, prev)) { abort_run("device decoder returned no labels"); return false; }
+            trace(g, "decoded");
+            std::lock_guard<std::mutex> l(mu);
+            for (Item *it : pending) it->slot.state = 3;
+            pending.clear();
+            drain();
             return true;
         };
         // A file longer than one launch (-b frames; take_launch hands it over alone).  Its posteriors are computed as
@@ -1188,9 +1228,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         while (take_launch(items)) {
             int cnt = (int)items.size();
             if (cnt == 1 && row_ranges && items[0]->job.frames > batch_frames_) {
-                if (!long_job(items[0])) return;
+                if (!finish_pending(false) || !long_job(items[0])) return;
                 continue;
             }
+            bool ran_staged = false;             // a staged call of this launch has switched the context's decoder sets
             off.assign(1, 0);
             for (int k = 0; k < cnt; k++) off.push_back(off.back() + items[k]->job.frames);
             trace(g, "took launch", cnt, off.back());
@@ -1266,6 +1307,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                         SlotHold hold(slots, tr);
                         trace(g, "slot");
                         if (!tr.StageRun(foff.data(), cnt)) { abort_run(tr.LastError()); return; }
+                        ran_staged = true;
                         trace(g, "run returned");
                         h_post = hp;
                     }
@@ -1273,6 +1315,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     SlotHold hold(slots, tr);
                     trace(g, "slot");
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                    ran_staged = true;
                     trace(g, "run returned");
                     h_post = tr.StagedPosteriors();
                 }
@@ -1288,6 +1331,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                 {
                     SlotHold hold(slots, tr);
                     if (!tr.StageRun(off.data(), cnt)) { abort_run(tr.LastError()); return; }
+                    ran_staged = true;
                 }
                 foff = off;
                 h_post = hp;
@@ -1295,8 +1339,13 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             if (first_launch.exchange(false))
                 stats_.first_launch_seconds = std::chrono::duration<double>(clock::now() - l0).count();
             if (off.back() > 0) kms[g] += tr.LastKernelMs();
-            if (dev_dec) {
-                if (off.back() > 0 && !device_labels(cnt)) { abort_run("device decoder returned no labels"); return; }
+            if (dev_dec && dec_overlap) {
+                // the launch before this one: its decoder ran beside this launch's kernels
+                if (!finish_pending(ran_staged)) return;
+                if (off.back() > 0) { pending = items; continue; }       // (this one's labels: after the next launch, or at the end)
+                pool_->ParallelFor(cnt, [&](int k) { EmitLabels(items[k]->job, mlf != nullptr, {}); });
+            } else if (dev_dec) {
+                if (off.back() > 0 && !device_labels(items, false)) { abort_run("device decoder returned no labels"); return; }
                 if (off.back() == 0) pool_->ParallelFor(cnt, [&](int k) { EmitLabels(items[k]->job, mlf != nullptr, {}); });
             } else {
                 pool_->ParallelFor(cnt, [&](int k) {
@@ -1311,6 +1360,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             for (Item *it : items) it->slot.state = 3;
             drain();
         }
+        if (!finish_pending(false)) return;      // the last launch's labels
         trace(g, "worker done");
     };
 
@@ -1428,7 +1478,8 @@ bool SpeechRec::ProcessFileList(DataFormat in, DataFormat out, const std::string
     if (!fl) return Fail("Can not open the file list: " + list + "\n");
     {
         struct stat st;
-        long_list_ = fstat(fileno(fl), &st) == 0 && st.st_size >= 4096;
+        list_bytes_ = fstat(fileno(fl), &st) == 0 ? (long long)st.st_size : 0;
+        long_list_ = list_bytes_ >= 4096;
     }
     FILE *mlf = nullptr;
     if (!mlf_path.empty()) {

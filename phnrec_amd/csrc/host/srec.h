@@ -164,6 +164,7 @@ private:
     WaveOptions wave_;
     int nbanks_ = 15, n_out_ = 0, n_gpus_ = 0, batch_frames_ = 32768, host_threads_ = 0;
     bool long_list_ = false;             // the list file has >= 4 KB (~100 entries): buffers are reserved ahead of the first launch
+    long long list_bytes_ = 0;           // size of the list file (how many contexts per GPU a list is worth)
     bool batch_given_ = false;           // -b: otherwise 32 768 frames per launch, 65 536 with the decoder on the GPU
     float wpenalty_ = -2.0f;
     bool wpenalty_set_ = false;

@@ -141,6 +141,20 @@ public:
     {
         return lcrc_last_labels(ctx_, labels, first, count, n_utts) == LCRC_OK;
     }
+    // the decoder of a staged call beside the next call's kernels; that call's labels: PrevLabels after the next call has
+    // returned, LastLabels after the last one (lcrc_set_decoder_overlap / lcrc_prev_labels)
+    bool SetDecoderOverlap(bool on)
+    {
+        if (lcrc_set_decoder_overlap(ctx_, on ? 1 : 0) == LCRC_OK) return true;
+        err_ = lcrc_last_error(ctx_);
+        return false;
+    }
+    // posterior kernels of this device's contexts one after the other, in queueing order (lcrc_set_launch_order)
+    void SetLaunchOrder(bool on) { if (ctx_) lcrc_set_launch_order(ctx_, on ? 1 : 0); }
+    bool PrevLabels(const lcrc_label **labels, const int **first, const int **count, int *n_utts)
+    {
+        return lcrc_prev_labels(ctx_, labels, first, count, n_utts) == LCRC_OK;
+    }
     // buffers for launches of up to this size, allocated ahead of the first one (lcrc_reserve)
     bool Reserve(int max_rows, int max_utts, long long max_wave_bytes)
     {

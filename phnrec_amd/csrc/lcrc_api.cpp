@@ -145,6 +145,32 @@ struct lcrc_ctx {
     size_t cap_label_rows = 0, cap_label_utts = 0;
     std::vector<int> label_first;
     int label_utts = 0;
+    // lcrc_set_decoder_overlap: the decoder kernel of a staged call runs on dec_stream, behind an event,
+    // BESIDE the next call's front-end and posterior kernels.  Everything a launch's decoder reads or writes exists twice and
+    // alternates: the context's own fields above (d_post, d_labels ... label_utts, with d_dec_off / ev_dec_done / dec_pending)
+    // are the set of the CURRENT call, `alt` is the set of the call before it.
+    bool launch_ordered = false;         // lcrc_set_launch_order: posterior kernels of this device's ordered contexts run one after the other
+    bool dec_overlap = false;
+    hipStream_t dec_stream = nullptr;
+    hipEvent_t ev_post = nullptr;        // this call's posterior kernels (and the decoder's copy of the offsets) are done
+    size_t d_post_cap = 0;               // rows d_post holds (cap_rows unless the sets have just been swapped)
+    int *d_dec_off = nullptr;            // the decoder's own copy of the utterance offsets (the next call overwrites d_off / d_foff)
+    size_t cap_dec_off = 0;
+    hipEvent_t ev_dec_done = nullptr;    // behind the decoder kernel of this set's last launch
+    bool dec_pending = false;            // ... recorded and not yet waited for
+    struct DecSet {
+        float *d_post = nullptr;
+        size_t d_post_cap = 0;
+        lcrc_label *d_labels = nullptr, *h_labels = nullptr;
+        int *d_count = nullptr, *h_count = nullptr;
+        size_t cap_label_rows = 0, cap_label_utts = 0;
+        std::vector<int> label_first;
+        int label_utts = 0;
+        int *d_dec_off = nullptr;
+        size_t cap_dec_off = 0;
+        hipEvent_t ev_dec_done = nullptr;
+        bool dec_pending = false;
+    } alt;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     std::string err;
     const char *variant = "none";
@@ -421,12 +447,13 @@ hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false)
 
 void free_frame_staging(lcrc_ctx *c)
 {
+    if (c->dec_stream) (void)hipStreamSynchronize(c->dec_stream);      // (a decoder of the last call may still read d_post)
     if (c->d_mel) (void)hipFree(c->d_mel);
     if (c->d_post) (void)hipFree(c->d_post);
     if (c->h_mel) (void)hipHostFree(c->h_mel);
     if (c->h_post) (void)hipHostFree(c->h_post);
     c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
-    c->cap_rows = c->cap_host_post = 0;
+    c->cap_rows = c->cap_host_post = c->d_post_cap = 0;
 }
 
 void free_offset_staging(lcrc_ctx *c)
@@ -540,7 +567,7 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
             (void)hipGetLastError();
             return fail(c, LCRC_E_NOMEM, "cannot allocate staging buffers for " + std::to_string(cap) + " frames");
         }
-        c->cap_rows = cap;
+        c->cap_rows = c->d_post_cap = cap;
     }
     if (utts + 1 > c->cap_utts) {
         const size_t cap = utts + utts / 4 + 64;
@@ -726,6 +753,40 @@ void ensure_split_scratch(lcrc_ctx *c)
 // d_post receives row_first's posteriors first.
 // lcrc_set_kernel_done_callback: an event behind the posterior kernels of the current call; reported by
 // report_kernel_done() once everything else of the call has been queued
+// lcrc_set_launch_order: one gate per device, shared by the process's contexts.  A launch's posterior kernels wait (on the
+// device: hipStreamWaitEvent) for the posterior kernels of the launch queued before it through the gate, and leave an event
+// for the next one.  The events come from a small ring the gate owns (a waiter refers to the record that was current when it
+// was queued; sixteen launches later nobody still waits for it).
+struct LaunchGate {
+    std::mutex mu;
+    hipEvent_t ring[16] = {};
+    int next = 0;
+    hipEvent_t last = nullptr;
+};
+LaunchGate g_gates[64];
+
+struct GateHold {
+    LaunchGate *g = nullptr;
+    hipStream_t s;
+    GateHold(lcrc_ctx *c, hipStream_t stream) : s(stream)
+    {
+        if (!c->launch_ordered || c->device < 0 || c->device >= 64) return;
+        g = &g_gates[c->device];
+        g->mu.lock();
+    }
+    hipError_t wait_for_previous() { return g && g->last ? hipStreamWaitEvent(s, g->last, 0) : hipSuccess; }
+    hipError_t leave_event()
+    {
+        if (!g) return hipSuccess;
+        hipEvent_t &e = g->ring[g->next];
+        if (!e) { const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming); if (rc != hipSuccess) return rc; }
+        const hipError_t rc = hipEventRecord(e, s);
+        if (rc == hipSuccess) { g->last = e; g->next = (g->next + 1) % 16; }
+        return rc;
+    }
+    ~GateHold() { if (g) g->mu.unlock(); }
+};
+
 int arm_kernel_done(lcrc_ctx *c, hipStream_t s)
 {
     if (!c->kdone_fn) return LCRC_OK;
@@ -743,7 +804,10 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
         if (dbg) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
         if (row_first != 0 || row_count != n_rows)
             return fail(c, LCRC_E_UNSUPPORTED, "row ranges exist for posteriors/system=LCRC only");
+        GateHold gate(c, s);
+        HIP_TRY(c, gate.wait_for_previous());
         int rc = launch_traps(c, d_mel, d_off, n_utts, n_rows, d_post, s);
+        HIP_TRY(c, gate.leave_event());
         if (rc == LCRC_OK) rc = arm_kernel_done(c, s);
         return rc;
     }
@@ -769,53 +833,132 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
     p.split_hint = c->split_hint;
     if (dbg) { p.dbg_in0 = dbg[0]; p.dbg_in1 = dbg[1]; p.dbg_p0 = dbg[2]; p.dbg_p1 = dbg[3]; p.dbg_g = dbg[4]; }
     timed = timed && c->timing;
+    GateHold gate(c, s);
+    HIP_TRY(c, gate.wait_for_previous());
     if (timed) HIP_TRY(c, hipEventRecord(c->ev0, s));
     HIP_TRY(c, lcrc_launch(p, s, nullptr));
     if (timed) { HIP_TRY(c, hipEventRecord(c->ev1, s)); c->timed = true; }
+    HIP_TRY(c, gate.leave_event());
     return arm_kernel_done(c, s);
 }
 
 // label and count buffers of the decoder on the device (one label slot per frame, one count per utterance)
+// Label buffers: pinned host memory mapped into the device -- the decoder kernel stores its labels and counts where the
+// host reads them (16 B per label, one per ~8 frames: posted writes over PCIe), so a launch queues NO copy command for
+// them.  As copy commands they stood in the device's copy queue, which every context shares in order, behind their 2 ms
+// decoder kernel -- and the next launch's upload of its files behind them (profiles/r05_ab_runs.txt 3).
+// d_labels / d_count are the device's view of h_labels / h_count.
 int ensure_labels(lcrc_ctx *c, size_t n_rows, size_t n_utts)
 {
     if (n_rows > c->cap_label_rows) {
         const size_t cap = n_rows + n_rows / 4 + 64;
-        if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
+        if (c->h_labels) (void)hipHostFree(c->h_labels);
         c->d_labels = c->h_labels = nullptr;
         c->cap_label_rows = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_labels, cap * sizeof(lcrc_label)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_labels, cap * sizeof(lcrc_label), kPinned));
+        HIP_TRY(c, pinned_alloc((void **)&c->h_labels, cap * sizeof(lcrc_label), true));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_labels, c->h_labels, 0));
         c->cap_label_rows = cap;
     }
     if (n_utts > c->cap_label_utts) {
         const size_t cap = n_utts + n_utts / 4 + 64;
-        if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
+        if (c->h_count) (void)hipHostFree(c->h_count);
         c->d_count = c->h_count = nullptr;
         c->cap_label_utts = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_count, cap * sizeof(int)));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_count, cap * sizeof(int), kPinned));
+        HIP_TRY(c, pinned_alloc((void **)&c->h_count, cap * sizeof(int), true));
+        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_count, c->h_count, 0));
         c->cap_label_utts = cap;
     }
     return LCRC_OK;
 }
 
-// Decoder behind the posterior kernel: labels and counts are copied to pinned memory on the same stream.
+// lcrc_set_decoder_overlap applies to the staged entry points of a context that decodes without reading posteriors back
+bool overlap_on(const lcrc_ctx *c) { return c->dec_overlap && c->dec_P > 0 && !c->readback; }
+
+void swap_decoder_sets(lcrc_ctx *c)
+{
+    std::swap(c->d_post, c->alt.d_post);
+    std::swap(c->d_post_cap, c->alt.d_post_cap);
+    std::swap(c->d_labels, c->alt.d_labels);
+    std::swap(c->h_labels, c->alt.h_labels);
+    std::swap(c->d_count, c->alt.d_count);
+    std::swap(c->h_count, c->alt.h_count);
+    std::swap(c->cap_label_rows, c->alt.cap_label_rows);
+    std::swap(c->cap_label_utts, c->alt.cap_label_utts);
+    c->label_first.swap(c->alt.label_first);
+    std::swap(c->label_utts, c->alt.label_utts);
+    std::swap(c->d_dec_off, c->alt.d_dec_off);
+    std::swap(c->cap_dec_off, c->alt.cap_dec_off);
+    std::swap(c->ev_dec_done, c->alt.ev_dec_done);
+    std::swap(c->dec_pending, c->alt.dec_pending);
+}
+
+// d_post for as many rows as the rest of the frame staging holds (the two sets' buffers grow one call apart)
+int ensure_post_rows(lcrc_ctx *c)
+{
+    if (c->d_post_cap >= c->cap_rows) return LCRC_OK;
+    if (c->d_post) (void)hipFree(c->d_post);
+    c->d_post = nullptr;
+    c->d_post_cap = 0;
+    if (dev_alloc((void **)&c->d_post, c->cap_rows * (size_t)c->nets[2].n_out * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, LCRC_E_NOMEM, "cannot allocate the second posterior buffer (lcrc_set_decoder_overlap)");
+    }
+    c->d_post_cap = c->cap_rows;
+    return LCRC_OK;
+}
+
+// Start of a staged call under lcrc_set_decoder_overlap: the call works on the set that the call BEFORE the last one used,
+// while the last call's decoder may still be reading and writing the other.
+int begin_overlapped_call(lcrc_ctx *c)
+{
+    if (!overlap_on(c)) return LCRC_OK;
+    swap_decoder_sets(c);
+    // what this call's kernels overwrite was read by the decoder two calls ago: behind it on the device, whether or not
+    // the caller has fetched those labels
+    if (c->dec_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dec_done, 0));
+    c->dec_pending = false;
+    c->label_utts = 0;
+    return c->cap_rows > 0 ? ensure_post_rows(c) : LCRC_OK;
+}
+
+// Decoder behind the posterior kernel (it stores labels and counts in the pinned buffers itself).  On the launch stream `s`;
+// `staged` calls of a context under lcrc_set_decoder_overlap queue it on the decoder stream instead, behind an event on `s`,
+// and return without waiting for it (lcrc_last_labels / lcrc_prev_labels wait).
 // h_first: host copy of the utterance offsets (first label slot of each utterance).
 int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, int n_rows, const float *d_post,
-                 hipStream_t s)
+                 hipStream_t s, bool staged = false)
 {
     c->label_utts = 0;
     if (c->dec_P <= 0 || n_rows <= 0) return LCRC_OK;
     if (c->out_be) return fail(c, LCRC_E_ARG, "the decoder needs posteriors in host byte order (lcrc_output_configure big_endian=0)");
     { const int rc = ensure_labels(c, (size_t)n_rows, (size_t)n_utts); if (rc) return rc; }
+    const bool overlap = staged && overlap_on(c);
+    hipStream_t ds = s;
+    if (overlap) {
+        if ((size_t)n_utts + 1 > c->cap_dec_off) {
+            const size_t cap = (size_t)n_utts + n_utts / 4 + 64;
+            if (c->d_dec_off) (void)hipFree(c->d_dec_off);
+            c->d_dec_off = nullptr;
+            c->cap_dec_off = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_dec_off, cap * sizeof(int)));
+            c->cap_dec_off = cap;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_dec_off, d_off, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->ev_post, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->dec_stream, c->ev_post, 0));
+        d_off = c->d_dec_off;
+        ds = c->dec_stream;
+    }
     PhnDecParams p;
     memset(&p, 0, sizeof p);
     p.logpost = d_post; p.off = d_off; p.n_utts = n_utts; p.cols = c->nets[2].n_out;
     p.P = c->dec_P; p.S = c->dec_S; p.prune = c->dec_prune; p.wpen = c->dec_wpen;
     p.labels = c->d_labels; p.count = c->d_count;
-    HIP_TRY(c, phndec_launch(p, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_labels, c->d_labels, (size_t)n_rows * sizeof(lcrc_label), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_count, c->d_count, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, phndec_launch(p, ds));          // (labels and counts: stored by the kernel straight into the pinned buffers)
+    if (overlap) {
+        HIP_TRY(c, hipEventRecord(c->ev_dec_done, ds));
+        c->dec_pending = true;
+    }
     c->label_first.assign(h_first, h_first + n_utts);
     c->label_utts = n_utts;
     return LCRC_OK;
@@ -1313,12 +1456,22 @@ void lcrc_destroy(lcrc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->dec_stream) (void)hipStreamSynchronize(c->dec_stream);
     for (void *p : c->allocs) (void)hipFree(p);
     free_frame_staging(c);
+    if (c->alt.d_post) (void)hipFree(c->alt.d_post);
+    if (c->alt.h_labels) (void)hipHostFree(c->alt.h_labels);
+    if (c->alt.h_count) (void)hipHostFree(c->alt.h_count);
+    if (c->d_dec_off) (void)hipFree(c->d_dec_off);
+    if (c->alt.d_dec_off) (void)hipFree(c->alt.d_dec_off);
+    if (c->ev_post) (void)hipEventDestroy(c->ev_post);
+    if (c->ev_dec_done) (void)hipEventDestroy(c->ev_dec_done);
+    if (c->alt.ev_dec_done) (void)hipEventDestroy(c->alt.ev_dec_done);
+    if (c->dec_stream) (void)hipStreamDestroy(c->dec_stream);
     free_offset_staging(c);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
-    if (c->d_labels) { (void)hipFree(c->d_labels); (void)hipHostFree(c->h_labels); }
-    if (c->d_count) { (void)hipFree(c->d_count); (void)hipHostFree(c->h_count); }
+    if (c->h_labels) (void)hipHostFree(c->h_labels);
+    if (c->h_count) (void)hipHostFree(c->h_count);
     if (c->d_feat) (void)hipFree(c->d_feat);
     if (c->d_minp) (void)hipFree(c->d_minp);
     if (c->d_hamming) (void)hipFree(c->d_hamming);
@@ -1418,9 +1571,10 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
     for (int u = 0; u < n_utts; u++)
         if (off[u + 1] < off[u]) return fail(c, LCRC_E_ARG, "lcrc_stage_run: offsets must be non-decreasing");
     const int n = off[n_utts];
-    if (n == 0) return LCRC_OK;
-    if ((size_t)n > c->cap_rows) return fail(c, LCRC_E_ARG, "lcrc_stage_run: more rows than lcrc_stage_buffers reserved");
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc0 = begin_overlapped_call(c); if (rc0) return rc0; }       // (every staged call, empty ones too: the sets alternate per call)
+    if (n == 0) { c->label_utts = 0; return LCRC_OK; }
+    if ((size_t)n > c->cap_rows) return fail(c, LCRC_E_ARG, "lcrc_stage_run: more rows than lcrc_stage_buffers reserved");
     const size_t nb = c->nbanks, O = c->nets[2].n_out;
     // only the offsets still have to be staged; the frame buffers are the pinned ones already
     float *keep_mel = c->h_mel, *keep_post = c->h_post, *dm = c->d_mel, *dp = c->d_post;
@@ -1447,7 +1601,7 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
     if (rc) return rc;
     rc = launch(c, mel_in, c->d_off, n_utts, n, out_dev, c->stream, nullptr);
     if (rc) return rc;
-    rc = decode_after(c, c->d_off, c->h_off, n_utts, n, c->d_post, c->stream);
+    rc = decode_after(c, c->d_off, c->h_off, n_utts, n, c->d_post, c->stream, true);
     if (rc) return rc;
     if (!direct && (c->readback || c->dec_P <= 0)) {
         rc = ensure_host_post(c);                // (lcrc_stage_buffers allocated it: a no-op)
@@ -1703,7 +1857,7 @@ int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *b
 }
 
 // the part of the waveform -> posteriors entries behind the front-end
-static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post, SlowTrace *st = nullptr)
+static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post, SlowTrace *st = nullptr, bool staged = false)
 {
     const bool copy_post = c->readback || c->dec_P <= 0;
     if (c->fe.sent_mean_norm) {
@@ -1725,7 +1879,7 @@ static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post, SlowTrace
     rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, out_dev, c->stream, nullptr);
     if (rc) return rc;
     if (st) st->mark("kernels queued");
-    rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream);
+    rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream, staged);
     if (rc) return rc;
     const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
     if (copy_post && direct) {
@@ -1792,6 +1946,13 @@ int lcrc_reserve(lcrc_ctx *c, int max_rows, int max_utts, long long max_wave_byt
     if (c->dec_P > 0) {
         rc = ensure_labels(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
         if (rc) return rc;
+        if (overlap_on(c)) {                     // the second set: posterior buffer and labels
+            swap_decoder_sets(c);
+            rc = ensure_post_rows(c);
+            if (!rc) rc = ensure_labels(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
+            swap_decoder_sets(c);
+            if (rc) return rc;
+        }
     }
     if (max_wave_bytes > 0) {
         rc = ensure_wave_bytes(c, max_wave_bytes);
@@ -1868,10 +2029,13 @@ int lcrc_wave_stage_run(lcrc_ctx *c, const long long *start, const long long *n_
     if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: beyond the capacity lcrc_wave_stage_buffer reserved");
     int rows = 0;
     SlowTrace st;
-    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, false, &st);
+    int rc = post ? LCRC_OK : begin_overlapped_call(c);
+    if (rc) return rc;
+    rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, false, &st);
     if (rc || rows == 0) { c->label_utts = 0; return rc; }
+    if (!post && overlap_on(c)) { rc = ensure_post_rows(c); if (rc) return rc; }      // (the staging may just have grown)
     st.mark("front-end queued");
-    return wave_finish(c, n_utts, rows, post, &st);
+    return wave_finish(c, n_utts, rows, post, &st, post == nullptr);
 }
 
 int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty)
@@ -1893,9 +2057,52 @@ int lcrc_set_posterior_readback(lcrc_ctx *c, int enabled)
     return LCRC_OK;
 }
 
+int lcrc_set_launch_order(lcrc_ctx *c, int ordered)
+{
+    if (!c) return LCRC_E_ARG;
+    c->launch_ordered = ordered != 0;
+    return LCRC_OK;
+}
+
+int lcrc_set_decoder_overlap(lcrc_ctx *c, int enabled)
+{
+    if (!c) return LCRC_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->dec_stream) HIP_TRY(c, hipStreamSynchronize(c->dec_stream));
+    c->dec_pending = c->alt.dec_pending = false;
+    if (enabled && !c->dec_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->dec_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->alt.ev_dec_done, hipEventDisableTiming));
+    }
+    c->dec_overlap = enabled != 0;
+    return LCRC_OK;
+}
+
+int lcrc_prev_labels(lcrc_ctx *c, const lcrc_label **labels, const int **first, const int **count, int *n_utts)
+{
+    if (!c || !labels || !first || !count || !n_utts) return LCRC_E_ARG;
+    if (c->alt.dec_pending) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, wait_event(c, c->alt.ev_dec_done));
+        c->alt.dec_pending = false;
+    }
+    *labels = c->alt.h_labels;
+    *first = c->alt.label_first.data();
+    *count = c->alt.h_count;
+    *n_utts = c->alt.label_utts;
+    return LCRC_OK;
+}
+
 int lcrc_last_labels(lcrc_ctx *c, const lcrc_label **labels, const int **first, const int **count, int *n_utts)
 {
     if (!c || !labels || !first || !count || !n_utts) return LCRC_E_ARG;
+    if (c->dec_pending) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, wait_event(c, c->ev_dec_done));
+        c->dec_pending = false;
+    }
     *labels = c->h_labels;
     *first = c->label_first.data();
     *count = c->h_count;

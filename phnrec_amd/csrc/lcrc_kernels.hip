@@ -136,11 +136,6 @@ __global__ __launch_bounds__(NW * 64) void lcrc_fused_kernel(const LcrcParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = p.nbanks;
-    // Issue priority above the default: with -D the decoder kernel's waves (phndec_kernels.hip: one per SIMD of the CUs they
-    // land on, ~250 dependent VALU instructions per frame for ~2 ms) sit beside this kernel's waves, and a SIMD issues one
-    // VALU-class instruction -- MFMA or not -- per cycle: at equal priority the arbiter gives the decoder wave every
-    // other turn.  The decoder fills the turns these waves leave (waits for weights, barriers).  No effect among this kernel's own waves.
-    __builtin_amdgcn_s_setprio(2);
     // k-groups per frame tile of the operand images.  Run-time shapes use their CLASS's counts as well (groups past the
     // net's own hold zeros): image addresses are then compile-time offsets in the hidden loops (mlp_dev.h RingLoop);
     // only the staging of the normalisation vectors knows the net's own sizes (nkq1_net, nkqm_net).

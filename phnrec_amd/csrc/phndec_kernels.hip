@@ -75,6 +75,9 @@ __global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecP
     //  readlane costs a v_readfirstlane and its hazard no-ops)
     const int u = blockIdx.x * kDecWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     if (u >= p.n_utts) return;                                  // wave-uniform
+#ifdef PHNDEC_PRIO
+    __builtin_amdgcn_s_setprio(PHNDEC_PRIO);
+#endif
     const int a0 = p.off[u], T = p.off[u + 1] - a0;
     const int P = p.P, H = p.prune + 1;
     const float lh = -0.69314718055994530941723212145818f;      // ln 0.5, both transitions (phndec.cpp:9,14-15)
@@ -200,32 +203,43 @@ __global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecP
         }
     }
 
-    // Done(): the winner that entered the loop last, traced back through the history
-    int offs = H - 1, end = T, phn = lane_get(pv[0], 0), ntail = 0;
-    while (offs > 0 && phn != -1) {
-        const int q = phys(offs);
-        const int len = lane_get(hlen, q), start = end - len;
-        const float al = lane_get(halpha, q);
-        const int pphn = lane_get(hphn, q);
-        if (len <= 0) break;
-        offs -= len;
-        const float like = offs > 0 ? al - lane_get(halpha, phys(offs)) : al - prev_alpha;
-        if (lane == 0) {
-            lcrc_label &l = out[nlab + ntail];
-            l.start = start; l.end = end; l.phn = phn; l.score = like;
+    // Done(): the winner that entered the loop last, traced back through the history.  The walk produces the tail newest
+    // first; `labels` may be pinned HOST memory (the launch code lets the kernel store its results where the host reads them:
+    // no copy commands), which is written once and never read here -- so the walk runs twice, first to count the tail's
+    // labels, then to store each one at its final place.
+    const int tail_phn = lane_get(pv[0], 0);
+    int ntail = 0;
+    {
+        int offs = H - 1, phn = tail_phn;
+        while (offs > 0 && phn != -1) {
+            const int q = phys(offs);
+            const int len = lane_get(hlen, q);
+            if (len <= 0) break;
+            phn = lane_get(hphn, q);
+            offs -= len;
+            ntail++;
         }
-        ntail++;
-        end = start;
-        phn = pphn;
     }
-    if (lane == 0) {
-        for (int i = 0, j = ntail - 1; i < j; i++, j--) {       // the tail was produced newest first
-            const lcrc_label tmp = out[nlab + i];
-            out[nlab + i] = out[nlab + j];
-            out[nlab + j] = tmp;
+    {
+        int offs = H - 1, end = T, phn = tail_phn, k = 0;
+        while (offs > 0 && phn != -1) {
+            const int q = phys(offs);
+            const int len = lane_get(hlen, q), start = end - len;
+            const float al = lane_get(halpha, q);
+            const int pphn = lane_get(hphn, q);
+            if (len <= 0) break;
+            offs -= len;
+            const float like = offs > 0 ? al - lane_get(halpha, phys(offs)) : al - prev_alpha;
+            if (lane == 0) {
+                lcrc_label &l = out[nlab + ntail - 1 - k];
+                l.start = start; l.end = end; l.phn = phn; l.score = like;
+            }
+            k++;
+            end = start;
+            phn = pphn;
         }
-        p.count[u] = nlab + ntail;
     }
+    if (lane == 0) p.count[u] = nlab + ntail;
 }
 
 hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libphnrec_lcrc.so does not export %s" % name
     assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with include/lcrc.h"
-    assert L.lcrc_abi_version() == 3      # include/lcrc.h LCRC_ABI_VERSION
+    assert L.lcrc_abi_version() == 4      # include/lcrc.h LCRC_ABI_VERSION
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (lcrc_[a-z_0-9]+)", out))
     assert set(declared) <= exported

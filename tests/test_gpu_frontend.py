@@ -307,3 +307,72 @@ def test_reserve_allocates_ahead_and_changes_nothing(capi):
     ctx.reserve(4096, 8)
     b = ctx.posteriors(mel)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_decoder_overlapped_with_the_next_call_gives_the_same_labels(capi):
+    """lcrc_set_decoder_overlap: staged calls return when their posterior kernels are done, the decoder of call k runs
+    beside the kernels of call k + 1 on the context's second stream and second set of buffers; prev_labels() after call
+    k + 1 (last_labels() after the last call) returns what last_labels() returns right after call k without the overlap --
+    for the waveform entry (lcrc_wave_stage_run) and the frame entry (lcrc_stage_run), across calls of growing and
+    shrinking size (buffers reallocated between the two sets), empty calls, and a switch back to synchronous decoding."""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()       # 7.5 s of speech (lin16, 8 kHz): real label sequences
+    rng = np.random.default_rng(11)
+
+    def blobs_of(sizes):                                          # slices of the utterance, `sizes` in samples
+        out = []
+        for n in sizes:
+            o = 2 * int(rng.integers(0, len(raw) // 2 - n + 1))
+            out.append(raw[o:o + 2 * n])
+        return out
+
+    calls = [blobs_of([4000, 9000, 200]), blobs_of([30000]), blobs_of([100, 100]), blobs_of([]), blobs_of([59000, 8000, 24000, 500]),
+             blobs_of([8000]), blobs_of([59900, 4000] + [16000] * 6), blobs_of([2000, 2000, 2000])]
+
+    def make():
+        c = _ctx(capi, CZ)
+        c.configure_output(("log",))
+        c.configure_decoder(45, 3, 40, -4.6875)
+        c.set_posterior_readback(False)
+        return c
+
+    ref = make()
+    want = []
+    for b in calls:
+        ref.wave_decode_staged(b)
+        want.append(ref.last_labels())
+    assert sum(len(u) for w in want for u in w) > 200           # (real label sequences, not empty lists)
+    ctx = make()
+    ctx.set_decoder_overlap(True)
+    got = []
+    for k, b in enumerate(calls):
+        ctx.wave_decode_staged(b)
+        if k > 0:
+            got.append(ctx.prev_labels())
+    got.append(ctx.last_labels())
+    assert got == want
+    # once more on the same context (the sets keep alternating), fetching nothing in between except at the end of each pair
+    for k in range(0, len(calls) - 1, 2):
+        ctx.wave_decode_staged(calls[k])
+        ctx.wave_decode_staged(calls[k + 1])
+        assert ctx.prev_labels() == want[k] and ctx.last_labels() == want[k + 1]
+    # the frame entry (lcrc_stage_run): features in, labels out
+    mels, offs, want2 = [], [], []
+    for k, lens in enumerate(([300, 0, 41, 900], [5000], [40, 40, 40], [2500, 1])):
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        mels.append(np.tile(read_htk(os.path.join(GOLD, CZ, "test.mel")), (8, 1))[:int(off[-1])] - 11.0)
+        offs.append(off)
+        ref.posteriors_staged(mels[-1], off)
+        want2.append(ref.last_labels())
+    got2 = []
+    for k in range(len(mels)):
+        ctx.posteriors_staged(mels[k], offs[k])
+        if k > 0:
+            got2.append(ctx.prev_labels())
+    got2.append(ctx.last_labels())
+    assert got2 == want2
+    # back to synchronous decoding on the same context
+    ctx.set_decoder_overlap(False)
+    ctx.wave_decode_staged(calls[0])
+    assert ctx.last_labels() == want[0]
+    ref.close()
+    ctx.close()
