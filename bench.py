@@ -523,9 +523,10 @@ def sharded_list_leg(n_gpus, dmap, n_files):
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         lst, names, frames = synthetic_list(td, n_files)
         out["frames"] = frames
-        # (from two GPUs on the CLI called without flags computes the energies on the GPU by itself -- the same output bytes:
-        #  `host_frontend` then IS the -E road; PHNREC_NO_AUTO_E=1 would keep the pure host front-end)
-        out["host_frontend_takes_E_road"] = n_gpus >= 2
+        # (from two GPUs on the CLI called without flags takes the GPU front-end by itself -- -F where its ln() is this host's
+        #  libm's own sequence, else -E; the same output bytes either way: `host_frontend` then IS that road ("mode" says
+        #  which); PHNREC_NO_AUTO_E=1 would keep the pure host front-end)
+        out["host_frontend_takes_gpu_road"] = n_gpus >= 2
         # (and from four GPUs on a list that ends in labels decodes on the GPUs by itself -- bit-identical labels, the
         #  Viterbi off the host's cores: every mode below is then `... -D`; PHNREC_NO_AUTO_D=1 would keep the host decoder)
         out["every_mode_decodes_on_the_gpu"] = n_gpus >= 4
@@ -581,8 +582,8 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             except Exception as e:
                 weak[key] = {"error": repr(e)}
         if n_gpus == 1:
-            # What `phnrec -g 8 -l ... -m ...`, called as the reference is called (no flags), selects by itself -- -E and,
-            # from four GPUs on, -D; two contexts per GPU; sleeping waits -- with all eight logical GPUs mapped onto this
+            # What `phnrec -g 8 -l ... -m ...`, called as the reference is called (no flags), selects by itself -- the GPU
+            # front-end and, from four GPUs on, -D; sleeping waits -- with all eight logical GPUs mapped onto this
             # box's one device: the per-GPU rate is that of ONE GPU behind sixteen contexts, the host CPU seconds are
             # those the auto-selected path costs per frame.
             try:
@@ -619,6 +620,8 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             # -E's features are the host front-end's bit for bit: so is its MLF
             out["mlf_E_equals_host_frontend"] = open(mlfs["gpu_energies_E"]).read() == open(mlfs["host_frontend"]).read()
             out["mlf_E_D_equals_host_frontend"] = open(mlfs["gpu_energies_decoder_E_D"]).read() == open(mlfs["host_frontend"]).read()
+            # ... and so are -F's, with ln() taken as this host's libm takes it (lcrc_frontend_set_ln)
+            out["mlf_F_equals_host_frontend"] = a == open(mlfs["host_frontend"]).read()
         except Exception:
             pass
         # ---- what the host alone can do on this list ----

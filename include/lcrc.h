@@ -34,7 +34,7 @@ extern "C" {
  *    scaled (any finite weights); lcrc_debug_fail_alloc needs LCRC_FAULT_INJECTION=1 in the environment */
 /* 3: additions only (every version-2 caller links and behaves as before): lcrc_device_pci_bus_id,
  *    lcrc_set_kernel_done_callback, lcrc_wave_stage_energies, lcrc_reserve */
-/* 4: additions only: lcrc_set_decoder_overlap, lcrc_prev_labels, lcrc_set_launch_order */
+/* 4: additions only: lcrc_set_decoder_overlap, lcrc_prev_labels, lcrc_set_launch_order, lcrc_frontend_set_ln, lcrc_device_ln */
 #define LCRC_ABI_VERSION 4
 
 enum {
@@ -191,6 +191,19 @@ typedef struct lcrc_frontend {
 } lcrc_frontend;
 
 int lcrc_frontend_configure(lcrc_ctx *ctx, const lcrc_frontend *cfg);
+/* How the front-end takes ln() (sLn, dspc.h:155-160: x > 0 ? logf(x) : 0).  The reference's bits are those of the HOST
+ * libm's logf.  glibc's logf (2.28 and later) is a fixed sequence of IEEE double operations, in one of two builds that glibc
+ * picks at load time (with fused multiply-adds / without): LCRC_LN_GLIBC_FMA and LCRC_LN_GLIBC run that sequence on the
+ * device and give that libm's result for every input -- a caller that has checked which of the two its libm matches (this
+ * repository's CLI does: host/veclog.cpp, 300 000 values at start-up; `phnrec --selftest-gpu-ln` compares every positive
+ * float) gets features equal to a host front-end's bit for bit.  LCRC_LN_DOUBLE (default): log() in double rounded once --
+ * independent of any libm, equal to glibc's result except in the rare cases where glibc's own 0.818-ulp error shows.
+ * Holds for every later waveform call on the context (not for lcrc_wave_stage_energies, which stops in front of ln). */
+enum { LCRC_LN_DOUBLE = 0, LCRC_LN_GLIBC_FMA = 1, LCRC_LN_GLIBC = 2 };
+int lcrc_frontend_set_ln(lcrc_ctx *ctx, int form);
+/* y[i] = the front-end's ln() of x[i] in the form named (LCRC_LN_*), computed on device `device_id` (host arrays in and
+ * out; no context needed: for self-checks and tests) */
+int lcrc_device_ln(int device_id, int form, const float *x, float *y, long long n);
 /* Order of the column sums of the sentence mean normalisation (srec.cpp:1500-1511, matrix.h:2101-2116).
  * 1 (default): the reference's sequential f32 sums in frame order, bit for bit (a dependent add chain per
  * utterance and bank: ~13 ns per frame of the longest utterance of the call; utterances run side by side).

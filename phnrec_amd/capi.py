@@ -18,7 +18,7 @@ SYMBOLS = [
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
-    "lcrc_frontend_configure", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
+    "lcrc_frontend_configure", "lcrc_frontend_set_ln", "lcrc_device_ln", "lcrc_set_mean_order", "lcrc_frontend_frames", "lcrc_wave_to_mel", "lcrc_wave_to_posteriors",
     "lcrc_reserve", "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels", "lcrc_set_decoder_overlap", "lcrc_prev_labels", "lcrc_set_launch_order",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
@@ -137,6 +137,7 @@ def load():
     L.lcrc_prev_labels.argtypes = L.lcrc_last_labels.argtypes
     L.lcrc_set_decoder_overlap.argtypes = [vp, C.c_int]
     L.lcrc_set_launch_order.argtypes = [vp, C.c_int]
+    L.lcrc_frontend_set_ln.argtypes = [vp, C.c_int]
     L.lcrc_frontend_frames.argtypes = [vp, C.c_longlong]
     _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
@@ -158,6 +159,19 @@ def load():
     L.lcrc_posteriors_rows.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
     _lib = L
     return L
+
+
+def device_ln(x, form, device=0):
+    """the GPU front-end's ln() of an array in the form named (0: double log rounded once, 1 / 2: glibc's logf sequence with /
+    without fused multiply-adds), computed on the device (lcrc_device_ln)"""
+    L = load()
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    y = np.empty_like(x)
+    L.lcrc_device_ln.argtypes = [C.c_int, C.c_int, _f32p, _f32p, C.c_longlong]
+    rc = L.lcrc_device_ln(int(device), int(form), x, y, x.size)
+    if rc != 0:
+        raise LcrcError(rc, L.lcrc_last_error(None).decode())
+    return y
 
 
 def model_info(model_dir, nbanks):
@@ -298,6 +312,10 @@ class Lcrc:
         fe = Frontend({"lin16": 1, "alaw": 2}[wave_format], sample_freq, vector_size, vector_step, nbanks_full,
                       lower_freq, higher_freq, preem_coef, scale, dc_shift, int(z_mean_source), int(sent_mean_norm))
         self._check(self.L.lcrc_frontend_configure(self.h, C.byref(fe)))
+
+    def set_frontend_ln(self, form):
+        """0: log() in double rounded once; 1 / 2: glibc's logf sequence with / without fused multiply-adds (lcrc_frontend_set_ln)"""
+        self._check(self.L.lcrc_frontend_set_ln(self.h, int(form)))
 
     def set_mean_order(self, sequential):
         """True (default): the reference's sequential column sums; False: fixed-shape tree sums (opt-in)"""

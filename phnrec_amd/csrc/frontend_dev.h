@@ -22,7 +22,11 @@ struct FrontendParams {
     float dc_shift, scale, preem_coef;
     int z_mean_source;
     int raw_energies;             // 1: store the mel-bank energies themselves (the caller takes the logarithm: lcrc_wave_stage_energies)
+    int ln_form;                  // LCRC_LN_*: how ln() is evaluated (lcrc_frontend_set_ln)
 };
+
+// the front-end's ln() (dspc.h:155-160: x > 0 ? logf(x) : 0) of n device values, in place; form = LCRC_LN_*
+hipError_t frontend_ln_launch(float *x, size_t n, int form, hipStream_t stream);
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
 // host (pinned, mapped) -> device by a kernel instead of a copy command; both 16-byte aligned, `bytes` rounded up to 16

@@ -1,8 +1,9 @@
 // frontend_kernels.hip -- "next" row f1 of SURVEY.md 8: the mel-bank front-end on the GPU.
 //
 // raw samples -> log mel-bank energies, one wave per 10 ms frame, following the reference's
-// arithmetic operation by operation; ln() is evaluated in double and rounded once (glibc's logf is
-// correctly rounded in all but rare cases), so dumps agree with the reference's to the last bit or one ulp:
+// arithmetic operation by operation; ln() is the host libm's own sequence of double operations when the caller names it
+// (lcrc_frontend_set_ln: the dumps then agree with the reference's to the last bit), else log() in double rounded once
+// (last bit or one ulp):
 //   waveform decode   srec.cpp:709-791, alaw.cpp      lin16 / A-law, dc_shift, scale
 //   framing           srec.cpp:945, melbanks.cpp:151   frame t = samples [t*step, t*step + vs)
 //   pre-processing    dspc.h:64-84                     z_mean_source, pre-emphasis (both off in shipped configs)
@@ -30,6 +31,76 @@ __device__ __forceinline__ float alaw_to_linear(unsigned b)
     if (seg == 0) mant += 8;
     else mant = (mant + 0x108) << (seg - 1);
     return (float)((a & 0x80u) ? mant : -mant);
+}
+
+// ---- ln() ------------------------------------------------------------------------------------------------------
+// The reference takes ln() with libm's logf (sLn, dspc.h:155-160), so "the reference's bits" means the bits of the HOST's
+// logf.  glibc's (2.28 and later; sysdeps/ieee754/flt-32/e_logf.c) is a fixed sequence of IEEE double operations -- a
+// 16-entry table (1/c, ln c), a cubic in double, ONE rounding to float -- and exists in two builds that glibc selects
+// between at load time: with fused multiply-adds and without.  Both sequences are restated here in the device's IEEE
+// double arithmetic (the table and coefficients are glibc's __logf_data, as in host/veclog.cpp); the caller says which
+// one its libm matches (lcrc_frontend_set_ln; the CLI finds out by checking 300 000 values, host/veclog.cpp) and gets that
+// libm's bits.  Form 0 -- log() in double, rounded once -- stays the default of the C entry points: correctly rounded, i.e.
+// glibc's result except where glibc's own 0.818-ulp error shows (about one value in 10^5).
+__device__ const double kLnInvC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0,  0x1.3c995b0b80385p+0,
+                                       0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0,
+                                       0x1.0953f419900a7p+0, 0x1p+0,               0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+                                       0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+__device__ const double kLnLogC[16] = {-0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3,
+                                       -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,   -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4,
+                                       -0x1.252f438e10c1ep-5, 0x0p+0,                0x1.aa5aa5df25984p-5,  0x1.c5e53aa362eb4p-4,
+                                       0x1.526e57720db08p-3,  0x1.bc2860d22477p-3,   0x1.1058bc8a07ee1p-2,  0x1.4043057b6ee09p-2};
+
+template <bool FMA>
+__device__ __forceinline__ float ln_glibc(float x)
+{
+    if (!(x > 0.0f)) return 0.0f;                           // sLn's guard (zero, negative, NaN)
+    unsigned ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;                     // e_logf.c: "fix sign of zero with downward rounding when x == 1"
+    if (ix == 0x7f800000u) return x;                        // log(inf) == inf
+    if (ix < 0x00800000u) ix = __float_as_uint(x * 0x1p23f) - (23u << 23);      // subnormal: normalised first
+    const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    const unsigned tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u), k = (int)tmp >> 23;
+    const double z = (double)__uint_as_float(ix - (tmp & 0xff800000u));
+    const double invc = kLnInvC[i], logc = kLnLogC[i];
+    double r, y0, y;
+    if (FMA) {
+        r = __builtin_fma(z, invc, -1.0);
+        y0 = __builtin_fma((double)k, Ln2, logc);
+        const double r2 = r * r;
+        y = __builtin_fma(A1, r, A2);
+        y = __builtin_fma(A0, r2, y);
+        y = __builtin_fma(y, r2, y0 + r);
+    } else {                                                // (compiled with -ffp-contract=off: nothing below is fused)
+        r = z * invc - 1.0;
+        y0 = logc + (double)k * Ln2;
+        const double r2 = r * r;
+        y = A1 * r + A2;
+        y = A0 * r2 + y;
+        y = y * r2 + (y0 + r);
+    }
+    return (float)y;
+}
+
+__device__ __forceinline__ float frontend_ln(float e, int form)
+{
+    if (form == 1) return ln_glibc<true>(e);
+    if (form == 2) return ln_glibc<false>(e);
+    return e > 0.0f ? (float)log((double)e) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void frontend_ln_kernel(float *x, size_t n, int form)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = frontend_ln(x[i], form);
+}
+
+hipError_t frontend_ln_launch(float *x, size_t n, int form, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)std::min<size_t>(4096, (n + 255) / 256);
+    frontend_ln_kernel<<<blocks, 256, 0, stream>>>(x, n, form);
+    return hipGetLastError();
 }
 
 template <int FFT>
@@ -237,9 +308,9 @@ __global__ __launch_bounds__(256) void melbank_kernel(const FrontendParams p)
             for (int k = 0; k < 4; k++) e += cc[k] * pp[k];
         }
         for (; i < c1; i++) e += coef_s[i] * pf[i];
-        // ln in double, rounded once: glibc's logf is correctly rounded in all but rare cases, the
-        // device's f32 logf is only good to a few ulp
-        p.mel[(size_t)ofr * p.nbanks + b] = p.raw_energies ? e : (e > 0.0f ? (float)log((double)e) : 0.0f);
+        // ln: the host libm's sequence when the caller has named it, else in double, rounded once (the device's f32 logf is
+        // only good to a few ulp)
+        p.mel[(size_t)ofr * p.nbanks + b] = p.raw_energies ? e : frontend_ln(e, p.ln_form);
     }
 }
 

@@ -6,7 +6,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <cstdint>
 #include <cstring>
+#include <vector>
 #include <string>
 
 #include "srec.h"
@@ -101,6 +104,30 @@ int main(int argc, char **argv)
         // the host front-end's ln() over every non-negative float against this process's libm (veclog.cpp)
         const long long bad = LnSelfTest(0);
         printf("ln(): %s; %lld of 2^31 non-negative values (and a stride of the negative ones) differ from logf()\n", LnForm(), bad);
+        return bad == 0 ? 0 : 1;
+    }
+    if (argc >= 2 && strcmp(argv[1], "--selftest-gpu-ln") == 0) {
+        // the GPU front-end's ln() (lcrc_frontend_set_ln, in the form this host's libm matches) over every positive float --
+        // and a stride of the other bit patterns -- against this process's logf(): what makes -F's features the host
+        // front-end's bit for bit.  phnrec --selftest-gpu-ln [device]
+        const int form = LibmLogfForm(), dev = argc > 2 ? atoi(argv[2]) : 0;
+        if (form == 0) { printf("this libm's logf matches neither of glibc's two sequences: the GPU front-end uses log() in double\n"); return 2; }
+        long long bad = 0, n_all = 0;
+        const size_t chunk = 1 << 24;
+        std::vector<float> x(chunk), y(chunk);
+        for (uint64_t base = 0; base <= 0xffffffffull; base += chunk) {
+            const bool positive = base < 0x80000000ull;
+            if (!positive && (base >> 24) % 16 != 0) continue;               // the negative half: every sixteenth chunk
+            for (size_t k = 0; k < chunk; k++) { const uint32_t u = (uint32_t)(base + k); memcpy(&x[k], &u, 4); }
+            if (lcrc_device_ln(dev, form, x.data(), y.data(), (long long)chunk) != LCRC_OK) Die(lcrc_last_error(nullptr));
+            for (size_t k = 0; k < chunk; k++) {
+                const float want = x[k] > 0.0f ? logf(x[k]) : 0.0f;
+                if (memcmp(&want, &y[k], 4) != 0) bad++;
+            }
+            n_all += (long long)chunk;
+        }
+        printf("GPU ln(), glibc's logf sequence %s fused multiply-adds: %lld of %lld values (every non-negative float, a sixteenth of "
+               "the negative ones) differ from this host's logf()\n", form == 1 ? "with" : "without", bad, n_all);
         return bad == 0 ? 0 : 1;
     }
     int ind = 0;

@@ -391,7 +391,7 @@ bool SpeechRec::GpuFrontendTakesConfig()
 std::string SpeechRec::SetUpContext(Traps &t)
 {
     if (split_f16_ && !t.SetArithmetic(LCRC_ARITH_SPLIT_F16)) return t.LastError() + "\n";
-    if (gpu_frontend_ || EnergiesOn()) {
+    if (FrontendOn() || EnergiesOn()) {
         if (wave_.noise_level != 0.0f) return "source/noise_level needs the host front-end (libc rand()); drop -F / -E\n";
         lcrc_frontend fe;
         fe.wave_format = wave_.format == WF_LIN16 ? 1 : 2;
@@ -413,6 +413,10 @@ std::string SpeechRec::SetUpContext(Traps &t)
                 return "offlinenorm/sent_max_norm and sent_chmax_norm need the host front-end; drop -F (or use -E)\n";
         }
         if (!t.ConfigureFrontend(fe)) return t.LastError() + "\n";
+        // ln() as THIS host's libm takes it (glibc's logf sequence, in the build -- fused multiply-adds or not -- that
+        // LibmLogfForm() found the process's logf to match): -F's features are then the host front-end's bit for bit.
+        // Another libc (0): log() in double rounded once, last bit or one ulp.
+        t.SetFrontendLn(LibmLogfForm());
     }
     return std::string();
 }
@@ -503,7 +507,7 @@ static bool ReadFile(const std::string &path, std::vector<unsigned char> &bytes)
 void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job, bool host_features)
 {
     char msg[1200];
-    if (in == dfWaveform && (gpu_frontend_ || EnergiesOn()) && out != dfParams && !host_features) {
+    if (in == dfWaveform && (FrontendOn() || EnergiesOn()) && out != dfParams && !host_features) {
         // -F: only the size is needed to plan the launches; the GPU worker reads the file straight into
         // its context's pinned byte buffer
         struct stat st;
@@ -817,8 +821,16 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // PHNREC_NO_AUTO_E=1 keeps the host front-end whatever -g says.  The choice lives in auto_energies_ / auto_decoder_:
     // what the caller set (SetGpuEnergies, SetGpuDecoder) is never overwritten.
     if (gpus_.empty()) {
-        auto_energies_ = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ && n_gpus_ >= 2 &&
-                         wave_.noise_level == 0.0f && GpuFrontendTakesConfig() && !getenv("PHNREC_NO_AUTO_E");
+        const bool auto_gpu_features = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ &&
+                                       n_gpus_ >= 2 && wave_.noise_level == 0.0f && GpuFrontendTakesConfig() &&
+                                       !getenv("PHNREC_NO_AUTO_E");
+        // ... the whole front-end (-F) where its ln() is this host's libm's own (LibmLogfForm: glibc) and the configuration
+        // asks for nothing that only the host / -E road does (framenorm/*, sent_max_norm, sent_chmax_norm): the same bits
+        // again, no round trip of the energies, a seventh of -E's host CPU time.  Otherwise the energies (-E).
+        const bool whole = auto_gpu_features && LibmLogfForm() != 0 && C.GetFloat("framenorm", "shift") == 0.0f &&
+                           C.GetFloat("framenorm", "min_floor") == -9999.9f && !sent_max_norm_ && !sent_chmax_norm_;
+        auto_frontend_ = whole;
+        auto_energies_ = auto_gpu_features && !whole;
         // A list over four or more GPUs that ends in labels: the decoder runs on the GPUs too (-D) by itself.  Its labels are
         // the host decoder's bit for bit (tested), it costs a GPU 1-3 % of its rate and takes the Viterbi -- half of what is
         // left of the host's work with -F, a third with -E -- off the cores that eight GPUs' lists otherwise bring to their
@@ -845,8 +857,8 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         if (!EnsureGpus(per_gpu)) {
             // -E was this function's own idea and the contexts did not take the front-end after all: the host front-end
             // serves the list as it did before the automatic choice existed
-            if (!(auto_energies_ && gpus_.empty())) return false;
-            auto_energies_ = false;
+            if (!((auto_energies_ || auto_frontend_) && gpus_.empty())) return false;
+            auto_energies_ = auto_frontend_ = false;
             err_.clear();
             if (!EnsureGpus(per_gpu)) return false;
         }
@@ -926,7 +938,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             //  on demand as before)
             const int rows = std::min(batch_frames_, 131072);
             long long wave_bytes = 0;
-            if ((gpu_frontend_ || EnergiesOn()) && in == dfWaveform)
+            if ((FrontendOn() || EnergiesOn()) && in == dfWaveform)
                 wave_bytes = ((long long)rows * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
                              (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
             std::vector<std::string> errs(gpus_.size());
@@ -1238,7 +1250,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             const auto l0 = clock::now();
             const float *h_post = nullptr;
             std::vector<int> foff;
-            if ((gpu_frontend_ || EnergiesOn()) && in == dfWaveform) {
+            if ((FrontendOn() || EnergiesOn()) && in == dfWaveform) {
                 // raw bytes in, posteriors out: decode, mel-bank front-end, sentence norm and the three nets all run
                 // on the device; the files go straight into the context's pinned byte buffer (read in parallel)
                 std::vector<long long> bstart(cnt), blen(cnt);
@@ -1372,7 +1384,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // Jobs whose stage 1 is next to nothing (-F: a stat(); the file is read when its launch is assembled) go to the pool
     // in chunks; the others one by one (a file's read + front-end is a task worth a thread by itself).
     // (the others too once their measured stage 1 turns out short -- lists of very short files: a chunk is sized to ~200 us)
-    const bool cheap_stage1 = need_gpu && (gpu_frontend_ || EnergiesOn()) && in == dfWaveform;
+    const bool cheap_stage1 = need_gpu && (FrontendOn() || EnergiesOn()) && in == dfWaveform;
     auto chunk_max = [&]() -> size_t {
         if (single_file) return 1;
         if (cheap_stage1) return 32;

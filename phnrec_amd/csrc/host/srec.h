@@ -117,9 +117,9 @@ public:
     // RunPipeline chose by itself (PHNREC_STATS prints it)
     std::string ModeString() const
     {
-        std::string m = gpu_frontend_ ? "F" : EnergiesOn() ? "E" : "host";
+        std::string m = FrontendOn() ? "F" : EnergiesOn() ? "E" : "host";
         if (DecoderOn()) m += "+D";
-        if ((auto_energies_ && !gpu_frontend_) || auto_decoder_) m += ",auto";
+        if (auto_frontend_ || auto_energies_ || auto_decoder_) m += ",auto";
         return m;
     }
     const RunStats &Stats() const { return stats_; }
@@ -157,8 +157,9 @@ private:
     bool sent_max_norm_ = false, sent_chmax_norm_ = false;
     bool verbose_ = false, traps_enabled_ = true, sent_mean_norm_ = false, gpu_frontend_ = false, gpu_energies_ = false, gpu_decoder_ = false, split_f16_ = false;
     // what RunPipeline switched on by itself for the contexts it built (-g >= 2: -E, -g >= 4: -D); the members above stay the caller's
-    bool auto_energies_ = false, auto_decoder_ = false;
-    bool EnergiesOn() const { return gpu_energies_ || auto_energies_; }
+    bool auto_frontend_ = false, auto_energies_ = false, auto_decoder_ = false;
+    bool FrontendOn() const { return gpu_frontend_ || auto_frontend_; }
+    bool EnergiesOn() const { return !FrontendOn() && (gpu_energies_ || auto_energies_); }
     bool DecoderOn() const { return gpu_decoder_ || auto_decoder_; }
     bool GpuFrontendTakesConfig();
     WaveOptions wave_;

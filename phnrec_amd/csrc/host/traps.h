@@ -115,6 +115,8 @@ public:
         err_ = lcrc_last_error(ctx_);
         return false;
     }
+    // ln() of the GPU front-end: the host libm's own sequence (LCRC_LN_GLIBC_FMA / LCRC_LN_GLIBC) or log() in double (lcrc_frontend_set_ln)
+    void SetFrontendLn(int form) { if (ctx_) lcrc_frontend_set_ln(ctx_, form); }
     int FrontendFrames(long long n_bytes) const { return lcrc_frontend_frames(ctx_, n_bytes); }
     bool WaveToPosteriors(const unsigned char *bytes, const long long *byte_off, int n_utts, float *post, int *frame_off)
     {

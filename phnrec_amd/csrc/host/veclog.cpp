@@ -43,6 +43,85 @@ inline bool MainPath(uint32_t ix) { return ix - 0x00800000u < 0x7f800000u - 0x00
 
 inline float ScalarLn(float x) { return x > 0.0f ? logf(x) : 0.0f; }
 
+// glibc's sequence on one value (e_logf.c), with fused multiply-adds or without; this file is compiled with
+// -ffp-contract=off, so the second form stays unfused
+__attribute__((always_inline)) inline float LnScalarImpl(float x, bool fma_form)
+{
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t ix = AsUint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix == 0x7f800000u) return x;
+    if (ix < 0x00800000u) ix = AsUint(x * 0x1p23f) - (23u << 23);
+    const uint32_t tmp = ix - kOff;
+    const int i = (int)((tmp >> 19) & 15u), k = (int)(int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    float zf; memcpy(&zf, &iz, 4);
+    const double z = (double)zf, invc = kInvC[i], logc = kLogC[i];
+    double r, y0, y;
+    if (fma_form) {
+        r = __builtin_fma(z, invc, -1.0);
+        y0 = __builtin_fma((double)k, kLn2, logc);
+        const double r2 = r * r;
+        y = __builtin_fma(kA[1], r, kA[2]);
+        y = __builtin_fma(kA[0], r2, y);
+        y = __builtin_fma(y, r2, y0 + r);
+    } else {
+        r = z * invc - 1.0;
+        y0 = logc + (double)k * kLn2;
+        const double r2 = r * r;
+        y = kA[1] * r + kA[2];
+        y = kA[0] * r2 + y;
+        y = y * r2 + (y0 + r);
+    }
+    return (float)y;
+}
+#if defined(__x86_64__)
+__attribute__((target("fma"))) float LnFmaHw(float x) { return LnScalarImpl(x, true); }      // vfmadd
+#endif
+float LnFmaSoft(float x) { return LnScalarImpl(x, true); }                                   // libm's fma()
+float LnPlain(float x) { return LnScalarImpl(x, false); }
+float LnFma(float x)
+{
+#if defined(__x86_64__)
+    static const bool hw = __builtin_cpu_supports("fma");
+    if (hw) return LnFmaHw(x);
+#endif
+    return LnFmaSoft(x);
+}
+
+// the probe: for every exponent of the normal range, both ends and the middle of each of the 16 table intervals (the
+// interval of a value is bits 19..22 of ix - OFF), values next to 1, special values, and a 32-bit LCG over all bit patterns
+size_t FillProbe(float *probe, size_t cap)
+{
+    size_t n = 0;
+    for (int k = -127; k <= 128; k++)
+        for (uint32_t iv = 0; iv < 16; iv++)
+            for (uint32_t m : {0u, 1u, 0x3ffffu, 0x40000u, 0x7fffeu, 0x7ffffu}) {
+                const uint32_t ix = kOff + (((uint32_t)k << 23) | (iv << 19) | m);      // ix - OFF = k : interval : m
+                float f; memcpy(&f, &ix, 4);
+                probe[n++] = f;
+            }
+    for (int d = -64; d <= 64; d++) { const uint32_t ix = 0x3f800000u + (uint32_t)d; float f; memcpy(&f, &ix, 4); probe[n++] = f; }
+    const float special[] = {0.0f, -0.0f, -1.0f, 1e-45f, 1e-39f, 1.17549435e-38f, 3.4028235e38f, INFINITY, -INFINITY, NAN};
+    for (float f : special) probe[n++] = f;
+    uint32_t s = 0x9e3779b9u;
+    while (n < cap) { s = s * 1664525u + 1013904223u; float f; memcpy(&f, &s, 4); probe[n++] = f; }
+    return n;
+}
+
+int DecideLibmForm()
+{
+    static float probe[300000];
+    const size_t n = FillProbe(probe, sizeof probe / sizeof probe[0]);
+    bool fma_ok = true, plain_ok = true;
+    for (size_t i = 0; i < n && (fma_ok || plain_ok); i++) {
+        const float want = ScalarLn(probe[i]);
+        if (fma_ok) { const float a = LnFma(probe[i]); if (memcmp(&a, &want, 4) != 0) fma_ok = false; }
+        if (plain_ok) { const float b = LnPlain(probe[i]); if (memcmp(&b, &want, 4) != 0) plain_ok = false; }
+    }
+    return fma_ok ? 1 : plain_ok ? 2 : 0;
+}
+
 #if defined(__x86_64__)
 template <bool FMA>
 __attribute__((target("avx512f,avx512dq,avx512vl,avx512bw,fma"))) inline __m256 Ln8(__m256i ix, __m512d invc_lo, __m512d invc_hi,
@@ -132,22 +211,8 @@ int Decide()
 {
 #if defined(__x86_64__)
     if (getenv("PHNREC_NO_VECTOR_LN") || getenv("PHNREC_NO_AVX512") || !CpuHasAvx512()) return 1;
-    // the probe: for every exponent of the normal range, both ends and the middle of each of the 16 table intervals (the
-    // interval of a value is bits 19..22 of ix - OFF), values next to 1, and 2^18 values from a 32-bit LCG over all bit patterns
     static float probe[300000];
-    size_t n = 0;
-    for (int k = -127; k <= 128; k++)
-        for (uint32_t iv = 0; iv < 16; iv++)
-            for (uint32_t m : {0u, 1u, 0x3ffffu, 0x40000u, 0x7fffeu, 0x7ffffu}) {
-                const uint32_t ix = kOff + (((uint32_t)k << 23) | (iv << 19) | m);      // ix - OFF = k : interval : m
-                float f; memcpy(&f, &ix, 4);
-                probe[n++] = f;
-            }
-    for (int d = -64; d <= 64; d++) { const uint32_t ix = 0x3f800000u + (uint32_t)d; float f; memcpy(&f, &ix, 4); probe[n++] = f; }
-    const float special[] = {0.0f, -0.0f, -1.0f, 1e-45f, 1e-39f, 1.17549435e-38f, 3.4028235e38f, INFINITY, -INFINITY, NAN};
-    for (float f : special) probe[n++] = f;
-    uint32_t s = 0x9e3779b9u;
-    while (n < sizeof probe / sizeof probe[0]) { s = s * 1664525u + 1013904223u; float f; memcpy(&f, &s, 4); probe[n++] = f; }
+    const size_t n = FillProbe(probe, sizeof probe / sizeof probe[0]);
     if (SameAsLibm(LnArray512<true>, probe, n)) return 2;
     if (SameAsLibm(LnArray512<false>, probe, n)) return 3;
 #endif
@@ -161,6 +226,14 @@ int Form()
 }
 
 }  // namespace
+
+int LibmLogfForm()
+{
+    static const int form = DecideLibmForm();
+    return form;
+}
+
+float LnRestated(float x, int form) { return form == 1 ? LnFma(x) : LnPlain(x); }
 
 void LnInPlace(float *x, size_t n)
 {

@@ -98,6 +98,7 @@ struct lcrc_ctx {
     bool fe_ready = false;
     lcrc_frontend fe = {};
     int fe_fft = 0;
+    int fe_ln_form = 0;                  // LCRC_LN_* (lcrc_frontend_set_ln)
     float *d_hamming = nullptr, *d_coeffs = nullptr;
     double *d_twiddle = nullptr;
     int *d_runs = nullptr;               // [4*nbanks_full]: run_begin[2*nbf], run_end[2*nbf]
@@ -1674,6 +1675,29 @@ int lcrc_frontend_configure(lcrc_ctx *c, const lcrc_frontend *cfg)
     return LCRC_OK;
 }
 
+int lcrc_frontend_set_ln(lcrc_ctx *c, int form)
+{
+    if (!c) return LCRC_E_ARG;
+    if (form < LCRC_LN_DOUBLE || form > LCRC_LN_GLIBC) return fail(c, LCRC_E_ARG, "lcrc_frontend_set_ln: form must be LCRC_LN_DOUBLE, LCRC_LN_GLIBC_FMA or LCRC_LN_GLIBC");
+    c->fe_ln_form = form;
+    return LCRC_OK;
+}
+
+int lcrc_device_ln(int device_id, int form, const float *x, float *y, long long n)
+{
+    if (n < 0 || (n > 0 && (!x || !y)) || form < LCRC_LN_DOUBLE || form > LCRC_LN_GLIBC) return fail(nullptr, LCRC_E_ARG, "lcrc_device_ln: bad argument");
+    if (n == 0) return LCRC_OK;
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    float *d = nullptr;
+    HIP_TRY(nullptr, hipMalloc((void **)&d, (size_t)n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = frontend_ln_launch(d, (size_t)n, form, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(y, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIP_TRY(nullptr, e);
+    return LCRC_OK;
+}
+
 static long long fe_samples(const lcrc_ctx *c, long long n_bytes)
 {
     return c->fe.wave_format == 1 ? n_bytes / 2 : n_bytes;
@@ -1811,6 +1835,7 @@ static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long l
     p.dc_shift = c->fe.dc_shift; p.scale = c->fe.scale; p.preem_coef = c->fe.preem_coef;
     p.z_mean_source = c->fe.z_mean_source;
     p.raw_energies = raw_energies ? 1 : 0;
+    p.ln_form = c->fe_ln_form;
     HIP_TRY(c, frontend_launch(p, c->stream));
     return LCRC_OK;
 }

@@ -194,10 +194,10 @@ def test_gpu_energies_flag_is_the_host_front_end_bit_for_bit(system, tmp_path):
     _labels_match(out2, os.path.join(GOLD, "rec", system + ".rec"))
 
 
-def test_two_gpus_called_as_the_reference_take_the_energies_road(tmp_path):
-    """`phnrec -g 2 -l ... -m ...` without -F / -E switches -E on by itself (the host front-end would feed 1.4 GPUs): its
-    stage-1 CPU time falls to a fraction, the MLF stays the one `-g 1` (host front-end) writes, byte for byte;
-    PHNREC_NO_AUTO_E=1 keeps the host front-end"""
+def test_two_gpus_called_as_the_reference_take_the_gpu_front_end(tmp_path):
+    """`phnrec -g 2 -l ... -m ...` without -F / -E switches the GPU front-end on by itself (the host front-end would feed 1.4
+    GPUs) -- -F where its ln() is this host's libm's own sequence (glibc: here), else -E --: its stage-1 CPU time falls to a
+    fraction, the MLF stays the one `-g 1` (host front-end) writes, byte for byte; PHNREC_NO_AUTO_E=1 keeps the host front-end"""
     lst = _make_list(tmp_path, "hu", 150, seed=23)
     one, two, two_host = tmp_path / "g1.mlf", tmp_path / "g2.mlf", tmp_path / "g2h.mlf"
     a = run("-c", model_dir(HU), "-l", lst, "-m", one, env={"PHNREC_STATS": "1"})
@@ -210,6 +210,37 @@ def test_two_gpus_called_as_the_reference_take_the_energies_road(tmp_path):
         line = [l for l in p.stderr.splitlines() if l.startswith("phnrec: files=")][-1]
         return float(line.split("stage1=")[1].split()[0])
     assert stage1(b) < 0.5 * stage1(a) and stage1(c) > 0.5 * stage1(a)
+    assert " mode=F,auto " in b.stderr and " mode=host " in c.stderr
+
+
+@pytest.mark.parametrize("system", [CZ, EN, HU, RU])
+def test_gpu_front_end_flag_is_the_host_front_end_bit_for_bit(system, tmp_path):
+    """-F with ln() taken as THIS host's libm takes it (lcrc_frontend_set_ln: glibc's logf sequence, in the build the CLI found
+    the process's logf to match): the whole front-end on the GPU -- decode, window, FFT, bank sums, ln(), sentence mean in
+    the reference's order -- gives the host front-end's features, so the posterior dump equals the default mode's BYTE FOR
+    BYTE, as -E's does; A-law too; over a list (several launches, two logical GPUs, device decoder) the MLF as well."""
+    raw = os.path.join(GOLD, "test.raw")
+    a, b = tmp_path / "host.lop", tmp_path / "f.lop"
+    run("-c", model_dir(system), "-i", raw, "-t", "post", "-o", a)
+    run("-c", model_dir(system), "-i", raw, "-t", "post", "-o", b, "-F")
+    assert open(a, "rb").read() == open(b, "rb").read()
+    if system == CZ:
+        run("-c", model_dir(system), "-w", "alaw", "-i", raw, "-t", "post", "-o", a)
+        run("-c", model_dir(system), "-w", "alaw", "-i", raw, "-t", "post", "-o", b, "-F")
+        assert open(a, "rb").read() == open(b, "rb").read()
+    lst = _make_list(tmp_path, system[4:6].lower(), 60, seed=31, rate=16000 if system == EN else 8000)
+    host, fe, fed = tmp_path / "host.mlf", tmp_path / "f.mlf", tmp_path / "fd.mlf"
+    run("-c", model_dir(system), "-l", lst, "-m", host, "-b", 3000)
+    run("-c", model_dir(system), "-l", lst, "-m", fe, "-b", 3000, "-F", "-g", 2, env={"PHNREC_DEVICE_MAP": "0,0"})
+    run("-c", model_dir(system), "-l", lst, "-m", fed, "-F", "-D")
+    assert host.read_text() == fe.read_text() == fed.read_text()
+
+
+def test_gpu_ln_on_this_boxs_host_and_gpu():
+    """the GPU front-end's ln() in the form this host's libm matches, against that libm's logf over every positive float and a
+    sixteenth of the other bit patterns (phnrec --selftest-gpu-ln)"""
+    p = subprocess.run([BIN, "--selftest-gpu-ln"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and ": 0 of " in p.stdout, p.stdout + p.stderr
 
 
 def test_vector_ln_on_this_boxs_host():
@@ -635,7 +666,7 @@ def test_bench_line_carries_every_leg():
     wl = sl["weak_list"]
     assert wl["files"] == 8 * 120 and all(wl[k]["value"] > 50000 and wl[k]["ceiling_over_8_gpus"] > 0 for k in (
         "host_frontend", "gpu_energies_E", "gpu_energies_decoder_E_D", "gpu_frontend_F", "gpu_frontend_decoder_F_D"))
-    assert wl["as_g8_default"]["mode"] == "E+D,auto" and wl["as_g8_default"]["value"] > 50000
+    assert wl["as_g8_default"]["mode"] == "F+D,auto" and wl["as_g8_default"]["value"] > 50000
     # configs[4]: the four systems at once (here: all on this box's one GPU), MLFs those of each system run alone
     fs = d["four_systems"]
     assert fs["oversubscribed"] is True and set(fs["default_flags"]["per_system"]) == set(fs["systems"])
@@ -666,7 +697,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     wl = sl["weak_list"]
     assert wl["files"] == 16 * 150 and wl["frames"] == 16 * sl["frames"]
     assert wl["gpu_frontend_F"]["value"] > 50000 and wl["gpu_frontend_decoder_F_D"]["value"] > 50000
-    assert wl["host_frontend"]["mode"] == "E,auto" and wl["gpu_energies_decoder_E_D"]["value"] > 50000
+    assert wl["host_frontend"]["mode"] == "F,auto" and wl["gpu_energies_decoder_E_D"]["value"] > 50000
     fs = line["four_systems"]
     assert fs["gpu_pairs"] == ["0,0"] * 4 and fs["oversubscribed"] is True and fs["default_flags"]["value"] > 50000
     assert sl["frames_per_s"] > 50000 and sl["host_ceiling"]["frames_per_s"] > 0 and sl["cores_usable"] >= 1

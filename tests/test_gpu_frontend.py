@@ -376,3 +376,31 @@ def test_decoder_overlapped_with_the_next_call_gives_the_same_labels(capi):
     assert ctx.last_labels() == want[0]
     ref.close()
     ctx.close()
+
+
+def test_device_ln_forms_against_this_hosts_logf(capi):
+    """lcrc_frontend_set_ln's three forms on raw values (lcrc_device_ln): one of glibc's two logf sequences (with / without
+    fused multiply-adds) must give THIS host's logf bit for bit on every probe -- all exponents, the ends of every table
+    interval, values next to 1, subnormals, infinity, NaN, zero and negative values (sLn: 0) --, and log() in double
+    rounded once stays within one ulp of it."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype, libm.logf.argtypes = ctypes.c_float, [ctypes.c_float]
+    bits = []
+    for k in range(-127, 129):
+        for iv in range(16):
+            for m in (0, 1, 0x3ffff, 0x40000, 0x7fffe, 0x7ffff):
+                bits.append((0x3f330000 + (((k & 0x1ff) << 23) | (iv << 19) | m)) & 0xffffffff)
+    bits += [0x3f800000 + d for d in range(-64, 65)]
+    bits += [0, 0x80000000, 0xbf800000, 1, 0x000fffff, 0x00800000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000]
+    rng = np.random.default_rng(3)
+    bits = np.concatenate([np.array(bits, np.uint64), rng.integers(0, 1 << 32, 60000, dtype=np.uint64)]).astype(np.uint32)
+    x = bits.view(np.float32)
+    want = np.array([libm.logf(float(v)) if v > 0 else 0.0 for v in x], np.float32)
+    got = [capi.device_ln(x, f) for f in (0, 1, 2)]
+    same = [np.array_equal(g.view(np.uint32), want.view(np.uint32)) for g in got]
+    assert same[1] or same[2], "neither of glibc's logf sequences gives this host's logf"
+    finite = np.isfinite(want) & (x > 0)
+    ulp = np.abs(got[0].view(np.int32)[finite].astype(np.int64) - want.view(np.int32)[finite].astype(np.int64))
+    assert ulp.max() <= 1 and (ulp == 0).mean() > 0.999
+    assert np.array_equal(got[0][~finite].view(np.uint32), want[~finite].view(np.uint32))      # zero, negative, NaN: 0; inf: inf

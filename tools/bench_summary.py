@@ -25,13 +25,30 @@ for f in sys.argv[1:]:
     cb = r["cpu_baseline"]
     print("   cpu sgemv %.0f" % cb["value"], [(k, v.get("value")) for k, v in cb.items() if isinstance(v, dict) and "value" in v])
     sl = r["sharded_list"]
-    modes = ("host_frontend", "gpu_energies_E", "gpu_frontend_F", "gpu_frontend_decoder_F_D")
+    modes = ("host_frontend", "gpu_energies_E", "gpu_energies_decoder_E_D", "gpu_frontend_F", "gpu_frontend_decoder_F_D")
     for k in modes:
-        print("   %-26s %.2f M  host_cpu %.3f s  list %.3f s  process %.3f s  set-up %.3f s" % (
-            k, sl[k]["value"] / 1e6, sl[k]["host_cpu_s"], sl[k]["list_wall_s"], sl[k]["process_wall_s"], sl[k].get("setup_s", 0)))
+        print("   %-26s %.2f M  host_cpu %.3f s  list %.3f s  process %.3f s  set-up %.3f s  mode %s" % (
+            k, sl[k]["value"] / 1e6, sl[k]["host_cpu_s"], sl[k]["list_wall_s"], sl[k]["process_wall_s"], sl[k].get("setup_s", 0), sl[k].get("mode")))
     hc = sl["host_ceiling"]
     print("   ceilings", {k: round(hc[k]["frames_per_s"] / 1e6, 1) for k in modes}, "per-file serial %.0f files/s = %.1f M" % (
         hc["per_file_serial"]["files_per_s"], hc["per_file_serial"]["frames_per_s_at_this_lists_file_length"] / 1e6))
+    wl = sl.get("weak_list", {})
+    print("   weak list: %s files, %.1f M frames" % (wl.get("files"), wl.get("frames", 0) / 1e6))
+    for k in modes + ("as_g8_default",):
+        v = wl.get(k)
+        if isinstance(v, dict) and "value" in v:
+            print("     %-26s %.2f M (process %.2f M, %.2f s)  host_cpu %.2f s  ceiling %.0f M = %.2f x 8 GPUs  mode %s" % (
+                k, v["value"] / 1e6, v["process_frames_per_s"] / 1e6, v["process_wall_s"], v["host_cpu_s"],
+                v.get("host_ceiling_frames_per_s", 0) / 1e6, v.get("ceiling_over_8_gpus", 0), v.get("mode")))
+    print("     F_D_over_F", wl.get("F_D_over_F"))
     cz = sl.get("cz_same_list", {})
     print("   cz_same_list", {k: round(v["value"] / 1e6, 2) for k, v in cz.items() if isinstance(v, dict) and "value" in v})
+    fs = r.get("four_systems", {})
+    for k in ("default_flags", "gpu_frontend_decoder_F_D"):
+        v = fs.get(k)
+        if isinstance(v, dict) and "value" in v:
+            print("   four_systems %-26s %.2f M frames/s in sum (whole script %.2f s, xRT %.2e; list loops %.1f M)  %s" % (
+                k, v["value"] / 1e6, v["process_wall_s"], v["xrt"], v["list_loops_frames_per_s"] / 1e6,
+                {n[4:6]: round(p["frames_per_s"] / 1e6, 1) for n, p in v["per_system"].items()}))
+    print("   four_systems MLFs equal single-system runs:", fs.get("mlf_equals_single_system_run"))
     print("   split_f16 %.4f ms  %.1f M" % (r["split_f16"]["kernel_ms"], r["split_f16"]["value"] / 1e6))
