@@ -290,6 +290,10 @@ class Lcrc:
         call, or last_labels() after the last one (lcrc_set_decoder_overlap)"""
         self._check(self.L.lcrc_set_decoder_overlap(self.h, int(on)))
 
+    def set_launch_order(self, on):
+        """posterior kernels of this device's ordered contexts run one after the other, in queueing order (lcrc_set_launch_order)"""
+        self._check(self.L.lcrc_set_launch_order(self.h, int(on)))
+
     def prev_labels(self):
         """labels of the staged call BEFORE the most recent one (lcrc_prev_labels)"""
         return self.last_labels(fn=self.L.lcrc_prev_labels)

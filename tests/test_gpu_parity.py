@@ -875,6 +875,45 @@ def test_kernel_done_callback(capi, tmp_path):
     ctx.close()
 
 
+def test_launch_order_across_the_contexts_of_a_device(capi):
+    """lcrc_set_launch_order: three contexts of one device (a model and two clones, as the CLI's three per GPU), each on its
+    own thread, fifty staged calls each of different sizes at once -- with the order on, every call's posterior kernels wait
+    on the device for those of the call queued before them; the results are those of the same calls without the order, bit
+    for bit, nothing deadlocks, and a context may switch the order off and on between calls."""
+    import threading
+    system = "PHN_CZ_SPDAT_LCRC_N1500"
+    a = capi.Lcrc(model_dir(system), 15)
+    ctxs = [a, a.clone(), a.clone()]
+    for c in ctxs:
+        c.set_hidden_split(1)
+    mels = [modelgen.synth_mel(n, 15, seed=40 + k, mean_norm=True) for k, n in enumerate((700, 5000, 33, 12000))]
+    offs = [np.array([0, m.shape[0]], np.int32) for m in mels]
+    want = [a.posteriors_staged(m, o) for m, o in zip(mels, offs)]
+
+    def work(c, k0, out):
+        for i in range(50):
+            k = (k0 + i) % len(mels)
+            if i == 20:
+                c.set_launch_order(False)
+            if i == 25:
+                c.set_launch_order(True)
+            out.append(np.array_equal(c.posteriors_staged(mels[k], offs[k]).view(np.uint32), want[k].view(np.uint32)))
+
+    for c in ctxs:
+        c.set_launch_order(True)
+    res = [[] for _ in ctxs]
+    th = [threading.Thread(target=work, args=(c, k, res[k])) for k, c in enumerate(ctxs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a context's calls did not come back"
+    assert all(len(r) == 50 and all(r) for r in res)
+    for c in ctxs[1:]:
+        c.close()
+    a.close()
+
+
 def test_decoder_on_the_device(capi, oracle_mod, tmp_path):
     """lcrc_decoder_configure ("next" row f3): the PhnDec kernel behind the posterior kernel against the
     decoder oracle run on the SAME log-posteriors (bit-identical labels, times and scores: both do the same

@@ -2,7 +2,7 @@
 # Copies the summaries of a tools/refresh_profiles.sh run (gpurun_out/refresh_<tag>/) into profiles/ under the round's names.
 #   tools/collect_profiles.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r05}
 R=gpurun_out/refresh_$TAG
 P=profiles
 clean() { grep -v amdgpu.ids "$1" > "$2"; }
@@ -16,7 +16,7 @@ cp $(first "$R/stats/*/*kernel_stats.csv") $P/${TAG}_kernel_stats_all_launches.c
 [ -f $R/system_sweep_fused_only.txt ] && clean $R/system_sweep_fused_only.txt $P/${TAG}_system_sweep_fused_only.txt
 [ -f $R/startup_probe.txt ] && clean $R/startup_probe.txt $P/${TAG}_startup_probe.txt
 [ -f $R/cli_contexts.txt ] && clean $R/cli_contexts.txt $P/${TAG}_cli_contexts.txt
-for f in cli_timeline cli_sweep host_decoder_probe pinned_read pipeline_trace pipeline_trace_no_reserve; do [ -f $R/$f.txt ] && clean $R/$f.txt $P/${TAG}_$f.txt; done
+for f in cli_timeline cli_sweep pinned_read pipeline_trace host_mem_load selftest_gpu_ln; do [ -f $R/$f.txt ] && clean $R/$f.txt $P/${TAG}_$f.txt; done
 cp $R/kernel_trace_head.csv $P/${TAG}_kernel_trace_head.csv
 python3 tools/pmc_summary.py $TAG $R > /dev/null
 clean $R/phase_stamps.txt $P/${TAG}_phase_stamps.txt

@@ -6,7 +6,7 @@
 # rocprofv3 is always given `python3 <script>` directly (no shell hop), PMC passes are separate runs
 # with --kernel-trace only.  Every step writes a file under $OUT as it ends (progress for the harness).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}     # a | b | c | all: the run fits gpurun's 20-minute limit in three parts
 OUT=gpurun_out/refresh_$TAG
 [ "$PART" = "a" -o "$PART" = "all" ] && rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
@@ -56,21 +56,17 @@ python3 tools/split_f16_bench.py > $OUT/split_f16_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/split_stats -- python3 tools/split_f16_bench.py 8192 > $OUT/split_prof.txt 2>&1
 fi
 [ "$PART" = "b" ] && { ls -R $OUT | head -60; exit 0; }
-# the CLI on the configs[3] list: contexts per GPU, logical -g N on this one GPU (host-side cost of more contexts)
-for n in 1 2 3 4; do echo "== PHNREC_CTX_PER_GPU=$n, -g 1"; PHNREC_CTX_PER_GPU=$n python3 -c "
-import bench, json
-r = bench.sharded_list_leg(1, [0], 10000)
-print(json.dumps({k: r[k] for k in ('host_frontend', 'gpu_frontend_F', 'gpu_frontend_decoder_F_D', 'host_ceiling')}))"; done > $OUT/cli_contexts.txt 2>&1
-for g in 2 4 8; do echo "== -g $g, every logical GPU on device 0"; python3 -c "
-import bench, json
-r = bench.sharded_list_leg($g, [0] * $g, 10000)
-print(json.dumps({k: r[k] for k in ('host_frontend', 'gpu_frontend_F', 'gpu_frontend_decoder_F_D', 'host_ceiling')}))"; done >> $OUT/cli_contexts.txt 2>&1
-# round 4: where a list run's wall clock goes, the host decoder's CPU time by thread count, pinned-memory reads
-TIMELINE_ROWS=40 python3 tools/cli_timeline.py 10000 -F > $OUT/cli_timeline.txt 2>&1
-python3 tools/cli_timeline.py 10000 -F -D >> $OUT/cli_timeline.txt 2>&1
-python3 tools/cli_timeline.py 10000 >> $OUT/cli_timeline.txt 2>&1
+# where a list run's wall clock goes on the device (the configs[3] list four times over), the modes by contexts per GPU,
+# the host decoder's CPU time by thread count and under the posterior stores of eight GPUs, pinned-memory reads
+TIMELINE_REPS=4 python3 tools/cli_timeline.py 10000 -F > $OUT/cli_timeline.txt 2>&1
+TIMELINE_REPS=4 python3 tools/cli_timeline.py 10000 -F -D >> $OUT/cli_timeline.txt 2>&1
+TIMELINE_REPS=4 python3 tools/cli_timeline.py 10000 -E -D >> $OUT/cli_timeline.txt 2>&1
+TIMELINE_REPS=4 python3 tools/cli_timeline.py 10000 >> $OUT/cli_timeline.txt 2>&1
 python3 tools/cli_sweep.py 10000 "3,0;2,0;4,0" > $OUT/cli_sweep.txt 2>&1
 python3 tools/host_decoder_probe.py > $OUT/host_decoder_probe.txt 2>&1
+./tools/ubench/host_mem_load 8 8 2 > $OUT/host_mem_load.txt 2>&1
+./tools/ubench/host_mem_load 4 12 2 0 45.6 91.2 182.4 -1 >> $OUT/host_mem_load.txt 2>&1
+./phnrec_amd/bin/phnrec --selftest-gpu-ln > $OUT/selftest_gpu_ln.txt 2>&1
 # the first milliseconds of a list: the workers' steps and the library's slow calls
 TRACE_CHARS=5000 python3 tools/pipeline_trace.py > $OUT/pipeline_trace.txt 2>&1
 ./tools/ubench/pinned_read 256 16 > $OUT/pinned_read.txt 2>&1
