@@ -30,21 +30,25 @@ constexpr int kMaxStates = 4;
 constexpr int kMaxHist = 64;       // time_pruning + 1 <= 64: history slot q lives in lane q of three registers
 
 // Maximum over the wave and the LOWEST lane holding it == the reference's first strict maximum.
-// Row maxima by DPP (quad_perm, quad_perm, row_half_mirror, row_mirror), the four rows by v_readlane, the
-// lane by ballot + find-first: no LDS traffic (a __shfl butterfly is six dependent ds_bpermute round trips).
+// Six v_max_f32 with a DPP source operand -- quad_perm, quad_perm, row_half_mirror, row_mirror give every lane its row's
+// maximum, row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) carry it across the rows into lane 63 -- and one
+// v_readlane; the lane by ballot + find-first.  No LDS traffic (a __shfl butterfly is six dependent ds_bpermute round trips).
+// Written as instructions: through the builtins (update_dpp on the bit pattern + fmaxf) every step was a v_mov_dpp, a
+// v_max x, x, x that quiets a possible signalling NaN and the v_max itself, and the four rows met through four v_readlane
+// and three more v_max -- 30 instructions per maximum, two maxima per frame on the decoder's one dependent chain.  (The
+// values are finite floats or -FLT_MAX: no NaN to quiet.  s_nop 1: a DPP operand written by the previous VALU instruction
+// needs two wait states, and the assembler does not see inside an asm block.)
 __device__ __forceinline__ void wave_argmax(float v, float &best, int &lane_of_best)
 {
     float m = v;
-    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true)));
-    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, true)));
-    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x141, 0xF, 0xF, true)));
-    m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x140, 0xF, 0xF, true)));
-    const int mi = __builtin_bit_cast(int, m);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mi, 48));
-    best = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(m));
+    best = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
     const unsigned long long hit = __ballot(v == best);
     lane_of_best = hit ? __builtin_ctzll(hit) : 0;
 }
@@ -83,9 +87,6 @@ __global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecP
     const float lh = -0.69314718055994530941723212145818f;      // ln 0.5, both transitions (phndec.cpp:9,14-15)
     const bool active = lane < P;
     lcrc_label *out = p.labels + a0;
-    auto lane_set_i = [&](int old, int at, int v) { return lane == at ? v : old; };
-    auto lane_set_f = [&](float old, int at, float v) { return lane == at ? v : old; };
-
     // winner history (phndec.cpp's hphn / hlen / halpha): physical slot = lane, logical slot q = (head + q) % H.
     // hmask (round 4): bit d of slot q's 64-bit word says that TimePruning's walk, started at q, visits q - d --
     // the walk "offs -= hlen[offs]" (phndec.cpp:206-214) is a chain of back pointers that never changes once a slot is
@@ -150,11 +151,22 @@ __global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecP
                 const unsigned long long sm = ((unsigned long long)(unsigned)lane_get(hm_hi, src) << 32) | (unsigned)lane_get(hm_lo, src);
                 m |= sm << eln;                                 // eln <= 63
             }
-            hphn = lane_set_i(hphn, back, epv);
-            hlen = lane_set_i(hlen, back, eln);
-            halpha = lane_set_f(halpha, back, best);
-            hm_lo = lane_set_i(hm_lo, back, (int)(unsigned)m);
-            hm_hi = lane_set_i(hm_hi, back, (int)(unsigned)(m >> 32));
+            // the slot's five registers take their wave-uniform values in lane `back`: one s_mov to M0 (the lane select;
+            // value and lane in two scalar registers would be two constant-bus reads) and five v_writelane_b32 -- as compare +
+            // move out of the scalar register + select it was eleven instructions.  (M0 is not allocatable and nothing else in
+            // this kernel uses it -- no LDS, no GDS, no s_movrel --, so writing it here disturbs nothing.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %10\n\t"
+                         "v_writelane_b32 %0, %5, m0\n\t"
+                         "v_writelane_b32 %1, %6, m0\n\t"
+                         "v_writelane_b32 %2, %7, m0\n\t"
+                         "v_writelane_b32 %3, %8, m0\n\t"
+                         "v_writelane_b32 %4, %9, m0"
+                         : "+v"(hphn), "+v"(hlen), "+v"(halpha), "+v"(hm_lo), "+v"(hm_hi)
+                         : "s"(epv), "s"(eln), "s"(best), "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "s"(back)
+                         : "m0");
+#pragma clang diagnostic pop
         }
         a[0] = active ? best + p.wpen : -FLT_MAX;
         pv[0] = bi;
