@@ -5,180 +5,11 @@
 // fragment order, owns the device buffers / stream / events, and mirrors the
 // two ways SpeechRec drives Traps: whole utterances (srec.cpp:1035-1059) and the
 // streaming CalcFeaturesBunched form (traps.cpp:518-535).
-// There is deliberately no CPU path in this file.
-#include "../../include/lcrc.h"
+// There is deliberately no CPU path in this file.  (The waveform entry points: lcrc_api_wave.cpp; the decoder on the
+// device: lcrc_api_decoder.cpp; what the three share: lcrc_ctx.h.)
+#include "lcrc_ctx.h"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <pthread.h>
-#include <string>
-#include <thread>
-#include <time.h>
-#include <vector>
-
-#include "frontend_dev.h"
-#include "lcrc_dev.h"
-#include "meltables.h"
-#include "nnet_io.h"
-
-using namespace phnrec;
-
-// SYS_LCRC: the fused kernels (length 31, add_c0, 11 coefficients per band: every shipped model); SYS_LCRC_GEN: LCRC at any
-// other geometry the reference accepts, composed from the general features / MLP kernels like the unfused other systems
-enum { SYS_LCRC = 0, SYS_1BT_DCT = 1, SYS_1BT = 2, SYS_3BT = 3, SYS_LCRC_GEN = 4 };
-
-// split-f16 operand images of one net (pack_net_h2)
-struct H2Images {
-    const float4 *w1h = nullptr, *w2h = nullptr;
-    const float *b1h = nullptr, *b2h = nullptr;
-    float sig_descale = 1.f, out_descale = 1.f;
-};
-
-// What the contexts of one model on one GPU share (lcrc_clone): the read-only device buffers -- packed weights,
-// biases, normalisation vectors, tables -- and the host copy of the nets the split-f16 operand images are packed
-// from on first request.  Freed with the last context.
-struct SharedModel {
-    int device = 0;
-    std::vector<void *> allocs;
-    HostNet host[3];
-    std::mutex mu;                       // guards the lazily built split-f16 images
-    int h2_state = 0;                    // 0: not built, 1: built, -1: the model has no such form
-    H2Images h2[3];
-    ~SharedModel()
-    {
-        if (allocs.empty()) return;
-        (void)hipSetDevice(device);
-        for (void *p : allocs) (void)hipFree(p);
-    }
-};
-
-struct lcrc_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int nbanks = 0;
-    std::shared_ptr<SharedModel> model;
-    NetDev nets[3];
-    std::vector<void *> allocs;          // this context's own device buffers (split scratch)
-    float *d_win = nullptr, *d_costab = nullptr;
-    float normc = 0.f;
-    // the other posteriors/system variants ("next" row f4): nets[2] is the merger in every system
-    int system = SYS_LCRC, trap_bands = 0, shift = 0;
-    bool use_hamming = false, add_c0 = true;
-    std::vector<NetDev> band_nets;       // 1BT / 3BT: trap_bands nets of 31 inputs
-    const NetDev *d_band_nets = nullptr; // the same on the device (one launch runs them all)
-    const int *d_band_col = nullptr;     // first merger-input column of each band net
-    NetDev band_max = {};                // maxima of ksteps / nkq / n_ot over the band nets
-    float *d_hamm31 = nullptr, *d_costab31 = nullptr;    // (named for the usual length; sized by trap_len)
-    float normc31 = 0.f;
-    int trap_len = kTrapLen;             // posteriors/length; anything but 31 runs the general (unfused) kernels
-    float *d_win_gen = nullptr;          // SYS_LCRC_GEN: [2][half] windows
-    float *d_feat = nullptr, *d_minp = nullptr;   // trajectories or C0/DCT rows; merger input of 1BT / 3BT
-    size_t cap_feat_rows = 0;
-    bool traps_unfused = false;          // PHNREC_TRAPS_UNFUSED=1: every system as separate features / MLP launches (A/B, tests)
-    bool bt_unfused = false;             // 1BT / 3BT model that no fused size class holds
-    const char *mlp_variant = "none";    // kernel of the last merger launch (1BT_DCT / 1BT / 3BT)
-    // staging for the host-pointer entry points (grown on demand)
-    float *d_mel = nullptr, *d_post = nullptr;
-    int *d_off = nullptr;
-    float *h_mel = nullptr, *h_post = nullptr;
-    int *h_off = nullptr;
-    size_t cap_rows = 0, cap_utts = 0, cap_host_post = 0;
-    float *d_dbg[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t cap_dbg = 0;
-    // GPU front-end ("next" row f1): configuration, device tables, staging for raw bytes
-    bool fe_ready = false;
-    lcrc_frontend fe = {};
-    int fe_fft = 0;
-    int fe_ln_form = 0;                  // LCRC_LN_* (lcrc_frontend_set_ln)
-    float *d_hamming = nullptr, *d_coeffs = nullptr;
-    double *d_twiddle = nullptr;
-    int *d_runs = nullptr;               // [4*nbanks_full]: run_begin[2*nbf], run_end[2*nbf]
-    unsigned char *d_bytes = nullptr, *h_bytes = nullptr;
-    long long *d_soff = nullptr, *h_soff = nullptr;
-    int *d_foff = nullptr, *h_foff = nullptr;
-    float *d_means = nullptr, *d_mean_part = nullptr;
-    size_t cap_bytes = 0, cap_fe_utts = 0, cap_mean_blocks = 0;
-    int mean_blocks = 0;                 // blocks of the last staged batch (tree mean)
-    bool mean_sequential = true;         // lcrc_set_mean_order: the reference's order unless the caller opts out
-    // streaming state (lcrc_push): the pushed frames live in a pinned, device-mapped strip whose last 30 rows
-    // are the history (Traps::be_mat minus its newest slot); the kernel reads the strip and writes the
-    // posteriors of a push in place (zero-copy), so a push costs no allocation and no copy command
-    float *h_ring = nullptr, *d_ring = nullptr;       // [ring_cap][nbanks], host and device view
-    float *h_pushout = nullptr, *d_pushout = nullptr; // [pushout_cap][n_out]
-    size_t ring_cap = 0, ring_rows = 0, pushout_cap = 0;
-    bool hist_init = false;
-    int delay = 0;
-    // split-hidden path (small launches): scratch for partial output tiles, operand images, tickets
-    float4 *d_part = nullptr, *d_gimg = nullptr;
-    unsigned *d_cnt = nullptr;
-    int split_hint = 0;
-    bool split_scratch_failed = false;
-    // timing
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timing = true, timed = false;
-    int poll_wait_us = 0;                // lcrc_set_wait_mode: 0 = spin in hipStreamSynchronize, > 0 = sleep between completion queries
-    hipEvent_t ev_wait = nullptr;
-    hipEvent_t ev_piece[8] = {};         // copy_back's pieces
-    lcrc_kernel_done_fn kdone_fn = nullptr;      // lcrc_set_kernel_done_callback
-    void *kdone_arg = nullptr;
-    hipEvent_t ev_kdone = nullptr;
-    bool kdone_armed = false;            // an event behind this call's posterior kernels is recorded and not yet reported
-    // posterior writer path
-    lcrc_softening soft[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    int out_be = 0;
-    int tile_frames = 0;
-    int arith = 0;              // LCRC_ARITH_*
-    // decoder on the device ("next" row f3): configuration, label buffers (device + pinned host)
-    int dec_P = 0, dec_S = 0, dec_prune = 0;
-    float dec_wpen = 0.f;
-    bool readback = true;
-    lcrc_label *d_labels = nullptr, *h_labels = nullptr;
-    int *d_count = nullptr, *h_count = nullptr;
-    size_t cap_label_rows = 0, cap_label_utts = 0;
-    std::vector<int> label_first;
-    int label_utts = 0;
-    // lcrc_set_decoder_overlap: the decoder kernel of a staged call runs on dec_stream, behind an event,
-    // BESIDE the next call's front-end and posterior kernels.  Everything a launch's decoder reads or writes exists twice and
-    // alternates: the context's own fields above (d_post, d_labels ... label_utts, with d_dec_off / ev_dec_done / dec_pending)
-    // are the set of the CURRENT call, `alt` is the set of the call before it.
-    bool launch_ordered = false;         // lcrc_set_launch_order: posterior kernels of this device's ordered contexts run one after the other
-    bool dec_overlap = false;
-    hipStream_t dec_stream = nullptr;
-    hipEvent_t ev_post = nullptr;        // this call's posterior kernels (and the decoder's copy of the offsets) are done
-    size_t d_post_cap = 0;               // rows d_post holds (cap_rows unless the sets have just been swapped)
-    int *d_dec_off = nullptr;            // the decoder's own copy of the utterance offsets (the next call overwrites d_off / d_foff)
-    size_t cap_dec_off = 0;
-    hipEvent_t ev_dec_done = nullptr;    // behind the decoder kernel of this set's last launch
-    bool dec_pending = false;            // ... recorded and not yet waited for
-    struct DecSet {
-        float *d_post = nullptr;
-        size_t d_post_cap = 0;
-        lcrc_label *d_labels = nullptr, *h_labels = nullptr;
-        int *d_count = nullptr, *h_count = nullptr;
-        size_t cap_label_rows = 0, cap_label_utts = 0;
-        std::vector<int> label_first;
-        int label_utts = 0;
-        int *d_dec_off = nullptr;
-        size_t cap_dec_off = 0;
-        hipEvent_t ev_dec_done = nullptr;
-        bool dec_pending = false;
-    } alt;
-    unsigned long long *d_stamps = nullptr;   // diagnostic build only
-    std::string err;
-    const char *variant = "none";
-    unsigned lds_bytes = 0;
-};
-
-namespace {
+namespace lcrc_impl {
 
 thread_local std::string g_create_err = "";
 
@@ -202,12 +33,6 @@ int fail(lcrc_ctx *c, int code, const std::string &msg)
     return code;
 }
 
-#define HIP_TRY(ctx, expr)                                                                  \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(ctx, LCRC_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
 
 // (the copy is queued on the context's stream: a synchronous hipMemcpy from pageable memory costs a fresh process twice as
 //  much -- 17 ms against 8 ms for the first 6.6 MB, tools/ubench/hip_upload -- and every later use of the buffer is
@@ -436,10 +261,8 @@ hipError_t dev_alloc(void **p, size_t bytes)
 // place by the kernels of the context's OWN device, whose pointer is taken under that device (hipSetDevice precedes
 // every hipHostGetDevicePointer here).  Without the flag the registration belongs to the device that was current at
 // allocation time only -- invisible on a one-GPU box.
-constexpr unsigned kPinned = hipHostMallocPortable;
-constexpr unsigned kPinnedMapped = hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent;
 // device_reads: a buffer that kernels read in place (mapped into the device, coherent: never cached on the device side)
-hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false)
+hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads)
 {
     *p = nullptr;
     if (inject_alloc_failure()) return hipErrorOutOfMemory;
@@ -496,7 +319,6 @@ hipError_t report_kernel_done(lcrc_ctx *c)
 // frames: 90 us + 80 us).  Pieces of >= 512 KiB, at most four (lcrc_posteriors of 8192 CZ frames, median of 60 calls on
 // one box: 0.469 / 0.465 / 0.431 / 0.454 ms with 1 / 2 / 4 / 8 pieces: an event wait per piece costs, too); small
 // transfers take the plain road.
-constexpr int kCopyPieces = 4;           // <= lcrc_ctx::ev_piece
 hipError_t copy_back(lcrc_ctx *c, float *dst, float *pinned, const float *dev, size_t nbytes)
 {
     // (the kernel-done report comes after the copies have been queued: the copy engine starts behind the kernel either way)
@@ -798,7 +620,7 @@ int arm_kernel_done(lcrc_ctx *c, hipStream_t s)
 }
 
 int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_rows, float *d_post,
-           hipStream_t s, float *const *dbg, int row_first = 0, int row_count = -1, bool timed = true)
+           hipStream_t s, float *const *dbg, int row_first, int row_count, bool timed)
 {
     if (row_count < 0) { row_first = 0; row_count = n_rows; }
     if (c->system != SYS_LCRC) {
@@ -844,127 +666,6 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
 }
 
 // label and count buffers of the decoder on the device (one label slot per frame, one count per utterance)
-// Label buffers: pinned host memory mapped into the device -- the decoder kernel stores its labels and counts where the
-// host reads them (16 B per label, one per ~8 frames: posted writes over PCIe), so a launch queues NO copy command for
-// them.  As copy commands they stood in the device's copy queue, which every context shares in order, behind their 2 ms
-// decoder kernel -- and the next launch's upload of its files behind them (profiles/r05_ab_runs.txt 3).
-// d_labels / d_count are the device's view of h_labels / h_count.
-int ensure_labels(lcrc_ctx *c, size_t n_rows, size_t n_utts)
-{
-    if (n_rows > c->cap_label_rows) {
-        const size_t cap = n_rows + n_rows / 4 + 64;
-        if (c->h_labels) (void)hipHostFree(c->h_labels);
-        c->d_labels = c->h_labels = nullptr;
-        c->cap_label_rows = 0;
-        HIP_TRY(c, pinned_alloc((void **)&c->h_labels, cap * sizeof(lcrc_label), true));
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_labels, c->h_labels, 0));
-        c->cap_label_rows = cap;
-    }
-    if (n_utts > c->cap_label_utts) {
-        const size_t cap = n_utts + n_utts / 4 + 64;
-        if (c->h_count) (void)hipHostFree(c->h_count);
-        c->d_count = c->h_count = nullptr;
-        c->cap_label_utts = 0;
-        HIP_TRY(c, pinned_alloc((void **)&c->h_count, cap * sizeof(int), true));
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&c->d_count, c->h_count, 0));
-        c->cap_label_utts = cap;
-    }
-    return LCRC_OK;
-}
-
-// lcrc_set_decoder_overlap applies to the staged entry points of a context that decodes without reading posteriors back
-bool overlap_on(const lcrc_ctx *c) { return c->dec_overlap && c->dec_P > 0 && !c->readback; }
-
-void swap_decoder_sets(lcrc_ctx *c)
-{
-    std::swap(c->d_post, c->alt.d_post);
-    std::swap(c->d_post_cap, c->alt.d_post_cap);
-    std::swap(c->d_labels, c->alt.d_labels);
-    std::swap(c->h_labels, c->alt.h_labels);
-    std::swap(c->d_count, c->alt.d_count);
-    std::swap(c->h_count, c->alt.h_count);
-    std::swap(c->cap_label_rows, c->alt.cap_label_rows);
-    std::swap(c->cap_label_utts, c->alt.cap_label_utts);
-    c->label_first.swap(c->alt.label_first);
-    std::swap(c->label_utts, c->alt.label_utts);
-    std::swap(c->d_dec_off, c->alt.d_dec_off);
-    std::swap(c->cap_dec_off, c->alt.cap_dec_off);
-    std::swap(c->ev_dec_done, c->alt.ev_dec_done);
-    std::swap(c->dec_pending, c->alt.dec_pending);
-}
-
-// d_post for as many rows as the rest of the frame staging holds (the two sets' buffers grow one call apart)
-int ensure_post_rows(lcrc_ctx *c)
-{
-    if (c->d_post_cap >= c->cap_rows) return LCRC_OK;
-    if (c->d_post) (void)hipFree(c->d_post);
-    c->d_post = nullptr;
-    c->d_post_cap = 0;
-    if (dev_alloc((void **)&c->d_post, c->cap_rows * (size_t)c->nets[2].n_out * sizeof(float)) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(c, LCRC_E_NOMEM, "cannot allocate the second posterior buffer (lcrc_set_decoder_overlap)");
-    }
-    c->d_post_cap = c->cap_rows;
-    return LCRC_OK;
-}
-
-// Start of a staged call under lcrc_set_decoder_overlap: the call works on the set that the call BEFORE the last one used,
-// while the last call's decoder may still be reading and writing the other.
-int begin_overlapped_call(lcrc_ctx *c)
-{
-    if (!overlap_on(c)) return LCRC_OK;
-    swap_decoder_sets(c);
-    // what this call's kernels overwrite was read by the decoder two calls ago: behind it on the device, whether or not
-    // the caller has fetched those labels
-    if (c->dec_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_dec_done, 0));
-    c->dec_pending = false;
-    c->label_utts = 0;
-    return c->cap_rows > 0 ? ensure_post_rows(c) : LCRC_OK;
-}
-
-// Decoder behind the posterior kernel (it stores labels and counts in the pinned buffers itself).  On the launch stream `s`;
-// `staged` calls of a context under lcrc_set_decoder_overlap queue it on the decoder stream instead, behind an event on `s`,
-// and return without waiting for it (lcrc_last_labels / lcrc_prev_labels wait).
-// h_first: host copy of the utterance offsets (first label slot of each utterance).
-int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, int n_rows, const float *d_post,
-                 hipStream_t s, bool staged = false)
-{
-    c->label_utts = 0;
-    if (c->dec_P <= 0 || n_rows <= 0) return LCRC_OK;
-    if (c->out_be) return fail(c, LCRC_E_ARG, "the decoder needs posteriors in host byte order (lcrc_output_configure big_endian=0)");
-    { const int rc = ensure_labels(c, (size_t)n_rows, (size_t)n_utts); if (rc) return rc; }
-    const bool overlap = staged && overlap_on(c);
-    hipStream_t ds = s;
-    if (overlap) {
-        if ((size_t)n_utts + 1 > c->cap_dec_off) {
-            const size_t cap = (size_t)n_utts + n_utts / 4 + 64;
-            if (c->d_dec_off) (void)hipFree(c->d_dec_off);
-            c->d_dec_off = nullptr;
-            c->cap_dec_off = 0;
-            HIP_TRY(c, hipMalloc((void **)&c->d_dec_off, cap * sizeof(int)));
-            c->cap_dec_off = cap;
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->d_dec_off, d_off, (size_t)(n_utts + 1) * sizeof(int), hipMemcpyDeviceToDevice, s));
-        HIP_TRY(c, hipEventRecord(c->ev_post, s));
-        HIP_TRY(c, hipStreamWaitEvent(c->dec_stream, c->ev_post, 0));
-        d_off = c->d_dec_off;
-        ds = c->dec_stream;
-    }
-    PhnDecParams p;
-    memset(&p, 0, sizeof p);
-    p.logpost = d_post; p.off = d_off; p.n_utts = n_utts; p.cols = c->nets[2].n_out;
-    p.P = c->dec_P; p.S = c->dec_S; p.prune = c->dec_prune; p.wpen = c->dec_wpen;
-    p.labels = c->d_labels; p.count = c->d_count;
-    HIP_TRY(c, phndec_launch(p, ds));          // (labels and counts: stored by the kernel straight into the pinned buffers)
-    if (overlap) {
-        HIP_TRY(c, hipEventRecord(c->ev_dec_done, ds));
-        c->dec_pending = true;
-    }
-    c->label_first.assign(h_first, h_first + n_utts);
-    c->label_utts = n_utts;
-    return LCRC_OK;
-}
-
 // Posteriors for a caller's own buffer, launches of 8192 frames and more (posteriors/system=LCRC): the rows are computed in
 // TWO launches that store straight into the pinned buffer, and the host copies the first half into the caller's buffer while
 // the second half is being computed.  What such a call waits for is the host's copy out of the pinned buffer (4.5 MB per 8192
@@ -1109,7 +810,9 @@ void shape_of(const HostNet &h, NetDev &d)
     d.n_ot = (h.n_out + 15) / 16;
 }
 
-}  // namespace
+}  // namespace lcrc_impl
+
+using namespace lcrc_impl;
 
 extern "C" {
 
@@ -1629,509 +1332,10 @@ int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, in
 
 // ---- waveform entry: GPU mel-bank front-end ------------------------------------------------
 
-int lcrc_frontend_configure(lcrc_ctx *c, const lcrc_frontend *cfg)
-{
-    if (!c || !cfg) return LCRC_E_ARG;
-    if ((cfg->wave_format != 1 && cfg->wave_format != 2) || cfg->vector_size < 2 || cfg->vector_size > 512 ||
-        cfg->vector_step < 1 || cfg->sample_freq < 1)
-        return fail(c, LCRC_E_ARG, "lcrc_frontend_configure: bad wave_format / vector_size (2..512) / vector_step / sample_freq");
-    const int nbf = cfg->nbanks_full == -1 ? c->nbanks : cfg->nbanks_full;
-    if (nbf < 3 || nbf < c->nbanks || nbf > 64)
-        return fail(c, LCRC_E_ARG, "lcrc_frontend_configure: nbanks_full must be >= max(3, nbanks) and <= 64");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const int fft = FftSizeFor(cfg->vector_size);
-    if (fft != 256 && fft != 512) return fail(c, LCRC_E_UNSUPPORTED, "lcrc_frontend_configure: frames of 129..512 samples only (FFT 256 / 512)");
-    std::vector<float> ham;
-    BuildHamming(cfg->vector_size, ham);
-    MelFilters mf;
-    BuildMelFilters(nbf, fft, cfg->sample_freq, cfg->lower_freq, cfg->higher_freq, mf);
-    std::vector<double> tw;
-    BuildTwiddles(fft, tw);
-    // contiguous runs of bins per bank: run 2b = bins with bank_of == b, run 2b+1 = bank_of == b+1
-    std::vector<int> runs(4 * (size_t)nbf, 0);
-    for (int b = 0; b < nbf; b++)
-        for (int k = 0; k < 2; k++) {
-            int lo = -1, hi = -1;
-            for (int i = mf.fftlo; i <= mf.ffthi; i++)
-                if (mf.bank_of[i] == b + k) { if (lo < 0) lo = i; hi = i + 1; }
-            runs[2 * b + k] = lo < 0 ? 0 : lo;
-            runs[2 * nbf + 2 * b + k] = lo < 0 ? 0 : hi;
-        }
-    for (void *p : {(void *)c->d_hamming, (void *)c->d_coeffs, (void *)c->d_twiddle, (void *)c->d_runs})
-        if (p) (void)hipFree(p);
-    c->d_hamming = c->d_coeffs = nullptr; c->d_twiddle = nullptr; c->d_runs = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&c->d_hamming, ham.size() * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_coeffs, mf.coeffs.size() * sizeof(float)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_twiddle, tw.size() * sizeof(double)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_runs, runs.size() * sizeof(int)));
-    HIP_TRY(c, hipMemcpy(c->d_hamming, ham.data(), ham.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_coeffs, mf.coeffs.data(), mf.coeffs.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_runs, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
-    c->fe = *cfg;
-    c->fe.nbanks_full = nbf;
-    c->fe_fft = fft;
-    c->fe_ready = true;
-    return LCRC_OK;
-}
-
-int lcrc_frontend_set_ln(lcrc_ctx *c, int form)
-{
-    if (!c) return LCRC_E_ARG;
-    if (form < LCRC_LN_DOUBLE || form > LCRC_LN_GLIBC) return fail(c, LCRC_E_ARG, "lcrc_frontend_set_ln: form must be LCRC_LN_DOUBLE, LCRC_LN_GLIBC_FMA or LCRC_LN_GLIBC");
-    c->fe_ln_form = form;
-    return LCRC_OK;
-}
-
-int lcrc_device_ln(int device_id, int form, const float *x, float *y, long long n)
-{
-    if (n < 0 || (n > 0 && (!x || !y)) || form < LCRC_LN_DOUBLE || form > LCRC_LN_GLIBC) return fail(nullptr, LCRC_E_ARG, "lcrc_device_ln: bad argument");
-    if (n == 0) return LCRC_OK;
-    HIP_TRY(nullptr, hipSetDevice(device_id));
-    float *d = nullptr;
-    HIP_TRY(nullptr, hipMalloc((void **)&d, (size_t)n * sizeof(float)));
-    hipError_t e = hipMemcpy(d, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = frontend_ln_launch(d, (size_t)n, form, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(y, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
-    HIP_TRY(nullptr, e);
-    return LCRC_OK;
-}
-
-static long long fe_samples(const lcrc_ctx *c, long long n_bytes)
-{
-    return c->fe.wave_format == 1 ? n_bytes / 2 : n_bytes;
-}
-
-int lcrc_frontend_frames(const lcrc_ctx *c, long long n_bytes)
-{
-    if (!c || !c->fe_ready || n_bytes < 0) return LCRC_E_ARG;
-    const long long len = fe_samples(c, n_bytes);
-    return len > c->fe.vector_size ? (int)((len - c->fe.vector_size) / c->fe.vector_step + 1) : 1;
-}
-
-// LCRC_TRACE_SLOW_US=N (diagnostic): a waveform call that takes longer than N microseconds prints where it spent them
-struct SlowTrace {
-    long threshold_us;
-    int n = 0;
-    const char *what[12];
-    std::chrono::steady_clock::time_point t[12];
-    SlowTrace() { static const long th = getenv("LCRC_TRACE_SLOW_US") ? atol(getenv("LCRC_TRACE_SLOW_US")) : 0; threshold_us = th; mark("enter"); }
-    void mark(const char *w) { if (threshold_us > 0 && n < 12) { what[n] = w; t[n++] = std::chrono::steady_clock::now(); } }
-    ~SlowTrace()
-    {
-        if (threshold_us <= 0 || n < 2) return;
-        const double total = std::chrono::duration<double, std::micro>(t[n - 1] - t[0]).count();
-        if (total < (double)threshold_us) return;
-        std::string line = "lcrc slow call at " + std::to_string((long long)std::chrono::duration<double, std::micro>(t[0].time_since_epoch()).count() % 100000000LL) +
-                           " us, thread " + std::to_string((long)(size_t)pthread_self() % 1000) + " (" + std::to_string((long)total) + " us):";
-        for (int i = 1; i < n; i++)
-            line += std::string(" ") + what[i] + " +" + std::to_string((long)std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count());
-        fprintf(stderr, "%s\n", line.c_str());
-    }
-};
-
-// Shared by the two waveform entry points: stage the bytes (each utterance at an even offset),
-// run the front-end into d_mel; on return *rows = total frames.
-// Capacity of the pinned / device byte buffers of the waveform entry
-static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
-{
-    if ((size_t)total_bytes + 16 > c->cap_bytes) {
-        if (c->d_bytes) { (void)hipFree(c->d_bytes); (void)hipHostFree(c->h_bytes); }
-        c->d_bytes = c->h_bytes = nullptr; c->cap_bytes = 0;
-        const size_t cap = (size_t)total_bytes + total_bytes / 4 + 4096;
-        HIP_TRY(c, hipMalloc((void **)&c->d_bytes, cap));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, kPinnedMapped));      // (mapped: lcrc_wave_stage_energies pulls it by a kernel)
-        c->cap_bytes = cap;
-    }
-    return LCRC_OK;
-}
-
-// per-utterance offsets and means of the waveform entry (2 * n_utts + 2 entries: sample starts and counts / frame and block offsets)
-static int ensure_fe_utts(lcrc_ctx *c, size_t n_utts)
-{
-    if (2 * n_utts + 2 <= c->cap_fe_utts) return LCRC_OK;
-    if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
-    c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
-    const size_t cap = 2 * n_utts + n_utts / 2 + 64;
-    HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_soff, cap * sizeof(long long), kPinned));
-    HIP_TRY(c, hipMalloc((void **)&c->d_foff, cap * sizeof(int)));
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_foff, cap * sizeof(int), kPinned));
-    HIP_TRY(c, hipMalloc((void **)&c->d_means, cap * 64 * sizeof(float)));
-    c->cap_fe_utts = cap;
-    return LCRC_OK;
-}
-
-// partial sums of the tree mean (lcrc_set_mean_order(0)), one 64-float row per block of rows
-static int ensure_mean_blocks(lcrc_ctx *c, size_t blocks)
-{
-    if (blocks <= c->cap_mean_blocks) return LCRC_OK;
-    if (c->d_mean_part) (void)hipFree(c->d_mean_part);
-    c->d_mean_part = nullptr; c->cap_mean_blocks = 0;
-    const size_t cap = blocks + blocks / 4 + 64;
-    HIP_TRY(c, hipMalloc((void **)&c->d_mean_part, cap * 64 * sizeof(float)));
-    c->cap_mean_blocks = cap;
-    return LCRC_OK;
-}
-
-// The front-end over utterances that already lie in the pinned byte buffer: utterance u = bytes
-// [start[u], start[u] + len[u]) of c->h_bytes.  Leaves the features in c->d_mel.
-static int run_frontend_staged(lcrc_ctx *c, const long long *start, const long long *len, int n_utts,
-                               long long extent, int *frame_off, int *rows, bool raw_energies = false, SlowTrace *st = nullptr)
-{
-    long long total_frames = 0;
-    for (int u = 0; u < n_utts; u++) total_frames += lcrc_frontend_frames(c, len[u]);
-    if (total_frames > 0x7fffffffLL / 256) return fail(c, LCRC_E_ARG, "waveform entry: too many frames for one call");
-    { const int rc = ensure_fe_utts(c, (size_t)n_utts); if (rc) return rc; }
-    const int unit = c->fe.wave_format == 1 ? 2 : 1;
-    c->h_foff[0] = 0;
-    int *const h_boff = c->h_foff + n_utts + 1;      // block offsets of the tree mean, behind the frame offsets
-    h_boff[0] = 0;
-    for (int u = 0; u < n_utts; u++) {               // h_soff: [start of u ...][sample count of u ...]
-        c->h_soff[u] = start[u] / unit;
-        c->h_soff[n_utts + u] = fe_samples(c, len[u]);
-        const int fr = lcrc_frontend_frames(c, len[u]);
-        c->h_foff[u + 1] = c->h_foff[u] + fr;
-        h_boff[u + 1] = h_boff[u] + meannorm_blocks(fr);
-    }
-    c->mean_blocks = h_boff[n_utts];
-    { const int rc = ensure_mean_blocks(c, (size_t)c->mean_blocks); if (rc) return rc; }
-    for (int u = 0; u < n_utts; u++) frame_off[u] = c->h_foff[u];
-    if (n_utts >= 0) frame_off[n_utts] = c->h_foff[n_utts];
-    *rows = (int)total_frames;
-    if (total_frames == 0) return LCRC_OK;
-    if (st) st->mark("offsets");
-    int rc = ensure_staging(c, (size_t)total_frames, (size_t)n_utts);
-    if (rc) return rc;
-    if (st) st->mark("staging");
-    // The energies entry keeps its two transfers out of the copy engine's queue, which every context of the device shares
-    // in order: the samples are pulled by a kernel, the energies stored straight into the pinned feature buffer.  As copy
-    // commands they stood behind other contexts' 24 MB of posteriors on their way back, which wait for those contexts'
-    // kernels (-E: 24.7 M frames/s on one GPU with them).
-    float *mel_out = c->d_mel;
-    // (-E with the upload as a copy command and only the energies stored directly: 20.8-24.7 M; -F with its upload pulled
-    //  by the kernel instead of copied: 27.4 against 28.7 M -- a caller that does not wait in between is better off with
-    //  the copy engine; profiles/r04_ab_runs.txt 18)
-    if (raw_energies) {
-        void *src = nullptr;
-        HIP_TRY(c, hipHostGetDevicePointer(&src, c->h_bytes, 0));
-        HIP_TRY(c, pull_bytes_launch(src, c->d_bytes, (size_t)extent, c->stream));
-        HIP_TRY(c, hipHostGetDevicePointer((void **)&mel_out, c->h_mel, 0));
-    } else {
-        HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)extent, hipMemcpyHostToDevice, c->stream));
-    }
-    if (st) st->mark("bytes copy queued");
-    HIP_TRY(c, hipMemcpyAsync(c->d_soff, c->h_soff, (size_t)(2 * n_utts) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_foff, c->h_foff, (size_t)(2 * n_utts + 2) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if (st) st->mark("offset copies queued");
-    FrontendParams p;
-    memset(&p, 0, sizeof p);
-    p.bytes = c->d_bytes; p.sample_start = c->d_soff; p.frame_off = c->d_foff; p.mel = mel_out;
-    p.hamming = c->d_hamming; p.twiddle = c->d_twiddle; p.coeffs = c->d_coeffs;
-    p.run_begin = c->d_runs; p.run_end = c->d_runs + 2 * c->fe.nbanks_full;
-    p.n_utts = n_utts; p.n_frames = (int)total_frames; p.nbanks = c->nbanks; p.fft = c->fe_fft;
-    p.wave_format = c->fe.wave_format; p.vector_size = c->fe.vector_size; p.vector_step = c->fe.vector_step;
-    p.dc_shift = c->fe.dc_shift; p.scale = c->fe.scale; p.preem_coef = c->fe.preem_coef;
-    p.z_mean_source = c->fe.z_mean_source;
-    p.raw_energies = raw_energies ? 1 : 0;
-    p.ln_form = c->fe_ln_form;
-    HIP_TRY(c, frontend_launch(p, c->stream));
-    return LCRC_OK;
-}
-
-static int run_frontend(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
-                        int *frame_off, int *rows)
-{
-    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
-    if (n_utts < 0 || (n_utts > 0 && (!bytes || !byte_off || !frame_off)) || (n_utts > 0 && byte_off[0] != 0))
-        return fail(c, LCRC_E_ARG, "waveform entry: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    long long total_bytes = 0;
-    for (int u = 0; u < n_utts; u++) {
-        const long long nb = byte_off[u + 1] - byte_off[u];
-        if (nb < 0) return fail(c, LCRC_E_ARG, "waveform entry: offsets must be non-decreasing");
-        total_bytes += nb + (nb & 1);
-    }
-    int rc = ensure_wave_bytes(c, total_bytes);
-    if (rc) return rc;
-    std::vector<long long> start((size_t)std::max(n_utts, 0)), len((size_t)std::max(n_utts, 0));
-    long long pos = 0;
-    for (int u = 0; u < n_utts; u++) {
-        const long long nb = byte_off[u + 1] - byte_off[u];
-        memcpy(c->h_bytes + pos, bytes + byte_off[u], (size_t)nb);
-        start[u] = pos; len[u] = nb;
-        pos += nb + (nb & 1);                        // keep lin16 utterances 2-byte aligned
-    }
-    return run_frontend_staged(c, start.data(), len.data(), n_utts, pos, frame_off, rows);
-}
-
-int lcrc_wave_to_mel(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
-                     float *mel, int *frame_off)
-{
-    if (!c) return LCRC_E_ARG;
-    int rows = 0;
-    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
-    if (rc || rows == 0) return rc;
-    if (!mel) return fail(c, LCRC_E_ARG, "lcrc_wave_to_mel: NULL output");
-    const size_t nbytes = (size_t)rows * c->nbanks * sizeof(float);
-    HIP_TRY(c, hipMemcpyAsync(c->h_mel, c->d_mel, nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, wait_stream(c));
-    memcpy(mel, c->h_mel, nbytes);
-    return LCRC_OK;
-}
-
-// the part of the waveform -> posteriors entries behind the front-end
-static int wave_finish(lcrc_ctx *c, int n_utts, int rows, float *post, SlowTrace *st = nullptr, bool staged = false)
-{
-    const bool copy_post = c->readback || c->dec_P <= 0;
-    if (c->fe.sent_mean_norm) {
-        int longest = 0;                         // (h_foff: the host copy of this call's frame offsets)
-        for (int u = 0; u < n_utts; u++) longest = std::max(longest, c->h_foff[u + 1] - c->h_foff[u]);
-        HIP_TRY(c, meannorm_launch(c->d_mel, c->d_foff, c->mean_sequential ? nullptr : c->d_foff + n_utts + 1, c->mean_blocks,
-                                   c->d_mean_part, n_utts, rows, c->nbanks, c->d_means, longest, c->stream));
-    }
-    if (st) st->mark("mean queued");
-    if (copy_post && c->dec_P <= 0) {
-        bool done = false;
-        const int rc2 = two_part_output(c, c->d_mel, c->d_foff, n_utts, rows, post, &done);
-        if (rc2 || done) { if (!rc2) c->label_utts = 0; return rc2; }
-    }
-    float *out_dev = c->d_post;
-    bool direct = false;
-    int rc = output_target(c, copy_post, post == nullptr, &out_dev, &direct);
-    if (rc) return rc;
-    rc = launch(c, c->d_mel, c->d_foff, n_utts, rows, out_dev, c->stream, nullptr);
-    if (rc) return rc;
-    if (st) st->mark("kernels queued");
-    rc = decode_after(c, c->d_foff, c->h_foff, n_utts, rows, c->d_post, c->stream, staged);
-    if (rc) return rc;
-    const size_t nbytes = (size_t)rows * c->nets[2].n_out * sizeof(float);
-    if (copy_post && direct) {
-        HIP_TRY(c, wait_stream(c));
-        if (post) memcpy(post, c->h_post, nbytes);
-    } else if (copy_post) {
-        rc = ensure_host_post(c);
-        if (rc) return rc;
-        if (st) st->mark("host buffer");
-        HIP_TRY(c, copy_back(c, post, c->h_post, c->d_post, nbytes));   // post == NULL: read them in place (lcrc_staged_posteriors)
-    } else {
-        HIP_TRY(c, wait_stream(c));
-    }
-    if (st) st->mark("done");
-    return LCRC_OK;
-}
-
-int lcrc_staged_posteriors(lcrc_ctx *c, const float **post)
-{
-    if (!c || !post) return LCRC_E_ARG;
-    *post = c->h_post;
-    return LCRC_OK;
-}
-
-int lcrc_wave_to_posteriors(lcrc_ctx *c, const unsigned char *bytes, const long long *byte_off, int n_utts,
-                            float *post, int *frame_off)
-{
-    if (!c) return LCRC_E_ARG;
-    int rows = 0;
-    int rc = run_frontend(c, bytes, byte_off, n_utts, frame_off, &rows);
-    if (rc || rows == 0) { c->label_utts = 0; return rc; }
-    if (!post && (c->readback || c->dec_P <= 0)) return fail(c, LCRC_E_ARG, "lcrc_wave_to_posteriors: NULL output");
-    return wave_finish(c, n_utts, rows, post);
-}
-
-int lcrc_wave_stage_buffer(lcrc_ctx *c, long long capacity, unsigned char **bytes)
-{
-    if (!c || capacity < 0 || !bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_buffer: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_wave_bytes(c, capacity);
-    if (rc) return rc;
-    *bytes = c->h_bytes;
-    return LCRC_OK;
-}
-
-// Every buffer a later call of up to max_rows frames in max_utts utterances (and max_wave_bytes of waveform, 0: the
-// frame entries only) would allocate on demand, allocated now: device staging, pinned features and posteriors, byte
-// buffers, per-utterance offsets.  What on-demand growth costs is page pinning -- 744 B per HU frame, ~8 ms per
-// 32 768 frames -- inside the first call; a caller with a warm-up phase (the CLI, while its list is still being opened)
-// pays it there, all contexts at once.
-int lcrc_reserve(lcrc_ctx *c, int max_rows, int max_utts, long long max_wave_bytes)
-{
-    if (!c) return LCRC_E_ARG;
-    if (max_rows < 0 || max_utts < 0 || max_wave_bytes < 0) return fail(c, LCRC_E_ARG, "lcrc_reserve: negative size");
-    if (max_wave_bytes > 0 && !c->fe_ready) return fail(c, LCRC_E_ARG, "lcrc_reserve: waveform bytes asked for before lcrc_frontend_configure");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_staging(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
-    if (rc) return rc;
-    if (c->readback || c->dec_P <= 0) {
-        rc = ensure_host_post(c);
-        if (rc) return rc;
-    }
-    if (c->system == SYS_LCRC && !c->d_part && c->split_hint != 1 && c->arith == 0) ensure_split_scratch(c);
-    if (c->dec_P > 0) {
-        rc = ensure_labels(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
-        if (rc) return rc;
-        if (overlap_on(c)) {                     // the second set: posterior buffer and labels
-            swap_decoder_sets(c);
-            rc = ensure_post_rows(c);
-            if (!rc) rc = ensure_labels(c, (size_t)std::max(max_rows, 1), (size_t)max_utts);
-            swap_decoder_sets(c);
-            if (rc) return rc;
-        }
-    }
-    if (max_wave_bytes > 0) {
-        rc = ensure_wave_bytes(c, max_wave_bytes);
-        if (rc) return rc;
-        rc = ensure_fe_utts(c, (size_t)max_utts);
-        if (rc) return rc;
-        rc = ensure_mean_blocks(c, (size_t)meannorm_blocks(max_rows) + (size_t)max_utts);
-        if (rc) return rc;
-    }
-    // The copy engines.  The runtime creates an SDMA queue the first time it uses an engine (~13 ms each, startup_probe:
-    // "first copy"), and picks a further engine whenever the ones it has are busy -- which, with several contexts copying
-    // bytes in and posteriors out at once, happened twice in the first 40 ms of every list, EVERY copy of the process waiting
-    // meanwhile (tools/pipeline_trace.py: hipMemcpyAsync blocking 13-15 ms).  So the buffers make a few round trips now, in
-    // both directions at once; contexts reserved from parallel threads overlap the way a list's launches will.
-    if (max_rows >= 4096) {
-        const size_t post_bytes = (size_t)max_rows * c->nets[2].n_out * sizeof(float);
-        const size_t mel_bytes = (size_t)max_rows * c->nbanks * sizeof(float);
-        for (int round = 0; round < 3; round++) {
-            if (max_wave_bytes > 0) HIP_TRY(c, hipMemcpyAsync(c->d_bytes, c->h_bytes, (size_t)max_wave_bytes, hipMemcpyHostToDevice, c->stream));
-            else HIP_TRY(c, hipMemcpyAsync(c->d_mel, c->h_mel, mel_bytes, hipMemcpyHostToDevice, c->stream));
-            if (c->h_post) {                                   // in pieces, the way copy_back() queues them
-                const size_t step = ((post_bytes / kCopyPieces) + 255) & ~(size_t)255;
-                for (int k = 0; k < kCopyPieces; k++) {
-                    const size_t lo = (size_t)k * step, n = k + 1 == kCopyPieces ? post_bytes - lo : step;
-                    HIP_TRY(c, hipMemcpyAsync((char *)c->h_post + lo, (const char *)c->d_post + lo, n, hipMemcpyDeviceToHost, c->stream));
-                }
-            }
-        }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return LCRC_OK;
-}
-
-int lcrc_wave_stage_energies(lcrc_ctx *c, const long long *start, const long long *n_bytes, int n_utts, float **energies,
-                             int *frame_off)
-{
-    if (!c) return LCRC_E_ARG;
-    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
-    if (n_utts < 0 || !energies || (n_utts > 0 && (!start || !n_bytes || !frame_off)))
-        return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: bad argument");
-    *energies = nullptr;
-    HIP_TRY(c, hipSetDevice(c->device));
-    long long extent = 0;
-    for (int u = 0; u < n_utts; u++) {
-        if (start[u] < extent || n_bytes[u] < 0 || (c->fe.wave_format == 1 && (start[u] & 1)))
-            return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: utterances must be in order, not overlap, and start on even bytes (lin16)");
-        extent = start[u] + n_bytes[u];
-    }
-    if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_energies: beyond the capacity lcrc_wave_stage_buffer reserved");
-    int rows = 0;
-    int rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, true);
-    if (rc || rows == 0) return rc;
-    rc = ensure_host_post(c);                    // lcrc_stage_run follows: everything it needs exists now and will not move
-    if (rc) return rc;
-    c->kdone_armed = false;
-    HIP_TRY(c, wait_stream(c));                  // (the kernel has stored the energies in the pinned buffer itself)
-    *energies = c->h_mel;
-    return LCRC_OK;
-}
-
-int lcrc_wave_stage_run(lcrc_ctx *c, const long long *start, const long long *n_bytes, int n_utts, float *post,
-                        int *frame_off)
-{
-    if (!c) return LCRC_E_ARG;
-    if (!c->fe_ready) return fail(c, LCRC_E_ARG, "waveform entry used before lcrc_frontend_configure");
-    if (n_utts < 0 || (n_utts > 0 && (!start || !n_bytes || !frame_off))) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    long long extent = 0;
-    for (int u = 0; u < n_utts; u++) {
-        if (start[u] < extent || n_bytes[u] < 0 || (c->fe.wave_format == 1 && (start[u] & 1)))
-            return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: utterances must be in order, not overlap, and start on even bytes (lin16)");
-        extent = start[u] + n_bytes[u];
-    }
-    if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: beyond the capacity lcrc_wave_stage_buffer reserved");
-    int rows = 0;
-    SlowTrace st;
-    int rc = post ? LCRC_OK : begin_overlapped_call(c);
-    if (rc) return rc;
-    rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, false, &st);
-    if (rc || rows == 0) { c->label_utts = 0; return rc; }
-    if (!post && overlap_on(c)) { rc = ensure_post_rows(c); if (rc) return rc; }      // (the staging may just have grown)
-    st.mark("front-end queued");
-    return wave_finish(c, n_utts, rows, post, &st, post == nullptr);
-}
-
-int lcrc_decoder_configure(lcrc_ctx *c, int n_phonemes, int states_per_phn, int time_pruning, float wpenalty)
-{
-    if (!c) return LCRC_E_ARG;
-    if (n_phonemes == 0) { c->dec_P = 0; c->label_utts = 0; return LCRC_OK; }
-    if (n_phonemes < 0 || n_phonemes > 64 || states_per_phn < 1 || states_per_phn > 4 || time_pruning < 1 ||
-        time_pruning > 63 || n_phonemes * states_per_phn > c->nets[2].n_out)
-        return fail(c, LCRC_E_UNSUPPORTED, "lcrc_decoder_configure: needs <= 64 phonemes, <= 4 states, time_pruning <= 63, "
-                                          "phonemes x states <= posterior outputs");
-    c->dec_P = n_phonemes; c->dec_S = states_per_phn; c->dec_prune = time_pruning; c->dec_wpen = wpenalty;
-    return LCRC_OK;
-}
-
-int lcrc_set_posterior_readback(lcrc_ctx *c, int enabled)
-{
-    if (!c) return LCRC_E_ARG;
-    c->readback = enabled != 0;
-    return LCRC_OK;
-}
-
 int lcrc_set_launch_order(lcrc_ctx *c, int ordered)
 {
     if (!c) return LCRC_E_ARG;
     c->launch_ordered = ordered != 0;
-    return LCRC_OK;
-}
-
-int lcrc_set_decoder_overlap(lcrc_ctx *c, int enabled)
-{
-    if (!c) return LCRC_E_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (c->dec_stream) HIP_TRY(c, hipStreamSynchronize(c->dec_stream));
-    c->dec_pending = c->alt.dec_pending = false;
-    if (enabled && !c->dec_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->dec_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_dec_done, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->alt.ev_dec_done, hipEventDisableTiming));
-    }
-    c->dec_overlap = enabled != 0;
-    return LCRC_OK;
-}
-
-int lcrc_prev_labels(lcrc_ctx *c, const lcrc_label **labels, const int **first, const int **count, int *n_utts)
-{
-    if (!c || !labels || !first || !count || !n_utts) return LCRC_E_ARG;
-    if (c->alt.dec_pending) {
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, wait_event(c, c->alt.ev_dec_done));
-        c->alt.dec_pending = false;
-    }
-    *labels = c->alt.h_labels;
-    *first = c->alt.label_first.data();
-    *count = c->alt.h_count;
-    *n_utts = c->alt.label_utts;
-    return LCRC_OK;
-}
-
-int lcrc_last_labels(lcrc_ctx *c, const lcrc_label **labels, const int **first, const int **count, int *n_utts)
-{
-    if (!c || !labels || !first || !count || !n_utts) return LCRC_E_ARG;
-    if (c->dec_pending) {
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, wait_event(c, c->ev_dec_done));
-        c->dec_pending = false;
-    }
-    *labels = c->h_labels;
-    *first = c->label_first.data();
-    *count = c->h_count;
-    *n_utts = c->label_utts;
     return LCRC_OK;
 }
 
