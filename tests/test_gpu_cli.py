@@ -213,6 +213,27 @@ def test_two_gpus_called_as_the_reference_take_the_gpu_front_end(tmp_path):
     assert " mode=F,auto " in b.stderr and " mode=host " in c.stderr
 
 
+def test_host_whose_libm_is_not_glibcs_takes_the_energies_road(tmp_path):
+    """PHNREC_LN_FORM=0 stands in for a host whose logf matches neither of glibc's sequences: a list over two GPUs then selects
+    -E by itself (its ln() is the host's own libm whatever that is) -- mode E,auto, and E+D,auto from four --, the MLF stays
+    the host front-end's byte for byte; -F given explicitly still runs, with log() in double (labels equal, features within
+    one ulp: the posterior dump within 1e-4 of the host front-end's)"""
+    lst = _make_list(tmp_path, "hu", 120, seed=37)
+    one, two, four = tmp_path / "g1.mlf", tmp_path / "g2.mlf", tmp_path / "g4.mlf"
+    run("-c", model_dir(HU), "-l", lst, "-m", one)
+    b = run("-c", model_dir(HU), "-l", lst, "-m", two, "-g", 2,
+            env={"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0", "PHNREC_LN_FORM": "0"})
+    c = run("-c", model_dir(HU), "-l", lst, "-m", four, "-g", 4,
+            env={"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": "0,0,0,0", "PHNREC_LN_FORM": "0"})
+    assert " mode=E,auto " in b.stderr and " mode=E+D,auto " in c.stderr
+    assert one.read_text() == two.read_text() == four.read_text()
+    raw = os.path.join(GOLD, "test.raw")
+    a, f = tmp_path / "host.lop", tmp_path / "f.lop"
+    run("-c", model_dir(HU), "-i", raw, "-t", "post", "-o", a)
+    run("-c", model_dir(HU), "-i", raw, "-t", "post", "-o", f, "-F", env={"PHNREC_LN_FORM": "0"})
+    assert np.abs(read_htk(str(a)) - read_htk(str(f))).max() < 1e-4
+
+
 @pytest.mark.parametrize("system", [CZ, EN, HU, RU])
 def test_gpu_front_end_flag_is_the_host_front_end_bit_for_bit(system, tmp_path):
     """-F with ln() taken as THIS host's libm takes it (lcrc_frontend_set_ln: glibc's logf sequence, in the build the CLI found
