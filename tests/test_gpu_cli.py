@@ -361,10 +361,11 @@ def test_sentence_maximum_normalisations(tmp_path):
 
 def test_fuzzed_lists_and_pipeline_settings():
     """tools/fuzz_cli.py with a fixed seed: random lists (empty files, files shorter than a frame, exactly one frame, up to
-    20 s, sometimes an unreadable name) through random batch sizes, logical GPU counts, host thread counts and the three
-    modes -- every configuration writes the MLF (or fails where) its mode's plain run does, within the time limit"""
+    20 s, sometimes an unreadable name) through random batch sizes, logical GPU counts, host thread counts, the five modes
+    (host front-end, -E, -E -D, -F, -F -D), contexts per GPU, launch order and decoder overlap on / off -- every configuration
+    writes the MLF (or fails where) the plain host-front-end run does, byte for byte, within the time limit"""
     from tools import fuzz_cli
-    assert fuzz_cli.fuzz(seed=20261004, n_lists=3, log=lambda *a: None) == 27
+    assert fuzz_cli.fuzz(seed=20261004, n_lists=3, log=lambda *a: None) == 45
 
 
 def test_lcrc_at_another_length_end_to_end(tmp_path):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised run of the CLI's list pipeline (GPU): random lists -- files of 0 bytes, less than a frame, exactly a frame, up to
 20 s, optionally one unreadable name --, random batch sizes (-b), logical GPU counts (-g N on the one device), host threads
-(-j) and modes (host front-end, -F, -F -D): every configuration must write the MLF its mode's plain run writes (or fail the
-same way), and none may hang (each run has a time limit).     usage: fuzz_cli.py [seed [lists]]"""
+(-j), modes (host front-end, -E, -E -D, -F, -F -D), contexts per GPU, launch order and decoder overlap on / off: every
+configuration must write the MLF the plain host-front-end run writes, byte for byte (every mode's features and labels are
+the host's), or fail the same way, and none may hang (each run has a time limit).     usage: fuzz_cli.py [seed [lists]]"""
 import os
 import subprocess
 import sys
@@ -40,11 +41,11 @@ def fuzz(seed=0, n_lists=12, log=print):
                 names.insert(int(rng.integers(0, len(names) + 1)), os.path.join(td, "missing.raw"))
             lst = os.path.join(td, "list.scp")
             open(lst, "w").write("".join(n + "\n" for n in names))
-            for mode in ([], ["-F"], ["-F", "-D"]):
-                ref_mlf = os.path.join(td, "ref.mlf")
-                rc0, err0 = run(["-c", MODEL, "-l", lst, "-m", ref_mlf] + mode)
-                assert (rc0 != 0) == bad, (seed, it, mode, rc0, err0[-300:])
-                want = open(ref_mlf).read() if os.path.exists(ref_mlf) else None
+            ref_mlf = os.path.join(td, "ref.mlf")
+            rc0, err0 = run(["-c", MODEL, "-l", lst, "-m", ref_mlf], env={"PHNREC_NO_AUTO_E": "1", "PHNREC_NO_AUTO_D": "1"})
+            assert (rc0 != 0) == bad, (seed, it, rc0, err0[-300:])
+            want = open(ref_mlf).read() if os.path.exists(ref_mlf) else None
+            for mode in ([], ["-E"], ["-E", "-D"], ["-F"], ["-F", "-D"]):
                 for _ in range(3):
                     g = int(rng.choice([1, 1, 2, 3, 4]))
                     b = int(rng.choice([64, 700, 5000, 32768, 200000]))
@@ -52,10 +53,15 @@ def fuzz(seed=0, n_lists=12, log=print):
                     out = os.path.join(td, "o.mlf")
                     if os.path.exists(out):
                         os.remove(out)
-                    rc, err = run(["-c", MODEL, "-l", lst, "-m", out, "-g", g, "-b", b, "-j", j] + mode,
-                                  env={"PHNREC_DEVICE_MAP": ",".join(["0"] * g)})
+                    env = {"PHNREC_DEVICE_MAP": ",".join(["0"] * g)}
+                    for name, choices in (("PHNREC_CTX_PER_GPU", ["", "1", "2", "3", "4"]), ("PHNREC_LAUNCH_ORDER", ["", "0", "1"]),
+                                          ("PHNREC_DECODER_OVERLAP", ["", "0", "1"])):
+                        v = str(rng.choice(choices))
+                        if v:
+                            env[name] = v
+                    rc, err = run(["-c", MODEL, "-l", lst, "-m", out, "-g", g, "-b", b, "-j", j] + mode, env=env)
                     got = open(out).read() if os.path.exists(out) else None
-                    assert rc == rc0 and got == want, (seed, it, mode, g, b, j, rc, err[-300:])
+                    assert rc == rc0 and got == want, (seed, it, mode, g, b, j, env, rc, err[-300:])
                     runs += 1
     log("cli fuzz ok: %d lists, %d configurations" % (n_lists, runs))
     return runs
