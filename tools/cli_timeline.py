@@ -2,7 +2,9 @@
 """Where a CLI list run's wall clock goes on the GPU: runs `phnrec` on the configs[3] list under rocprofv3 --kernel-trace
 and reports, per kernel, calls / total / average, and the UNION of the kernels' busy intervals against the span from the
 first launch to the last (idle share = the host could not keep the device fed).  usage: cli_timeline.py [files] [flags...]
-env TIMELINE_REPS=n: every file listed n times (a list loop of seconds); TIMELINE_ROWS=k: the first k launches one by one."""
+env TIMELINE_REPS=n: every file listed n times (a list loop of seconds); TIMELINE_ROWS=k: the first k launches one by one;
+TIMELINE_PAR=1: the list's files are first turned into parameter files (`-t par`, host front-end) and the traced run reads
+those (`-s par`): no front-end kernels on the device, only the posterior kernels (and the decoder's with -D)."""
 import csv
 import glob
 import os
@@ -23,6 +25,16 @@ def main():
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         lst, names, frames = bench.synthetic_list(td, n_files)
         reps = int(os.environ.get("TIMELINE_REPS", "1"))
+        if os.environ.get("TIMELINE_PAR"):
+            par_lst = os.path.join(td, "par.scp")
+            with open(par_lst, "w") as f:
+                f.write("".join("%s %s.mel\n" % (n, n) for n in names))
+            subprocess.run([exe, "-c", mdir, "-l", par_lst, "-t", "par"], check=True, capture_output=True)
+            names = [n + ".mel" for n in names]
+            lst = os.path.join(td, "mel.scp")
+            with open(lst, "w") as f:
+                f.write("".join(n + "\n" for n in names))
+            flags = ["-s", "par"] + flags
         if reps > 1:
             lst = os.path.join(td, "rep.scp")
             with open(lst, "w") as f:
