@@ -527,17 +527,22 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         #  libm's own sequence, else -E; the same output bytes either way: `host_frontend` then IS that road ("mode" says
         #  which); PHNREC_NO_AUTO_E=1 would keep the pure host front-end)
         out["host_frontend_takes_gpu_road"] = n_gpus >= 2
+        out["default_flags_on_one_gpu"] = "a list of ~100 files or more takes -F by itself (mode F,auto): see gpu_frontend_F"
         # (and from four GPUs on a list that ends in labels decodes on the GPUs by itself -- bit-identical labels, the
         #  Viterbi off the host's cores: every mode below is then `... -D`; PHNREC_NO_AUTO_D=1 would keep the host decoder)
         out["every_mode_decodes_on_the_gpu"] = n_gpus >= 4
         env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=",".join(str(d) for d in dmap))
         mlfs = {}
+        # (on ONE GPU a list of this length called without flags takes the GPU front-end by itself too -- `gpu_frontend_F` is
+        #  that road; `host_frontend` there is run with PHNREC_NO_AUTO_E=1 so that it keeps measuring the host front-end)
+        host_env = dict(env, PHNREC_NO_AUTO_E="1") if n_gpus == 1 else env
         for key, extra in LIST_MODES:
             mlf = os.path.join(td, key + ".mlf")
             try:
                 best = None
                 for _ in range(2):                    # the better of two runs (the first also warms the page cache)
-                    r, _pr = run_cli(exe, ["-c", mdir, "-l", lst, "-m", mlf, "-g", str(n_gpus)] + extra, env)
+                    r, _pr = run_cli(exe, ["-c", mdir, "-l", lst, "-m", mlf, "-g", str(n_gpus)] + extra,
+                                     host_env if key == "host_frontend" else env)
                     if "error" in r or best is None or r["value"] > best["value"]:
                         best = r
                     if "error" in r:
@@ -578,7 +583,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             return r
         for key, extra in LIST_MODES:
             try:
-                weak[key] = weak_run(extra, n_gpus, env)
+                weak[key] = weak_run(extra, n_gpus, host_env if key == "host_frontend" else env)
             except Exception as e:
                 weak[key] = {"error": repr(e)}
         if n_gpus == 1:
@@ -608,7 +613,8 @@ def sharded_list_leg(n_gpus, dmap, n_files):
             cz = {}
             for key, extra in (("host_frontend", []), ("gpu_frontend_F", ["-F"])):
                 try:
-                    r, _pr = run_cli(exe, ["-c", cz_dir, "-l", lst, "-m", os.path.join(td, "cz.mlf"), "-g", str(n_gpus)] + extra, env)
+                    r, _pr = run_cli(exe, ["-c", cz_dir, "-l", lst, "-m", os.path.join(td, "cz.mlf"), "-g", str(n_gpus)] + extra,
+                                     host_env if key == "host_frontend" else env)
                     cz[key] = r
                 except Exception as e:
                     cz[key] = {"error": repr(e)}

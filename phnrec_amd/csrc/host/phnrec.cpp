@@ -37,7 +37,8 @@ static void Help()
     puts(" -g num [1]         number of GPUs to spread a file list over (MI355X build)");
     puts(" -b num [32768]     frames per GPU launch when batching a file list (65536 with -D)");
     puts(" -j num [all]       host threads for the front-end and the decoder");
-    puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device)");
+    puts(" -F                 mel-bank front-end on the GPU too (waveform -> posteriors on the device; the host front-end's\n"
+         "                    features bit for bit where the host's libm is glibc's: lists take it by themselves)");
     puts(" -E                 the front-end's FFTs and bank sums on the GPU, ln() and the normalisations on the host:\n"
          "                    the host front-end's features bit for bit, at a tenth of its CPU time");
     puts(" -D                 phoneme-loop decoder on the GPU too (only labels leave the device)");

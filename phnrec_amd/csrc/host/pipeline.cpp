@@ -170,24 +170,25 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         pool_.reset(new ThreadPool(threads > 1 ? threads : 0));
     }
     const bool need_gpu = (in == dfWaveform || in == dfParams) && (out == dfPosteriors || out == dfStrings);
-    // A list over two or more GPUs, called as the reference is called (no -F, no -E): the host front-end's 0.36 us per
-    // frame and core would feed 1.4 GPUs on 16 cores.  -E produces the same features bit for bit (tests compare dumps and
-    // MLFs byte for byte) at a fifth of the CPU time, so it is switched on by itself there -- where the GPU front-end takes
-    // the configuration at all (GpuFrontendTakesConfig: the limits lcrc_frontend_configure enforces; anything else keeps
-    // the host front-end as before) --; one GPU is served faster by the host front-end and keeps it.
-    // PHNREC_NO_AUTO_E=1 keeps the host front-end whatever -g says.  The choice lives in auto_energies_ / auto_decoder_:
-    // what the caller set (SetGpuEnergies, SetGpuDecoder) is never overwritten.
+    // A list called as the reference is called (no -F, no -E) takes the GPU front-end by itself:
+    //   -F (the whole front-end) where its features are the host front-end's bit for bit -- ln() as this host's libm takes it
+    //      (LibmLogfForm: glibc) and a configuration that asks for nothing only the host / -E road does (framenorm/*,
+    //      sent_max_norm, sent_chmax_norm) -- from ONE GPU on, for lists of at least ~100 files (long_list_): the same bytes
+    //      out (tests compare dumps and MLFs byte for byte), the same or a higher rate on one GPU (configs[3] list x 8: 32.3
+    //      against 30.9 M frames/s) at an eighth of the host's CPU time (3.6 against 30.6 CPU-s), and the only road on which
+    //      the host side feeds more than one GPU (the host front-end's 0.36 us per frame and core feeds 1.2 on 16 cores);
+    //   -E (the energies; ln() and normalisations on the host: the same bits on any libm) from TWO GPUs on otherwise;
+    // where the GPU front-end takes the configuration at all (GpuFrontendTakesConfig: the limits lcrc_frontend_configure
+    // enforces; anything else keeps the host front-end).  One file, and short lists on one GPU, keep the host front-end.
+    // PHNREC_NO_AUTO_E=1 keeps it whatever the list and -g say.  The choice lives in auto_frontend_ / auto_energies_ /
+    // auto_decoder_: what the caller set (SetGpuFrontend, SetGpuEnergies, SetGpuDecoder) is never overwritten.
     if (gpus_.empty()) {
-        const bool auto_gpu_features = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ &&
-                                       n_gpus_ >= 2 && wave_.noise_level == 0.0f && GpuFrontendTakesConfig() &&
-                                       !getenv("PHNREC_NO_AUTO_E");
-        // ... the whole front-end (-F) where its ln() is this host's libm's own (LibmLogfForm: glibc) and the configuration
-        // asks for nothing that only the host / -E road does (framenorm/*, sent_max_norm, sent_chmax_norm): the same bits
-        // again, no round trip of the energies, a seventh of -E's host CPU time.  Otherwise the energies (-E).
-        const bool whole = auto_gpu_features && LibmLogfForm() != 0 && C.GetFloat("framenorm", "shift") == 0.0f &&
-                           C.GetFloat("framenorm", "min_floor") == -9999.9f && !sent_max_norm_ && !sent_chmax_norm_;
-        auto_frontend_ = whole;
-        auto_energies_ = auto_gpu_features && !whole;
+        const bool eligible = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ &&
+                              wave_.noise_level == 0.0f && GpuFrontendTakesConfig() && !getenv("PHNREC_NO_AUTO_E");
+        const bool same_bits = eligible && LibmLogfForm() != 0 && C.GetFloat("framenorm", "shift") == 0.0f &&
+                               C.GetFloat("framenorm", "min_floor") == -9999.9f && !sent_max_norm_ && !sent_chmax_norm_;
+        auto_frontend_ = same_bits && (n_gpus_ >= 2 || long_list_);
+        auto_energies_ = eligible && !same_bits && n_gpus_ >= 2;
         // A list over four or more GPUs that ends in labels: the decoder runs on the GPUs too (-D) by itself.  Its labels are
         // the host decoder's bit for bit (tested), it costs a GPU 1-3 % of its rate and takes the Viterbi -- half of what is
         // left of the host's work with -F, a third with -E -- off the cores that eight GPUs' lists otherwise bring to their

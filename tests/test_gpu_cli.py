@@ -15,8 +15,16 @@ HU, RU = "PHN_HU_SPDAT_LCRC_N1500", "PHN_RU_SPDAT_LCRC_N1500"
 
 
 def run(*args, env=None):
+    """one CLI run that must succeed.  Runs on ONE GPU without -F / -E are what most tests use as "the host front-end": they
+    get PHNREC_NO_AUTO_E=1 (since round 5 a list of ~100 files or more would take the GPU front-end by itself there as well
+    -- the same bytes, but then those tests would compare the GPU front-end with itself); tests of the automatic choice
+    pass their own environment (AUTO: "1" switches this default off)."""
     e = dict(os.environ)
-    e.update(env or {})
+    a = [str(x) for x in args]
+    one_gpu = "-g" not in a or a[a.index("-g") + 1] == "1"
+    if one_gpu and "-F" not in a and "-E" not in a and not (env or {}).get("AUTO"):
+        e["PHNREC_NO_AUTO_E"] = "1"
+    e.update({k: v for k, v in (env or {}).items() if k != "AUTO"})
     p = subprocess.run([BIN] + [str(a) for a in args], capture_output=True, text=True, env=e)
     assert p.returncode == 0, p.stderr
     return p
@@ -210,7 +218,16 @@ def test_two_gpus_called_as_the_reference_take_the_gpu_front_end(tmp_path):
         line = [l for l in p.stderr.splitlines() if l.startswith("phnrec: files=")][-1]
         return float(line.split("stage1=")[1].split()[0])
     assert stage1(b) < 0.5 * stage1(a) and stage1(c) > 0.5 * stage1(a)
-    assert " mode=F,auto " in b.stderr and " mode=host " in c.stderr
+    assert " mode=F,auto " in b.stderr and " mode=host " in c.stderr and " mode=host " in a.stderr
+    # ... and so does a list of this length on ONE GPU when nothing holds it back (the helper's default does, above)
+    auto1 = tmp_path / "g1auto.mlf"
+    d = run("-c", model_dir(HU), "-l", lst, "-m", auto1, env={"PHNREC_STATS": "1", "AUTO": "1"})
+    assert " mode=F,auto " in d.stderr and auto1.read_text() == one.read_text() and stage1(d) < 0.5 * stage1(a)
+    # a handful of files keep the host front-end
+    few = tmp_path / "few.scp"
+    few.write_text("".join(l + "\n" for l in lst.read_text().split()[:5]))
+    f = run("-c", model_dir(HU), "-l", few, "-m", tmp_path / "few.mlf", env={"PHNREC_STATS": "1", "AUTO": "1"})
+    assert " mode=host " in f.stderr
 
 
 def test_host_whose_libm_is_not_glibcs_takes_the_energies_road(tmp_path):

@@ -3,7 +3,8 @@
 file listed REPS times (a list loop of seconds, not of 0.3 s).  The library file next to the CLI is swapped in place and
 restored at the end.
     ab_cli_list.py LIB_A LIB_B [reps = 4] [rounds = 3] [mode ...]        ("-" = the library as it stands; a mode is the flag
-                                                                        string, e.g. "-F" "-F -D" "-E -D" ""; default -F, -F -D)
+                                                                        string, e.g. "-F" "-F -D" "-E -D" "" (the host
+                                                                        front-end: run with PHNREC_NO_AUTO_E=1); default -F, -F -D)
 An environment variant instead of a second library: LIB_B = "env:NAME=VALUE[,NAME=VALUE]" runs the same library with it set."""
 import os
 import shutil
@@ -47,8 +48,10 @@ def main():
                     for tag, (so, extra) in zip("AB", builds):
                         shutil.copyfile(so, lib)
                         mlf = os.path.join(td, "o%s.mlf" % tag)
-                        v, _pr = bench.run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", mlf] + mode.split(),
-                                               dict(os.environ, PHNREC_STATS="1", **extra))
+                        env = dict(os.environ, PHNREC_STATS="1", **extra)
+                        if not mode.split():
+                            env.setdefault("PHNREC_NO_AUTO_E", "1")
+                        v, _pr = bench.run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", mlf] + mode.split(), env)
                         if "error" in v:
                             print(tag, mode, v["error"], flush=True)
                             continue

@@ -23,6 +23,8 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
         for cfg in grid.split(";"):
             ctx, batch = (int(x) for x in cfg.split(","))
             env = dict(os.environ, PHNREC_STATS="1", PHNREC_CTX_PER_GPU=str(ctx))
+            if not flags:
+                env["PHNREC_NO_AUTO_E"] = "1"          # (host fe): a list of this length would take -F by itself
             extra = ["-b", str(batch)] if batch else []
             best = None
             for _ in range(3):

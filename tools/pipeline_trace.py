@@ -22,6 +22,8 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
     for flags in [f.split() for f in os.environ.get("TRACE_FLAGS", "-F;-F -D;").split(";")]:
         for rep in range(2):
             env = dict(os.environ, PHNREC_STATS="1", PHNREC_TRACE_PIPELINE="1", LCRC_TRACE_SLOW_US=os.environ.get("LCRC_TRACE_SLOW_US", "5000"))
+            if not flags:
+                env["PHNREC_NO_AUTO_E"] = "1"          # (the host front-end: a list of this length would take -F by itself)
             p = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "o.mlf"), "-g", "1"] + flags, env=env, capture_output=True, text=True)
         print("=====", flags)
         print(p.stderr[:int(os.environ.get("TRACE_CHARS", "9000"))])
@@ -34,6 +36,8 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
             best = None
             for rep in range(5):
                 env = dict(os.environ, PHNREC_STATS="1", **extra)
+                if not flags:
+                    env["PHNREC_NO_AUTO_E"] = "1"      # (host): a list of this length would take -F by itself
                 t0 = time.perf_counter()
                 p = subprocess.run([exe, "-c", mdir, "-l", lst, "-m", os.path.join(td, "o.mlf"), "-g", "1"] + flags, env=env, capture_output=True, text=True)
                 dt = time.perf_counter() - t0
