@@ -157,3 +157,22 @@ def test_header_is_plain_c(tmp_path):
                    check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert int(out[0]) == len(names) >= 30 and int(out[1]) >= 1
+
+
+def test_device_ln_argument_checks_need_no_gpu():
+    """lcrc_device_ln validates its arguments before it touches a device: an unknown form, a negative count or missing arrays
+    are LCRC_E_ARG, an empty array is nothing to do; with values to compute it needs the GPU and says so (no CPU fallback)"""
+    x = np.array([1.0, 2.0, 0.0, -1.0], np.float32)
+    with pytest.raises(capi.LcrcError) as e:
+        capi.device_ln(x, 7)
+    assert e.value.code == capi.LCRC_E_ARG
+    assert capi.device_ln(np.zeros(0, np.float32), 1).size == 0
+    L = capi.load()
+    import ctypes as C
+    L.lcrc_device_ln.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]
+    assert L.lcrc_device_ln(0, 1, None, None, 4) == capi.LCRC_E_ARG and L.lcrc_device_ln(0, 1, None, None, -1) == capi.LCRC_E_ARG
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.LcrcError) as e:
+            capi.device_ln(x, 1)
+        assert e.value.code == capi.LCRC_E_DEVICE

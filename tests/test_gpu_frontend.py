@@ -404,3 +404,27 @@ def test_device_ln_forms_against_this_hosts_logf(capi):
     ulp = np.abs(got[0].view(np.int32)[finite].astype(np.int64) - want.view(np.int32)[finite].astype(np.int64))
     assert ulp.max() <= 1 and (ulp == 0).mean() > 0.999
     assert np.array_equal(got[0][~finite].view(np.uint32), want[~finite].view(np.uint32))      # zero, negative, NaN: 0; inf: inf
+
+
+def test_decoder_overlap_is_inert_while_posteriors_are_read_back(capi):
+    """lcrc_set_decoder_overlap applies to contexts that decode WITHOUT reading posteriors back: with read-back on, a staged
+    call decodes before it returns, as always -- last_labels() right behind it is that call's, prev_labels() has nothing --,
+    and the posteriors it hands out are the ones of a context that never heard of the overlap"""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    ref, ctx = _ctx(capi, CZ), _ctx(capi, CZ)
+    for c in (ref, ctx):
+        c.configure_output(("log",))
+        c.configure_decoder(45, 3, 40, -4.6875)
+    ctx.set_decoder_overlap(True)                               # read-back stays on (the default)
+    mel = read_htk(os.path.join(GOLD, CZ, "test.mel")) - 11.0
+    off = np.array([0, 300, 747], np.int32)
+    a = ref.posteriors_staged(mel, off)
+    b = ctx.posteriors_staged(mel, off)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert ctx.last_labels() == ref.last_labels() and len(ctx.last_labels()[1]) > 10
+    assert ctx.prev_labels() == []
+    pa, _ = ref.wave_to_posteriors_staged([raw[:40000], raw[40000:]])
+    pb, _ = ctx.wave_to_posteriors_staged([raw[:40000], raw[40000:]])
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)) and ctx.last_labels() == ref.last_labels()
+    ref.close()
+    ctx.close()
