@@ -828,6 +828,31 @@ def reference_cli_leg(mdir, gpu):
         return out
 
 
+def emit(full, detail_out):
+    """The record leaves in three forms: the FULL one (every leg's break-down and its sentence of what it measured)
+    to a file and, leg by leg, to stderr; stdout gets ONE line of at most benchline.LIMIT bytes -- the contract's
+    keys, `roofline`, `cpu_baseline` and numbers only per side leg (the driver parses a bounded line: round 5's
+    21.7 KB one was cut and its record lost)."""
+    from phnrec_amd import benchline
+    path = detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+        full = dict(full, detail=os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path)
+    except OSError as e:                      # a read-only tree: stderr still has it
+        sys.stderr.write("bench.py: detail file not written: %r\n" % (e,))
+    head = {k: v for k, v in full.items() if not isinstance(v, (dict, list))}
+    sys.stderr.write("bench detail [head]: %s\n" % json.dumps(head))
+    for k, v in full.items():
+        if isinstance(v, (dict, list)):
+            sys.stderr.write("bench detail [%s]: %s\n" % (k, json.dumps(v)))
+    sys.stderr.flush()
+    _RECORD_OUT.write(benchline.stdout_line(full) + "\n")
+    _RECORD_OUT.flush()
+
+
 def stub_main(args, ranks):
     """Launcher self-test: everything of the N-rank harness except the GPU (see --stub)."""
     from phnrec_amd import distrun
@@ -841,12 +866,11 @@ def stub_main(args, ranks):
     elapsed = distrun.timed_steps(ranks, step, lambda: None, args.steps, args.warmup)
     total = ranks.sum_int(state["n"])
     if ranks.rank == 0:
-        _RECORD_OUT.write(json.dumps({"stub": True, "metric": "launcher self-test (no GPU work)", "n_gpus": 0,
-                                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                                      "frames_all_ranks": total,
-                                      "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
-                                                "device_map": distrun.device_map(ranks.world)}}) + "\n")
-        _RECORD_OUT.flush()
+        emit({"stub": True, "metric": "launcher self-test (no GPU work)", "n_gpus": 0,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+              "frames_all_ranks": total,
+              "ranks": {"world": ranks.world, "launcher": ranks.launcher, "backend": ranks.backend,
+                        "device_map": distrun.device_map(ranks.world)}}, args.detail_out)
     ranks.finish()
 
 
@@ -872,6 +896,8 @@ def main():
     # launcher self-test (tests/test_distrun.py): the same launch / rendezvous / barrier / MAX-over-ranks
     # code with a sleeping step and gloo instead of the GPU step and RCCL; its line says "stub": true
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--detail-out", default=None,
+                    help="file for the full record (default gpurun_out/bench_detail.json); stdout carries its compact form")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -1120,8 +1146,7 @@ def main():
     ranks.host_barrier()     # rank 0's side legs are over (a CPU-side wait: the other ranks' GPUs stay idle meanwhile)
     ranks.finish()
     if line is not None:
-        _RECORD_OUT.write(json.dumps(line) + "\n")
-        _RECORD_OUT.flush()
+        emit(line, args.detail_out)
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 
 from phnrec_amd import distrun
@@ -98,12 +99,15 @@ def test_bench_self_launch_starts_n_ranks():
     """`python bench.py --gpus 2` with no RANK in the environment starts two fresh ranks itself; the line
     rank 0 prints carries the world size the process group counted (stub step, gloo: no GPU here)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub"],
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub",
+                        "--detail-out", os.path.join(tempfile.mkdtemp(), "detail.json")],
                        capture_output=True, text=True, env=env, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
     # stdout is the record and nothing else (gloo announces its ranks on stdout from C++: bench.py points fd 1 at stderr)
     assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1, p.stdout[:500]
+    assert len(p.stdout.strip()) + 1 <= 6144, "the stdout line stays inside what the driver parses"
+    assert "bench detail [ranks]" in p.stderr, "the full record goes to stderr, leg by leg"
     line = _last_json(p.stdout)
     assert line["ranks"] == {"world": 2, "launcher": "self", "backend": "gloo", "device_map": [0, 1]}
     assert line["frames_all_ranks"] == 2 * (4 + 1) * 8192          # both ranks stepped, warm-up included
@@ -176,3 +180,57 @@ def test_device_map_override(monkeypatch):
     import pytest
     with pytest.raises(SystemExit):
         distrun.device_map(3)
+
+
+# ---- the stdout line of bench.py: bounded, numbers only (phnrec_amd/benchline.py) ------------------------
+def test_bench_line_of_the_round5_record_fits_six_kilobytes():
+    """Round 5's full record (21.7 KB on stdout: the driver's parser cut it, BENCH_r05.parsed = null) through the
+    compaction bench.py now applies: one line <= 6 KB that still carries the contract's keys, `roofline` with its cold
+    figure, windows and traffic, `cpu_baseline` with the reference's three regimes, the port, the host and both parities,
+    and every side leg as numbers; no prose; nothing dropped."""
+    import json
+    from phnrec_amd import benchline
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_form.json")))
+    assert len(json.dumps(full)) > 20000
+    line = benchline.stdout_line(full)
+    assert len(line) + 1 <= benchline.LIMIT == 6144
+    c = json.loads(line)
+    for k in benchline.CONTRACT + ("roofline", "cpu_baseline"):
+        assert k in c, k
+    for k in benchline.CONTRACT:
+        assert c[k] == full[k] or k == "config", k          # the contract's keys travel unrounded
+    assert c["config"]["workload"] == full["config"]["workload"]
+    assert "dropped" not in c
+    r = c["roofline"]
+    assert r["frac"] == 0.8289 and r["kernel_ms"] == 0.1923 and r["cold"]["frac"] == 0.5083 and r["traffic"] == 64106436
+    assert r["windows"]["kernel_ms_median"] == 0.1916 and r["traffic_source"] == "profiles/hbm_traffic.json"
+    b = c["cpu_baseline"]
+    assert b["kind"] == "reference" and b["cores"] == 1 and b["sgemm_all_cores"]["cores"] == 16 and b["port"]["kind"] == "port"
+    assert b["host"]["cpu_model"].startswith("AMD EPYC") and b["parity_max_abs_vs_gpu"] < 1e-4
+    sl = c["sharded_list"]
+    assert set(sl) >= {"host", "E", "E_D", "F", "F_D", "weak_list", "host_ceiling", "mlf_all_modes_equal"}
+    assert sl["weak_list"]["g8_default"]["mode"] == "F+D,auto" and sl["weak_list"]["F_D"]["ceiling_over_8_gpus"] > 1
+
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                assert k not in ("what", "cpu_s_by_stage", "create_trace_ms"), k
+                walk(v)
+        elif isinstance(o, str):
+            assert len(o) <= 160, o
+    walk(c)
+
+
+def test_bench_line_gives_up_side_legs_before_the_contract():
+    """a record whose compact form is still over the limit loses whole side legs, least important first, and says
+    which; the contract's keys, `roofline` and `cpu_baseline` stay"""
+    import json
+    from phnrec_amd import benchline
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_form.json")))
+    line = benchline.stdout_line(full, limit=3500)
+    c = json.loads(line)
+    assert len(line) + 1 <= 3500 and c["dropped"][0] == "push_bunch512" and "sharded_list" in c
+    assert "roofline" in c and "cpu_baseline" in c and all(k in c for k in benchline.CONTRACT)
+    import pytest
+    with pytest.raises(RuntimeError):
+        benchline.stdout_line(full, limit=500)

@@ -649,20 +649,39 @@ def test_configs3_list_at_scale(tmp_path):
         assert max(abs(float(x[3]) - float(y[3])) for x, y in zip(entry, one)) < 1e-3
 
 
-def test_bench_line_carries_every_leg():
-    """bench.py in the driver's form (shortened): ONE JSON line with the contract's keys, the roofline object with
-    its disclosed pre-heat / cold figure / traffic source, the CPU baseline, and the side legs that put the
-    streaming entry, the small-launch regime, the waveform entry and the CLI into the driver-run record"""
+def test_bench_line_carries_every_leg(tmp_path):
+    """bench.py in the driver's form (shortened): ONE JSON line on stdout, at most 6 KB (the driver parses a bounded
+    line: round 5's 21.7 KB one was cut, BENCH_r05.parsed = null), with the contract's keys, the roofline object with
+    its cold figure / windows / traffic, the CPU baseline, and NUMBERS ONLY for the side legs; the full record --
+    every leg's break-down -- in the file the line names, and leg by leg on stderr"""
     import json
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PHNREC_DEVICE_MAP")}
+    detail = tmp_path / "detail.json"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
-                        "--preheat", "10", "--cpu-seconds", "1", "--list-files", "120"],
+                        "--preheat", "10", "--cpu-seconds", "1", "--list-files", "120", "--detail-out", str(detail)],
                        capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
-    d = json.loads(lines[0])
+    assert len(lines[0]) + 1 <= 6144, "the stdout line is %d bytes" % (len(lines[0]) + 1)
+    c = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "ranks", "roofline", "cpu_baseline", "preheat_launches"):
+        assert k in c, k
+    assert "dropped" not in c, "every side leg fits: %s" % c.get("dropped")
+    assert not any(k == "what" for k in _all_keys(c)), "no prose on stdout"
+    assert c["roofline"]["bound"] == "mfma" and 0.3 < c["roofline"]["frac"] < 1.0 and "cold" in c["roofline"]
+    assert "windows" in c["roofline"] and c["roofline"]["traffic"] > 0
+    assert c["cpu_baseline"]["kind"] in ("reference", "port") and c["cpu_baseline"]["cores"] == 1
+    assert c["cpu_baseline"]["parity_max_abs_vs_gpu"] < 1e-4 and "cpu_model" in c["cpu_baseline"]["host"]
+    for leg in ("sharded_list", "four_systems", "systems", "small_launches", "single_file", "split_f16", "push_bunch5"):
+        assert leg in c, leg
+    assert c["sharded_list"]["F"]["value"] > 50000 and c["sharded_list"]["F"]["process_frames_per_s"] > 0
+    assert c["sharded_list"]["mlf_all_modes_equal"] is True and c["four_systems"]["mlf_equal"] is True
+    assert "bench detail [roofline]" in p.stderr and "bench detail [sharded_list]" in p.stderr
+    d = json.loads(detail.read_text())                    # the full record
+    assert d["value"] == c["value"] and d["ms_per_step"] == c["ms_per_step"] and d["roofline"]["frac"] == c["roofline"]["frac"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "preheat_launches"):
         assert k in d, k
@@ -713,6 +732,16 @@ def test_bench_line_carries_every_leg():
     assert all(fs["mlf_equals_single_system_run"].values()) and len(fs["mlf_equals_single_system_run"]) == 4
 
 
+def _all_keys(o):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield k
+            yield from _all_keys(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _all_keys(v)
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py --gpus 2 started plainly (no launcher): the parent starts two ranks itself before touching the GPU;
     PHNREC_DEVICE_MAP=0,0 puts both on the one GPU of this box (functional run: rendezvous over gloo, labelled
@@ -722,10 +751,13 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["PHNREC_DEVICE_MAP"] = "0,0"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-                        "--preheat", "0", "--no-cpu", "--no-extras", "--list-files", "150"],
+                        "--preheat", "0", "--no-cpu", "--no-extras", "--list-files", "150",
+                        "--detail-out", str(tmp_path / "detail.json")],
                        capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    short = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(short) + 1 <= 6144 and json.loads(short)["ranks"]["world"] == 2
+    line = json.loads((tmp_path / "detail.json").read_text())
     assert line["ranks"]["world"] == 2 and line["ranks"]["oversubscribed"] is True
     assert line["ranks"]["device_map"] == [0, 0] and line["n_gpus"] == 1
     assert line["value"] > 0 and line["steps"] == 5

@@ -2,13 +2,14 @@
 # Copies the summaries of a tools/refresh_profiles.sh run (gpurun_out/refresh_<tag>/) into profiles/ under the round's names.
 #   tools/collect_profiles.sh r02
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=gpurun_out/refresh_$TAG
 P=profiles
 clean() { grep -v amdgpu.ids "$1" > "$2"; }
 first() { ls $1 | head -1; }     # (a traced run may leave one file per process)
 cp $R/bench.json $P/${TAG}_bench.json
 cp $R/bench_driver_form.json $P/${TAG}_bench_driver_form.json
+for f in bench_line bench_driver_form_line; do [ -f $R/$f.json ] && cp $R/$f.json $P/${TAG}_$f.json; done      # what stdout carried
 cp $(first "$R/stats/*/*kernel_stats.csv") $P/${TAG}_kernel_stats_all_launches.csv
 [ -f $R/steady_kernel_stats.csv ] && cp $R/steady_kernel_stats.csv $P/${TAG}_kernel_stats.csv      # the timed launches only
 [ -f $R/bench_profiled.json ] && cp $R/bench_profiled.json $P/${TAG}_bench_profiled.json              # the traced run's own line

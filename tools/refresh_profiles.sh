@@ -6,20 +6,21 @@
 # rocprofv3 is always given `python3 <script>` directly (no shell hop), PMC passes are separate runs
 # with --kernel-trace only.  Every step writes a file under $OUT as it ends (progress for the harness).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}     # a | b | c | all: the run fits gpurun's 20-minute limit in three parts
 OUT=gpurun_out/refresh_$TAG
 [ "$PART" = "a" -o "$PART" = "all" ] && rm -rf $OUT    # (gpurun merges results into the local gpurun_out/: clear the local copy before calling, too)
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "$PART" = "a" -o "$PART" = "all" ]; then
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2>> $OUT/bench.err      # the driver's invocation
+# stdout = the bounded line the driver parses (<= 6 KB, numbers only); --detail-out = the full record of the same run
+python3 bench.py --detail-out $OUT/bench.json > $OUT/bench_line.json 2> $OUT/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail-out $OUT/bench_driver_form.json > $OUT/bench_driver_form_line.json 2>> $OUT/bench.err      # the driver's invocation
 # the N-rank form on this box's one GPU (two ranks mapped onto it: functional, labelled oversubscribed)
-PHNREC_DEVICE_MAP=0,0 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu --no-extras > $OUT/bench_2ranks_one_gpu.json 2>> $OUT/bench.err
+PHNREC_DEVICE_MAP=0,0 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu --no-extras --detail-out $OUT/bench_2ranks_one_gpu.json > $OUT/bench_2ranks_one_gpu_line.json 2>> $OUT/bench.err
 echo "bench done"
 # per-kernel summary: rocprofv3's own (every launch of the process) and the steady-state one (the 200 timed launches)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 200 --warmup 100 --no-cpu --no-extras --list-files 0 > $OUT/bench_profiled.json 2> $OUT/stats.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 200 --warmup 100 --no-cpu --no-extras --list-files 0 --detail-out $OUT/bench_profiled.json > $OUT/bench_profiled_line.json 2> $OUT/stats.log
 python3 tools/steady_kernel_stats.py $OUT/stats 200 $OUT/steady_kernel_stats.csv $OUT/bench_profiled.json
 # the fused kernel's own dispatch rows (grid, workgroup, LDS, registers)
 for f in $OUT/stats/*/*kernel_trace.csv; do head -1 $f > $OUT/kernel_trace_head.csv; grep -m 3 lcrc_fused_kernel $f >> $OUT/kernel_trace_head.csv; done
