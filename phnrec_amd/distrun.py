@@ -149,7 +149,12 @@ class Ranks:
     def barrier(self):
         if self.pg:
             import torch.distributed as dist
-            dist.barrier()
+            if self.backend == "nccl":
+                # name the device: an RCCL barrier otherwise guesses it from the rank number and warns
+                import torch
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
 
     def max_float(self, v, device=None):
         if not self.pg:

@@ -774,6 +774,40 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert sl["frames_per_s"] > 50000 and sl["host_ceiling"]["frames_per_s"] > 0 and sl["cores_usable"] >= 1
 
 
+def test_bench_one_rank_over_rccl(tmp_path):
+    """The driver's launcher form on this box's one GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1
+    bench.py --gpus 1 ...` (launcher first; nothing touches the GPU before it).  Under a launcher Ranks.init takes the
+    process-group branch even at world size 1, so this executes on real RCCL what the 8-GPU scaling run adds to an
+    N = 1 run: init_process_group("nccl"), the gloo side group, dist.barrier() on the device and the device-side
+    all_reduce(MAX) of timed_steps (phnrec_amd/distrun.py)."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PHNREC_DEVICE_MAP")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    detail = tmp_path / "detail.json"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--kernel-only", "--steps", "5", "--warmup", "2",
+                        "--preheat", "10", "--detail-out", str(detail)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) + 1 <= 6144, p.stdout[:500]
+    c = json.loads(lines[0])
+    assert c["ranks"]["backend"] == "nccl" and c["ranks"]["world"] == 1
+    assert c["ranks"]["launcher"] == "torch.distributed.run" and c["ranks"]["oversubscribed"] is False
+    assert c["n_gpus"] == 1 and c["steps"] == 5 and c["warmup"] == 2
+    # 8192 CZ frames per step: 0.19-0.25 ms of kernel; the bracket (barrier + synchronise on both sides) adds the collective
+    assert 0.15 < c["ms_per_step_before_closing_barrier"] <= c["ms_per_step"] < 2.0, c
+    assert 0.3 < c["roofline"]["frac"] < 1.0 and c["roofline"]["kernel_ms"] <= c["ms_per_step"]
+    assert "device_ids" not in p.stderr or "using GPU" not in p.stderr, "the barrier names its device"
+
+
 def test_more_gpus_than_the_box_has_fails_loudly(tmp_path):
     lst = _make_list(tmp_path, "cz", 3, seed=1)
     e = dict(os.environ)
