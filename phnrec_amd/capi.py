@@ -22,7 +22,7 @@ SYMBOLS = [
     "lcrc_reserve", "lcrc_wave_stage_buffer", "lcrc_wave_stage_run", "lcrc_wave_stage_energies", "lcrc_staged_posteriors",
     "lcrc_output_configure", "lcrc_decoder_configure", "lcrc_set_posterior_readback", "lcrc_last_labels", "lcrc_set_decoder_overlap", "lcrc_prev_labels", "lcrc_set_launch_order",
     "lcrc_reset", "lcrc_push", "lcrc_delay",
-    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_kernel_done_callback", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_kernel_name",
+    "lcrc_last_kernel_ms", "lcrc_set_timing", "lcrc_set_wait_mode", "lcrc_set_kernel_done_callback", "lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_set_arithmetic", "lcrc_debug_fail_alloc", "lcrc_debug_fail_launch", "lcrc_kernel_name",
 ]
 
 LCRC_OK, LCRC_E_ARG, LCRC_E_IO, LCRC_E_MODEL, LCRC_E_DEVICE, LCRC_E_NOMEM, LCRC_E_UNSUPPORTED = \
@@ -156,6 +156,7 @@ def load():
     L.lcrc_set_mean_order.argtypes = [vp, C.c_int]
     L.lcrc_set_arithmetic.argtypes = [vp, C.c_int]
     L.lcrc_debug_fail_alloc.argtypes = [C.c_int]
+    L.lcrc_debug_fail_launch.argtypes = [C.c_int]
     L.lcrc_posteriors_rows.argtypes = [vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
     _lib = L
     return L

@@ -173,14 +173,22 @@ int main(int argc, char **argv)
         }
     }
 
+    // Fault injection for tests of the list pipeline's error paths (inert unless LCRC_FAULT_INJECTION=1: the library refuses
+    // to arm its hooks otherwise, and asking without it is an error, not a silent no-op): the n-th staging-buffer
+    // allocation / the n-th posterior launch of this process fails (lcrc_debug_fail_alloc, lcrc_debug_fail_launch).
+    if (const char *e = getenv("PHNREC_FAIL_ALLOC_NTH"))
+        if (lcrc_debug_fail_alloc(atoi(e)) != LCRC_OK) Die(std::string(lcrc_last_error(nullptr)) + "\n");
+    if (const char *e = getenv("PHNREC_FAIL_LAUNCH_NTH"))
+        if (lcrc_debug_fail_launch(atoi(e)) != LCRC_OK) Die(std::string(lcrc_last_error(nullptr)) + "\n");
+
     SpeechRec SR;
     g_sr = &SR;
     SR.SetVerbose(verbose);
     if (!config_dir) Die("Configuration directory is not set (-c)\n");
     // a conversion through the posterior estimator will need the GPU: bring the HIP runtime up NOW, on a helper thread,
     // while the configuration, the model files and the weights' re-packing are dealt with on this one
-    if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     SR.SetGpus(gpus);
+    if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
     if (batch > 0) SR.SetBatchFrames(batch);
     if (threads > 0) SR.SetHostThreads(threads);
     if (gpu_fe && gpu_en) Die("-F and -E are two forms of the GPU front-end: give one\n");
@@ -212,17 +220,19 @@ int main(int argc, char **argv)
 
     if (getenv("PHNREC_STATS")) {
         const RunStats &s = SR.Stats();
-        // setup_s: pool + GPU contexts (create_s of it: HIP start-up, model load, pack, upload); first_launch_s: the first
-        // launch call of the run (code-object load, cold clock) -- part of wall_s; main_s: since main() was entered
+        // setup_s: what runs in front of the list (pool, plan); wall_s: the list from its first line to its last, the contexts'
+        // start-up included -- they come up beside it: first_ctx_s until the first one could take a launch (HIP start-up,
+        // model load, pack, upload), create_s until the last one could; first_launch_s: the first launch call of the run
+        // (code-object load, cold clock); main_s: since main() was entered
         fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f "
-                        "(front_end_s=%.3f setup_s=%.3f create_s=%.3f first_launch_s=%.3f config_s=%.3f main_s=%.3f) "
-                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d mode=%s max_rss_mb=%.1f\n",
+                        "(front_end_s=%.3f setup_s=%.3f first_ctx_s=%.3f create_s=%.3f first_launch_s=%.3f config_s=%.3f main_s=%.3f) "
+                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d contexts=%d mode=%s max_rss_mb=%.1f\n",
                 s.files, s.frames, s.seconds, s.seconds > 0 ? s.frames / s.seconds : 0.0,
                 s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds,
-                s.create_seconds, s.first_launch_seconds, config_s,
+                s.first_context_seconds, s.create_seconds, s.first_launch_seconds, config_s,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
                 s.cpu_stage1 + s.cpu_read + s.cpu_gather + s.cpu_stage3, s.cpu_stage1, s.cpu_read, s.cpu_gather, s.cpu_stage3, s.cpu_viterbi,
-                s.host_threads, SR.ModeString().c_str(), MaxRssMb());
+                s.host_threads, s.contexts, SR.ModeString().c_str(), MaxRssMb());
     }
     // Every output file is closed by now.  Leave without tearing the HIP runtime down piece by piece (contexts, streams,
     // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.

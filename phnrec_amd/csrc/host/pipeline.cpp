@@ -19,6 +19,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <set>
 #include <thread>
 
 #include "htk.h"
@@ -212,27 +213,13 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // GPU, some 4000 files, a tenth of a second of work per GPU --, otherwise two.
         const bool worth_three = std::max(1, n_gpus_) < 4 || list_bytes_ / std::max(1, n_gpus_) >= (128 << 10);
         const int per_gpu = single_file ? 1 : worth_three ? 3 : 2;
-        if (!EnsureGpus(per_gpu)) {
-            // -E was this function's own idea and the contexts did not take the front-end after all: the host front-end
-            // serves the list as it did before the automatic choice existed
-            if (!((auto_energies_ || auto_frontend_) && gpus_.empty())) return false;
-            auto_energies_ = auto_frontend_ = false;
-            err_.clear();
-            if (!EnsureGpus(per_gpu)) return false;
-        }
-    }
-    if (need_gpu && !single_file && pool_->Size() > 0) {
-        cpu_set_t all, one;
-        CPU_ZERO(&all);
-        bool every = true;
-        for (int d : gpu_devices_) {
-            if (!GpuNodeCpus(d, &one)) { every = false; break; }
-            CPU_OR(&all, &all, &one);
-        }
-        // (only where those nodes hold at least as many usable CPUs as the pool has threads: the pool is sized from every
-        //  socket's CPUs, and on a two-socket host with one GPU and the host front-end -- the CPU-bound stage there -- N
-        //  threads confined to N/2 cores beside the spinning GPU workers would halve it)
-        if (every && CPU_COUNT(&all) >= pool_->Size()) pool_->SetAffinity(all);
+        // (only the places: each context is built by its own worker below, beside the running list)
+        if (!PlanGpus(per_gpu)) return false;
+        // (which of glibc's two logf sequences this host's libm runs -- 300 000 probes, ~12 ms -- is found out HERE, on this
+        //  thread, while the HIP runtime starts up on others; the first context's set-up asked in front of its first launch)
+        if (FrontendOn()) (void)LibmLogfForm();
+        fe_vector_size_ = C.GetInt("melbanks", "vector_size");
+        fe_vector_step_ = std::max(1, C.GetInt("melbanks", "vector_step"));
     }
     // (a model the device decoder does not take -- more states than posterior outputs, say -- keeps the host decoder
     //  when -D was this function's own idea)
@@ -259,54 +246,40 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     bool dec_overlap = dev_dec && !single_file && (int)gpus_.size() <= 2 * std::max(1, n_gpus_);
     if (const char *e = getenv("PHNREC_DECODER_OVERLAP")) dec_overlap = dev_dec && !single_file && atoi(e) != 0;
     std::vector<std::string> phn_names;
+    ContextPlan plan;
     if (need_gpu) {
         // posterior writer path: both softening functions and the dump's byte order run in the posterior
         // kernel's epilogue; the host only decodes or writes
-        lcrc_softening st[2] = {DeviceSoftening(post_soft_, post_soft_arg_), DeviceSoftening(dec_soft_, dec_soft_arg_)};
-        for (auto &g : gpus_)
-            if (!g->ConfigureOutput(st, out == dfStrings ? 2 : 1, out == dfPosteriors)) return Fail(g->LastError() + "\n");
+        plan.soft[0] = DeviceSoftening(post_soft_, post_soft_arg_);
+        plan.soft[1] = DeviceSoftening(dec_soft_, dec_soft_arg_);
+        plan.n_soft = out == dfStrings ? 2 : 1;
+        plan.big_endian = out == dfPosteriors;
         // -D: the decoder runs behind the posterior kernel and only labels cross PCIe
         if (dev_dec) phn_names = phn_names_;
-        for (auto &g : gpus_)
-            if (!g->ConfigureDecoder(dev_dec ? (int)phn_names.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !dev_dec))
-                return Fail(g->LastError() + "\n");
-        for (auto &g : gpus_) {
-            if (!g->SetDecoderOverlap(dec_overlap)) return Fail(g->LastError() + "\n");
-            g->SetLaunchOrder(launch_order);
-        }
+        plan.device_decoder = dev_dec;
+        plan.decoder_overlap = dec_overlap;
+        plan.launch_order = launch_order;
         // Every context has a thread waiting for it.  Spinning (the default) is the fastest way to notice a finished
         // launch and costs a core each: fine for one GPU's three on 16 cores (sleeping waits lose 15 % with -F there,
         // profiles/r03_ab_runs.txt 14), not when the waiting threads of many GPUs would take more than half of the cores
         // the front-end and the decoder of the same run need (16 contexts on 16 cores: +10-20 % with sleeping waits,
         // item 18).  PHNREC_WAIT_POLL_US overrides (0 = spin).
-        int poll_us = (int)gpus_.size() * 2 > UsableCpus() ? 50 : 0;
-        if (const char *e = getenv("PHNREC_WAIT_POLL_US")) poll_us = std::max(0, atoi(e));
-        for (auto &g : gpus_) g->SetWaitMode(poll_us);
-        // A list: every context's buffers for launches of batch_frames_, allocated here, all contexts at once, instead of
-        // inside each context's first launch (pinning 30 MB of posterior buffer is 5-10 ms, and the runtime lets other
-        // contexts' copies wait meanwhile: the first 40 ms of a list ran at a third of the steady rate).
+        plan.poll_us = (int)gpus_.size() * 2 > UsableCpus() ? 50 : 0;
+        if (const char *e = getenv("PHNREC_WAIT_POLL_US")) plan.poll_us = std::max(0, atoi(e));
+        // A list: every context's buffers for launches of batch_frames_, allocated by the context's worker before its first
+        // launch instead of inside it (pinning 30 MB of posterior buffer is 5-10 ms; the other contexts run meanwhile).
         // (lists of at least ~100 entries, by the size of the list file: a short list's launches never fill such buffers and
         //  its few files are done sooner than 3 x 40 MB are pinned)
-        // (With the posteriors of a list's launches stored straight into the pinned buffer -- no copy-backs -- the step is
-        //  worth less than before and nothing on some boxes: list loop 0.285 / 0.305 / 0.308 / 0.273 s with it against
-        //  0.302 / 0.327 / 0.325 / 0.289 s without on one box, -F / -F -D / -E / host front-end, 0.293 / 0.303 / 0.333 / 0.315
-        //  against 0.296 / 0.325 / 0.323 / 0.312 on another; the process takes as long either way.)
         if (!single_file && long_list_) {
             // (a -b beyond 131 072 frames is reserved up to that: a short list would never fill the rest, the buffers grow
             //  on demand as before)
-            const int rows = std::min(batch_frames_, 131072);
-            long long wave_bytes = 0;
+            plan.reserve_rows = std::min(batch_frames_, 131072);
             if ((FrontendOn() || EnergiesOn()) && in == dfWaveform)
-                wave_bytes = ((long long)rows * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
-                             (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
-            std::vector<std::string> errs(gpus_.size());
-            std::vector<std::thread> th;
-            for (size_t i = 0; i < gpus_.size(); i++)
-                th.emplace_back([&, i] { if (!gpus_[i]->Reserve(rows, 256, wave_bytes)) errs[i] = gpus_[i]->LastError() + "\n"; });
-            for (auto &t : th) t.join();
-            for (const std::string &e : errs) if (!e.empty()) return Fail(e);
+                plan.reserve_wave_bytes = ((long long)plan.reserve_rows * C.GetInt("melbanks", "vector_step") + C.GetInt("melbanks", "vector_size")) *
+                                          (wave_.format == WF_LIN16 ? 2 : 1) + 4096;
         }
     }
+    // (what is left in front of the list: the pool and the plan -- the contexts come up beside it, inside `seconds`)
     const auto t1 = clock::now();
     stats_.init_seconds += std::chrono::duration<double>(t1 - t0).count();
 
@@ -320,6 +293,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     bool eof = false, feeder_blocked = false;
     long long stop_seq = -1;                   // first job whose stage 1 failed: nothing at or behind it is launched
     std::string fatal;                         // GPU / output error: the run ends
+    bool fatal_pending_clone = false;          // a clone gave up because its GPU's first context failed (whose message is `fatal`)
     long long files_done = 0, frames_done = 0;
     // CPU time the host stages take, summed over the threads that run them (what the cores must deliver however
     // fast the GPUs are: PHNREC_STATS prints it, bench.py derives the host ceiling of a list from it)
@@ -349,6 +323,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     const int max_pending = std::max(8, 4 * std::max(1, pool_->Size()));
     const long long max_staged_frames = (long long)batch_frames_ * (n_ctx + 2);
     const long long max_staged_bytes = 2LL << 30;
+    const long long start_up_bytes = 512LL << 20;
     const size_t max_window = 1 << 16;
 
     // in-order output; call with `mu` held
@@ -458,9 +433,73 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             drain();
         }
     };
+    std::atomic<int> contexts_up(0), contexts_committed(0);
+    std::atomic<bool> pool_placed(false);
+    // A context that shares another's weights comes up 20-50 ms after that one (stream, tables, 30-40 MB of pinned staging --
+    // steps the runtime serialises against everything else the process does on the GPUs, the running contexts' launches
+    // included).  It is worth that only if the list is still long enough by then: more than ~1.5 M frames -- 50 ms of a
+    // GPU's work -- left to launch per context already up or on its way.  While the list is still being read its length is
+    // unknown and the answer is yes.  (Eight GPUs over configs[3]'s 8.9 M frames: the eight first contexts finish the list
+    // in the time sixteen clones would take to come up.)  PHNREC_ALL_CONTEXTS=1: every planned context, always.
+    const bool all_contexts = getenv("PHNREC_ALL_CONTEXTS") != nullptr;
+    // (the first context of every physical device is always created)
+    const int n_first_contexts = (int)std::set<int>(gpu_devices_.begin(), gpu_devices_.end()).size();
+    auto worth_another_context = [&]() -> bool {
+        std::lock_guard<std::mutex> l(mu);
+        if (!fatal.empty()) return false;
+        long long left = -1;                             // frames no launch has taken yet; -1: unknown
+        if (eof) {
+            left = 0;
+            for (long long q = next_launch; q - base < (long long)win.size(); q++) {
+                const Item *it = win[(size_t)(q - base)].get();
+                if (it->slot.state == 0) { left = -1; break; }      // (a job still in stage 1: its length is not known yet)
+                left += it->job.frames;
+            }
+        }
+        const bool yes = all_contexts || left < 0 || left > 1500000LL * (n_first_contexts + contexts_committed.load());
+        if (yes) contexts_committed++;
+        return yes;
+    };
     auto worker = [&](int g) {
-        Traps &tr = *gpus_[g];
         const int device = gpu_devices_[(size_t)(g % n_log)];
+        // This context first: the model and the HIP start-up for a GPU's first one, a share of its weights for the others,
+        // then the run's configuration and the buffers of full-size launches.  The list is running meanwhile -- its files
+        // are being staged from its first line on, and the contexts that are up take launches.
+        {
+            std::string cerr;
+            const int up_rc = BringUpContext(g, plan, cerr, [&](const char *what) { trace(g, what); }, worth_another_context);
+            if (up_rc < 0) return;                  // left out: the contexts that are up finish the list sooner without it
+            if (up_rc == 0) {
+                std::lock_guard<std::mutex> l(mu);
+                // (a clone whose GPU's first context failed says nothing: that context's own message is the run's)
+                if (fatal.empty() && !cerr.empty()) fatal = cerr;
+                else if (fatal.empty()) fatal_pending_clone = true;
+                cv_work.notify_all(); cv_feed.notify_all(); cv_idle.notify_all();
+                return;
+            }
+            const double up = std::chrono::duration<double>(clock::now() - t0).count();
+            if (contexts_up.fetch_add(1) == 0) stats_.first_context_seconds = up;
+            {
+                std::lock_guard<std::mutex> l(mu);
+                stats_.create_seconds = std::max(stats_.create_seconds, up);
+            }
+        }
+        Traps &tr = *gpus_[g];
+        // (the HIP runtime is up by now: asking for the devices' bus ids costs nothing -- in front of the first context it
+        //  waited for the runtime's start-up)
+        if (!single_file && pool_->Size() > 0 && !pool_placed.exchange(true)) {
+            cpu_set_t all, one;
+            CPU_ZERO(&all);
+            bool every = true;
+            for (int d : gpu_devices_) {
+                if (!GpuNodeCpus(d, &one)) { every = false; break; }
+                CPU_OR(&all, &all, &one);
+            }
+            // (only where those nodes hold at least as many usable CPUs as the pool has threads: the pool is sized from every
+            //  socket's CPUs, and on a two-socket host with one GPU and the host front-end -- the CPU-bound stage there -- N
+            //  threads confined to N/2 cores beside the spinning GPU workers would halve it)
+            if (every && CPU_COUNT(&all) >= pool_->Size()) pool_->SetAffinity(all);
+        }
         DeviceSlots *slots = dev_slots.count(device) ? dev_slots[device].get() : nullptr;
         // One launch's stay on the device: from its admission until its posterior kernels are done -- the library says
         // so (lcrc_set_kernel_done_callback) while the launch's decoder kernel, labels and posteriors are still on their
@@ -657,6 +696,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     // libm and the normalisations follow here, in the pinned buffer the posterior kernel then reads in place
                     float *feat = nullptr;
                     if (!tr.WaveStageEnergies(bstart.data(), blen.data(), cnt, &feat, foff.data())) { abort_run(tr.LastError()); return; }
+                    if (foff[cnt] != off.back()) { abort_run("frame counts of the launch plan and the GPU front-end differ"); return; }
                     trace(g, "energies back");
                     if (foff[cnt] > 0) {
                         const float shift = C.GetFloat("framenorm", "shift"), floor_ = C.GetFloat("framenorm", "min_floor");
@@ -685,6 +725,8 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
                     SlotHold hold(slots, tr);
                     trace(g, "slot");
                     if (!tr.WaveStageRun(bstart.data(), blen.data(), cnt, nullptr, foff.data())) { abort_run(tr.LastError()); return; }
+                    // (the launches were planned with FrontendFramesOf(): the library counts the frames of a file the same way)
+                    if (foff[cnt] != off.back()) { abort_run("frame counts of the launch plan and the GPU front-end differ"); return; }
                     ran_staged = true;
                     trace(g, "run returned");
                     h_post = tr.StagedPosteriors();
@@ -765,7 +807,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             std::unique_lock<std::mutex> l(mu);
             for (;;) {
                 if (!fatal.empty() || stop_seq >= 0) break;
-                const bool room = win.size() < max_window && staged_frames < max_staged_frames && staged_bytes < max_staged_bytes;
+                // (until the first context is up nothing takes launches: the host front-end works ahead meanwhile -- 0.1-0.2 s
+                //  of every core -- within a byte budget instead of the few launches' worth of frames of the steady state)
+                const bool frames_ok = contexts_up.load() == 0 && need_gpu ? staged_bytes < start_up_bytes : staged_frames < max_staged_frames;
+                const bool room = win.size() < max_window && frames_ok && staged_bytes < max_staged_bytes;
                 if (room && pending1 < max_pending_jobs) break;
                 if (!chunk.empty()) {                  // never wait on jobs that have not been handed to the pool yet
                     l.unlock();
@@ -821,10 +866,12 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     stats_.cpu_viterbi = viterbi_ns_.load() * 1e-9;
     stats_.host_threads = std::max(1, pool_->Size());
     for (double k : kms) stats_.gpu_kernel_ms += k;
+    stats_.contexts = contexts_up.load();
     stats_.files += files_done;
     stats_.frames += frames_done;
     stats_.seconds += std::chrono::duration<double>(clock::now() - t1).count();
     if (!fatal.empty()) return Fail(fatal);
+    if (fatal_pending_clone) return Fail("a GPU context could not be created\n");
     // a job whose stage 1 failed: everything before it has been written
     for (auto &it : win)
         if (!it->job.ok) return Fail(it->job.err);

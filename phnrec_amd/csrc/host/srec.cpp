@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -352,26 +353,43 @@ bool SpeechRec::Init(const std::string &config_file)
     return true;
 }
 
-static int FirstDevice()
+// PHNREC_DEVICE_MAP="0,0": the physical device of each of the -g N logical GPUs (default: 0..N-1).  Lets a 1-GPU box
+// run the -g 2 arrangement (4 contexts, one launch queue); on an 8-GPU node it picks the GPUs.
+bool SpeechRec::DeviceMap(std::vector<int> &devices)
 {
+    const int n = std::max(1, n_gpus_);
+    std::vector<int> dmap;
     if (const char *e = getenv("PHNREC_DEVICE_MAP")) {
-        char *end = nullptr;
-        const long v = strtol(e, &end, 10);
-        if (end != e && v >= 0) return (int)v;
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q || v < 0 || (*end && *end != ','))
+                return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
+            dmap.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+        }
+        if ((int)dmap.size() < n) return Fail("PHNREC_DEVICE_MAP names fewer devices than -g asks for\n");
     }
-    return 0;
+    devices.clear();
+    for (int g = 0; g < n; g++) devices.push_back(dmap.empty() ? g : dmap[(size_t)g]);
+    return true;
 }
 
 void SpeechRec::WarmUpGpuAsync()
 {
-    if (warmup_.joinable()) return;
-    const int dev = FirstDevice();
-    warmup_ = std::thread([dev] { (void)lcrc_device_warmup(dev); });    // failures surface in lcrc_create
+    if (!warmup_.empty()) return;
+    std::vector<int> devices;
+    if (!DeviceMap(devices)) { err_.clear(); devices.assign(1, 0); }      // (a bad map is reported where the contexts are planned)
+    std::sort(devices.begin(), devices.end());
+    devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
+    // one thread per distinct device: seven more HIP start-ups of 80-100 ms each would otherwise begin only when the
+    // list's workers create their contexts (failures surface in lcrc_create)
+    for (int dev : devices) warmup_.emplace_back([dev] { (void)lcrc_device_warmup(dev); });
 }
 
 SpeechRec::~SpeechRec()
 {
-    if (warmup_.joinable()) warmup_.join();
+    JoinWarmUp();
 }
 
 // Whether lcrc_frontend_configure would take this configuration (its own limits, restated: lin16 / A-law, frames of
@@ -422,71 +440,109 @@ std::string SpeechRec::SetUpContext(Traps &t)
 }
 
 // Contexts: `per_gpu` on each of the -g N GPUs.  A list wants three per GPU (kernel, copy-back and decoding of
-// successive launches overlap); one file wants one.  The first context of a GPU loads the model (GPUs in
-// parallel: one thread each), further ones share its weights on the device (lcrc_clone: no file reads, no
-// packing, no upload).
-bool SpeechRec::EnsureGpus(int per_gpu)
+// successive launches overlap); one file wants one.  Only the PLACES are made here: every context is built by its own
+// worker thread while the list is already running (BringUpContext), so the list starts at its first line and not behind
+// a set-up phase (srec.cpp:1246-1290), and the contexts of eight GPUs come up side by side.
+bool SpeechRec::PlanGpus(int per_gpu)
 {
     const int n = std::max(1, n_gpus_);
     // (PHNREC_CTX_PER_GPU overrides the default for experiments)
     if (const char *e = getenv("PHNREC_CTX_PER_GPU")) per_gpu = std::max(1, std::min(8, atoi(e)));
-    if (gpu_devices_.empty()) {
-        // PHNREC_DEVICE_MAP="0,0": the physical device of each of the -g N logical GPUs (default: 0..N-1).  Lets a
-        // 1-GPU box run the -g 2 arrangement (4 contexts, one launch queue); on an 8-GPU node it picks the GPUs.
-        std::vector<int> dmap;
-        if (const char *e = getenv("PHNREC_DEVICE_MAP")) {
-            for (const char *q = e; *q;) {
-                char *end = nullptr;
-                const long v = strtol(q, &end, 10);
-                if (end == q || v < 0 || (*end && *end != ','))
-                    return Fail(std::string("PHNREC_DEVICE_MAP must be a comma-separated list of GPU indices: ") + e + "\n");
-                dmap.push_back((int)v);
-                q = *end == ',' ? end + 1 : end;
-            }
-            if ((int)dmap.size() < n) return Fail("PHNREC_DEVICE_MAP names fewer devices than -g asks for\n");
-        }
-        for (int g = 0; g < n; g++) gpu_devices_.push_back(dmap.empty() ? g : dmap[g]);
+    if (gpu_devices_.empty() && !DeviceMap(gpu_devices_)) { gpu_devices_.clear(); return false; }
+    std::lock_guard<std::mutex> l(ctx_mu_);
+    if (gpus_.size() < (size_t)per_gpu * n) {
+        gpus_.resize((size_t)per_gpu * n);          // (context g + k * n serves GPU g)
+        ctx_state_.resize(gpus_.size(), 0);
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    // context k of GPU g; k == 0 loads the model, the others clone it
-    auto make = [&](int g, int k, std::unique_ptr<Traps> &out, std::string &err) {
-        std::unique_ptr<Traps> t(new Traps);
+    for (size_t i = 0; i < gpus_.size(); i++) ctx_state_[i] = gpus_[i] ? 1 : 0;      // (a failed place of an earlier run is tried again)
+    return true;
+}
+
+int SpeechRec::FrontendFramesOf(long long file_bytes) const
+{
+    const long long len = wave_.format == WF_LIN16 ? file_bytes / 2 : file_bytes;
+    return len > fe_vector_size_ ? (int)((len - fe_vector_size_) / fe_vector_step_ + 1) : 1;
+}
+
+int SpeechRec::BringUpContext(int idx, const ContextPlan &plan, std::string &err, const std::function<void(const char *)> &mark,
+                              const std::function<bool()> &worth_it)
+{
+    const int n = std::max(1, n_gpus_), g = idx % n, k = idx / n;
+    // The context whose weights this one shares on the device (lcrc_clone: no file reads, no packing, no upload): the first
+    // context of its GPU -- or, for a GPU's first context, that of an earlier logical GPU on the SAME physical device
+    // (PHNREC_DEVICE_MAP=0,0,...: one copy of the model per device however many logical GPUs are mapped onto it).
+    int base = k > 0 ? g : -1;
+    if (k == 0)
+        for (int q = 0; q < g; q++)
+            if (gpu_devices_[(size_t)q] == gpu_devices_[(size_t)g]) { base = q; break; }
+    Traps *t = nullptr;
+    std::unique_ptr<Traps> made;
+    {
+        std::unique_lock<std::mutex> l(ctx_mu_);
+        t = gpus_[(size_t)idx].get();
+        if (!t && base >= 0) {
+            ctx_cv_.wait(l, [&] { return ctx_state_[(size_t)base] != 0; });
+            if (ctx_state_[(size_t)base] < 0) {        // failed (its own message is the run's) or left out: so is this one
+                const int why = ctx_state_[(size_t)base];
+                ctx_state_[(size_t)idx] = why;
+                ctx_cv_.notify_all();
+                err.clear();
+                return why == -2 ? -1 : 0;
+            }
+        }
+    }
+    if (!t && base >= 0 && !worth_it()) {
+        std::lock_guard<std::mutex> l(ctx_mu_);
+        ctx_state_[(size_t)idx] = -2;
+        ctx_cv_.notify_all();
+        mark("ctx: left out");
+        return -1;
+    }
+    auto failed = [&](const std::string &msg) {
+        err = msg;
+        std::lock_guard<std::mutex> l(ctx_mu_);
+        if (!gpus_[(size_t)idx]) ctx_state_[(size_t)idx] = -1;
+        ctx_cv_.notify_all();
+        return 0;
+    };
+    if (!t) {
+        made.reset(new Traps);
+        t = made.get();
         t->SetSystem(C.GetString("posteriors", "system").c_str());
         t->SetTrapLen(C.GetInt("posteriors", "length"));
         t->SetHamming(C.GetBool("posteriors", "hamming"));
         t->SetNBanks(nbanks_);
         t->SetAddC0(C.GetBool("posteriors", "add_c0"));
         t->SetBunchSize(atoi(C.GetString("posteriors", "bunch_size").c_str()));
-        t->SetDevice(gpu_devices_[g]);
+        t->SetDevice(gpu_devices_[(size_t)g]);
         // outputs must not depend on how files are packed into launches (-g 1 and -g N write the same bytes)
         t->SetHiddenSplit(1);
-        if (!(k == 0 ? t->Init(config_dir_.c_str()) : t->InitClone(*gpus_[g]))) { err = t->LastError() + "\n"; return; }
-        err = SetUpContext(*t);
-        if (err.empty()) out = std::move(t);
-    };
-    // Two rounds: the first context of every GPU (GPUs in parallel), then ALL the clones at once -- a clone is a stream,
-    // a few events and small tables, ~10 ms of mostly waiting inside the runtime each; one after the other they were
-    // 20-30 ms in front of every list.
-    const int have = (int)gpus_.size() / n;
-    for (int round = 0; round < 2; round++) {
-        const int k_lo = round == 0 ? have : std::max(have, 1), k_hi = round == 0 ? std::min(per_gpu, 1) : per_gpu;
-        if (k_hi <= k_lo) continue;
-        if (round == 1 && warmup_.joinable()) warmup_.join();
-        const int cnt = (k_hi - k_lo) * n;
-        std::vector<std::unique_ptr<Traps>> made((size_t)cnt);
-        std::vector<std::string> errs((size_t)cnt);
-        if (cnt == 1) {
-            make(0, k_lo, made[0], errs[0]);
-        } else {
-            std::vector<std::thread> th;
-            for (int i = 0; i < cnt; i++) th.emplace_back([&, i] { make(i % n, k_lo + i / n, made[(size_t)i], errs[(size_t)i]); });
-            for (auto &t : th) t.join();
-        }
-        for (int i = 0; i < cnt; i++) if (!made[(size_t)i]) return Fail(errs[(size_t)i]);
-        for (int i = 0; i < cnt; i++) gpus_.push_back(std::move(made[(size_t)i]));      // (context g + k * n serves GPU g)
+        mark(base < 0 ? "ctx: create" : "ctx: clone");
+        if (!(base < 0 ? t->Init(config_dir_.c_str()) : t->InitClone(*gpus_[(size_t)base]))) return failed(t->LastError() + "\n");
+        mark("ctx: created");
+        const std::string e = SetUpContext(*t);
+        if (!e.empty()) return failed(e);
+        mark("ctx: front-end set");
     }
-    stats_.create_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return true;
+    // posterior writer path: both softening functions and the dump's byte order run in the posterior kernel's epilogue;
+    // -D: the decoder runs behind the posterior kernel and only labels cross PCIe
+    if (!t->ConfigureOutput(plan.soft, plan.n_soft, plan.big_endian) ||
+        !t->ConfigureDecoder(plan.device_decoder ? (int)phn_names_.size() : 0, states_per_phn_, time_pruning_, wpenalty_, !plan.device_decoder) ||
+        !t->SetDecoderOverlap(plan.decoder_overlap))
+        return failed(t->LastError() + "\n");
+    t->SetLaunchOrder(plan.launch_order);
+    t->SetWaitMode(plan.poll_us);
+    if (made) {
+        // up: clones of this GPU may be made, launches may be taken -- the buffers of full-size launches follow
+        std::lock_guard<std::mutex> l(ctx_mu_);
+        gpus_[(size_t)idx] = std::move(made);
+        ctx_state_[(size_t)idx] = 1;
+        ctx_cv_.notify_all();
+    }
+    mark("ctx: configured");
+    if (plan.reserve_rows > 0 && !t->Reserve(plan.reserve_rows, 256, plan.reserve_wave_bytes)) { err = t->LastError() + "\n"; return 0; }
+    mark("ctx: reserved");
+    return 1;
 }
 
 // ---- per-utterance stages --------------------------------------------------------------
@@ -517,7 +573,7 @@ void SpeechRec::Stage1(DataFormat in, DataFormat out, Job &job, bool host_featur
             return;
         }
         job.file_bytes = (long long)st.st_size;
-        job.frames = gpus_[0]->FrontendFrames(job.file_bytes);
+        job.frames = FrontendFramesOf(job.file_bytes);
         job.cols = nbanks_;
         return;
     }

@@ -37,9 +37,13 @@ DataFormat ParseDataFormat(const std::string &s);          // wf | par | post | 
 
 struct RunStats {
     long long frames = 0, files = 0;
-    double seconds = 0, gpu_kernel_ms = 0;      // seconds: processing without one-off GPU/pool set-up
+    double seconds = 0, gpu_kernel_ms = 0;      // seconds: the list from its first line to its last, context start-up included
     double init_seconds = 0, stage1_seconds = 0;
-    double create_seconds = 0;                  // of init_seconds: creating the GPU contexts (HIP start-up, model load, upload)
+    // The GPU contexts come up BESIDE the list (each context's worker creates it, then joins the running pipeline):
+    // create_seconds = from the start of the run until the last one was up, first_context_seconds = until the first was
+    // (HIP start-up, model load, pack, upload: no launch can start sooner) -- both overlap `seconds`, not init_seconds
+    double create_seconds = 0, first_context_seconds = 0;
+    int contexts = 0;                           // GPU contexts that came up and took launches (of the 2-3 per GPU planned)
     double first_launch_seconds = 0;            // wall time of the run's first launch call (code-object load, cold clock)
     // CPU seconds of the host stages, summed over threads: stage 1 (file read [+ front-end]; stat() with -F), file reads
     // into pinned memory (-F), gather into pinned memory, stage 3 (Viterbi / label formatting / dump writing)
@@ -104,10 +108,11 @@ public:
     // -E: the front-end's FFTs and bank sums on the GPU, ln() and the normalisations on the host: the host front-end's
     // features bit for bit at a tenth of its CPU time
     void SetGpuEnergies(bool v) { gpu_energies_ = v; }
-    // Starts the HIP runtime and the first GPU's context on a helper thread (lcrc_device_warmup): ~0.2 s that then overlap
-    // with Init(), the model files and their re-packing.  Call it as early as the conversion is known to need the GPU.
+    // Starts the HIP runtime and the primary context of EVERY distinct device the run will use (SetGpus first: -g N,
+    // PHNREC_DEVICE_MAP) on helper threads, one per device (lcrc_device_warmup): ~0.1-0.2 s each that then overlap with
+    // Init(), the model files, their re-packing and each other.  Call it as early as the conversion is known to need the GPU.
     void WarmUpGpuAsync();
-    void JoinWarmUp() { if (warmup_.joinable()) warmup_.join(); }
+    void JoinWarmUp() { for (auto &t : warmup_) if (t.joinable()) t.join(); }
     ~SpeechRec();
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)
     bool ProcessFileListLine(DataFormat in, DataFormat out, const std::string &line);
@@ -146,8 +151,26 @@ private:
     // device_done: softening (and, for dumps, the big-endian byte order) already applied by the GPU
     void Stage3(DataFormat out, Job &job, bool mlf, float *post, int cols, bool device_done = false);
     void EmitLabels(Job &job, bool mlf, const std::vector<Label> &labels);
-    bool EnsureGpus(int contexts_per_gpu);
+    // what every context of a run is configured with before it takes its first launch
+    struct ContextPlan {
+        lcrc_softening soft[2];
+        int n_soft = 1;
+        bool big_endian = false, device_decoder = false, decoder_overlap = false, launch_order = false;
+        int poll_us = 0;
+        int reserve_rows = 0;              // 0: buffers grow with the first launches
+        long long reserve_wave_bytes = 0;
+    };
+    bool DeviceMap(std::vector<int> &devices);            // physical device of each of the -g N logical GPUs
+    bool PlanGpus(int contexts_per_gpu);                  // device map + one (empty) place per context
+    // context `idx` (k * n_gpus + g): created if it does not exist yet -- the first of a GPU loads the model, the others
+    // wait for it and share its weights --, then configured per `plan`.  Called by the context's own worker thread.
+    // mark(what): the steps' names as they end (PHNREC_TRACE_PIPELINE's time line).  worth_it(): asked once, when a context
+    // that shares another's weights could be created (its base is up): false = the list will be over before this context
+    // could help -- it is not created (and neither are those that would share ITS place).  1 = up, 0 = failed (err), -1 = left out.
+    int BringUpContext(int idx, const ContextPlan &plan, std::string &err, const std::function<void(const char *)> &mark,
+                       const std::function<bool()> &worth_it);
     std::string SetUpContext(Traps &t);
+    int FrontendFramesOf(long long file_bytes) const;     // frames of a waveform file of that size (lcrc_frontend_frames' rule)
     void Log(const std::string &msg) const { if (verbose_) fputs(msg.c_str(), stdout); }
     bool Fail(const std::string &msg) { err_ = msg; return false; }
     std::string LabelNameForMlf(const std::string &file) const;        // srec.cpp:1424-1436
@@ -175,10 +198,14 @@ private:
     std::vector<std::string> phonemes_path_;
     std::string phoneme_list_;
     std::vector<std::string> phn_names_;              // dicts/phoneme_list, read once in Init
-    std::vector<std::unique_ptr<Traps>> gpus_;        // [context k of GPU g] at k * n_gpus + g
+    std::vector<std::unique_ptr<Traps>> gpus_;        // [context k of GPU g] at k * n_gpus + g; null until its worker has built it
+    std::vector<int> ctx_state_;                      // per context: 0 not yet, 1 up, -1 failed, -2 left out (ctx_mu_)
+    std::mutex ctx_mu_;
+    std::condition_variable ctx_cv_;
+    int fe_vector_size_ = 0, fe_vector_step_ = 1;    // melbanks/vector_size, vector_step (FrontendFramesOf)
     std::vector<int> gpu_devices_;                    // physical device of each logical GPU (PHNREC_DEVICE_MAP)
     std::unique_ptr<ThreadPool> pool_;
-    std::thread warmup_;
+    std::vector<std::thread> warmup_;
     RunStats stats_;
     MelBanks mb_proto_;
 };

@@ -10,7 +10,7 @@
 
 #include <string>
 
-#include "../../../include/lcrc.h"
+#include "../../../include/lcrc_experimental.h"      // lcrc.h (the Traps seam) + lcrc_pipeline.h (lists) + SetHiddenSplit / SetWaitMode
 
 namespace phnrec {
 

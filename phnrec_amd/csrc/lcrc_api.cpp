@@ -251,6 +251,16 @@ bool inject_alloc_failure()
     }
     return false;
 }
+// Test hook (lcrc_debug_fail_launch): the n-th posterior launch from now on fails before anything is queued.
+std::atomic<int> g_fail_launch{-1};
+bool inject_launch_failure()
+{
+    int v = g_fail_launch.load();
+    while (v >= 0) {
+        if (g_fail_launch.compare_exchange_weak(v, v - 1)) return v == 0;
+    }
+    return false;
+}
 hipError_t dev_alloc(void **p, size_t bytes)
 {
     *p = nullptr;
@@ -623,6 +633,9 @@ int launch(lcrc_ctx *c, const float *d_mel, const int *d_off, int n_utts, int n_
            hipStream_t s, float *const *dbg, int row_first, int row_count, bool timed)
 {
     if (row_count < 0) { row_first = 0; row_count = n_rows; }
+    if (inject_launch_failure()) return fail(c, LCRC_E_DEVICE, "injected launch failure (lcrc_debug_fail_launch)");
+    // (a call outside the overlapped path must not write posteriors a still-running decoder of this context reads)
+    if (!c->overlapped_call) { const int rc = settle_pending_decoders(c); if (rc) return rc; }
     if (c->system != SYS_LCRC) {
         if (dbg) return fail(c, LCRC_E_UNSUPPORTED, "stage probes exist for posteriors/system=LCRC only");
         if (row_first != 0 || row_count != n_rows)
@@ -1276,6 +1289,7 @@ int lcrc_stage_run(lcrc_ctx *c, const int *off, int n_utts)
         if (off[u + 1] < off[u]) return fail(c, LCRC_E_ARG, "lcrc_stage_run: offsets must be non-decreasing");
     const int n = off[n_utts];
     HIP_TRY(c, hipSetDevice(c->device));
+    OverlapScope scope(c);
     { const int rc0 = begin_overlapped_call(c); if (rc0) return rc0; }       // (every staged call, empty ones too: the sets alternate per call)
     if (n == 0) { c->label_utts = 0; return LCRC_OK; }
     if ((size_t)n > c->cap_rows) return fail(c, LCRC_E_ARG, "lcrc_stage_run: more rows than lcrc_stage_buffers reserved");
@@ -1504,6 +1518,14 @@ int lcrc_debug_fail_alloc(int nth)
     const char *e = getenv("LCRC_FAULT_INJECTION");
     if (!e || strcmp(e, "1") != 0) return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_debug_fail_alloc: set LCRC_FAULT_INJECTION=1");
     g_fail_alloc = nth;
+    return LCRC_OK;
+}
+
+int lcrc_debug_fail_launch(int nth)
+{
+    const char *e = getenv("LCRC_FAULT_INJECTION");
+    if (!e || strcmp(e, "1") != 0) return fail(nullptr, LCRC_E_UNSUPPORTED, "lcrc_debug_fail_launch: set LCRC_FAULT_INJECTION=1");
+    g_fail_launch = nth;
     return LCRC_OK;
 }
 

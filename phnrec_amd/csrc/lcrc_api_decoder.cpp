@@ -69,11 +69,24 @@ int ensure_post_rows(lcrc_ctx *c)
     return LCRC_OK;
 }
 
+// A decoder that an overlapped staged call left running is ordered only against LATER overlapped calls (the event waits
+// below).  Every other call on the context -- the synchronous entry points, a staged call after lcrc_set_posterior_readback(1)
+// or lcrc_decoder_configure(0) -- writes d_post on the context's stream and may start a decoder of its own that stores into
+// the same label buffers: such a call first waits here for both sets' decoders (lcrc.h: mixing entry points is allowed).
+int settle_pending_decoders(lcrc_ctx *c)
+{
+    if (!c->dec_pending && !c->alt.dec_pending) return LCRC_OK;
+    if (c->dec_stream) HIP_TRY(c, hipStreamSynchronize(c->dec_stream));
+    c->dec_pending = c->alt.dec_pending = false;
+    return LCRC_OK;
+}
+
 // Start of a staged call under lcrc_set_decoder_overlap: the call works on the set that the call BEFORE the last one used,
 // while the last call's decoder may still be reading and writing the other.
 int begin_overlapped_call(lcrc_ctx *c)
 {
-    if (!overlap_on(c)) return LCRC_OK;
+    c->overlapped_call = overlap_on(c);
+    if (!c->overlapped_call) return settle_pending_decoders(c);
     swap_decoder_sets(c);
     // what this call's kernels overwrite was read by the decoder two calls ago: behind it on the device, whether or not
     // the caller has fetched those labels
@@ -93,8 +106,9 @@ int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, 
     c->label_utts = 0;
     if (c->dec_P <= 0 || n_rows <= 0) return LCRC_OK;
     if (c->out_be) return fail(c, LCRC_E_ARG, "the decoder needs posteriors in host byte order (lcrc_output_configure big_endian=0)");
-    { const int rc = ensure_labels(c, (size_t)n_rows, (size_t)n_utts); if (rc) return rc; }
     const bool overlap = staged && overlap_on(c);
+    if (!overlap) { const int rc = settle_pending_decoders(c); if (rc) return rc; }      // (ensure_labels may free what a decoder still writes)
+    { const int rc = ensure_labels(c, (size_t)n_rows, (size_t)n_utts); if (rc) return rc; }
     hipStream_t ds = s;
     if (overlap) {
         if ((size_t)n_utts + 1 > c->cap_dec_off) {

@@ -432,7 +432,8 @@ int lcrc_wave_stage_run(lcrc_ctx *c, const long long *start, const long long *n_
     if ((size_t)extent + 16 > c->cap_bytes) return fail(c, LCRC_E_ARG, "lcrc_wave_stage_run: beyond the capacity lcrc_wave_stage_buffer reserved");
     int rows = 0;
     SlowTrace st;
-    int rc = post ? LCRC_OK : begin_overlapped_call(c);
+    OverlapScope scope(c);
+    int rc = post ? settle_pending_decoders(c) : begin_overlapped_call(c);
     if (rc) return rc;
     rc = run_frontend_staged(c, start, n_bytes, n_utts, extent, frame_off, &rows, false, &st);
     if (rc || rows == 0) { c->label_utts = 0; return rc; }

@@ -4,7 +4,7 @@
 // lcrc_api_decoder.cpp: the decoder on the device (label buffers, launch behind the posterior kernel, overlap mode).
 #ifndef PHNREC_LCRC_CTX_H
 #define PHNREC_LCRC_CTX_H
-#include "../../include/lcrc.h"
+#include "../../include/lcrc_experimental.h"      // (includes lcrc_pipeline.h and lcrc.h: the library defines them all)
 
 #include <hip/hip_runtime.h>
 
@@ -157,6 +157,7 @@ struct lcrc_ctx {
     size_t cap_dec_off = 0;
     hipEvent_t ev_dec_done = nullptr;    // behind the decoder kernel of this set's last launch
     bool dec_pending = false;            // ... recorded and not yet waited for
+    bool overlapped_call = false;        // inside a staged call that takes the overlapped path (begin_overlapped_call)
     struct DecSet {
         float *d_post = nullptr;
         size_t d_post_cap = 0;
@@ -212,6 +213,13 @@ bool overlap_on(const lcrc_ctx *c);
 void swap_decoder_sets(lcrc_ctx *c);
 int ensure_post_rows(lcrc_ctx *c);
 int begin_overlapped_call(lcrc_ctx *c);
+int settle_pending_decoders(lcrc_ctx *c);
+// a staged entry point's stay: whatever begin_overlapped_call decided ends with the call
+struct OverlapScope {
+    lcrc_ctx *c;
+    explicit OverlapScope(lcrc_ctx *x) : c(x) {}
+    ~OverlapScope() { if (c) c->overlapped_call = false; }
+};
 int decode_after(lcrc_ctx *c, const int *d_off, const int *h_first, int n_utts, int n_rows, const float *d_post,
                  hipStream_t s, bool staged = false);
 

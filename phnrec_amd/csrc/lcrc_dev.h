@@ -5,7 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/lcrc.h"
+#include "../../include/lcrc_experimental.h"
 
 namespace phnrec {
 

@@ -12,10 +12,16 @@ from phnrec_amd import capi, modelgen
 from tests.util import ROOT, model_dir
 
 
-def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "lcrc.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(lcrc_[a-z_0-9]+)\s*\(", txt)))
+HEADERS = ("lcrc.h", "lcrc_pipeline.h", "lcrc_experimental.h")      # the Traps seam; the "next" rows + list helpers; hooks
+
+
+def _declared_functions(headers=HEADERS):
+    names = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(lcrc_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names - {"lcrc_kernel_done_fn"})
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,8 +30,9 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 18
     for name in declared:
         assert hasattr(L, name), "libphnrec_lcrc.so does not export %s" % name
-    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with include/lcrc.h"
-    assert L.lcrc_abi_version() == 4      # include/lcrc.h LCRC_ABI_VERSION
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with include/*.h"
+    assert L.lcrc_abi_version() == 5      # include/lcrc.h LCRC_ABI_VERSION
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == sorted(HEADERS)
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (lcrc_[a-z_0-9]+)", out))
     assert set(declared) <= exported
@@ -137,17 +144,16 @@ def test_no_cpu_fallback():
                 assert not pat.search(txt), "%s reaches into oracle/: the product may not depend on it" % f
 
 
-def test_header_is_plain_c(tmp_path):
-    """include/lcrc.h is the boundary a C / cgo / JNI binding would include: it must compile as C99 on its
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h is the boundary a C / cgo / JNI binding would include: each header must compile as C99 on its
     own, and a C program that only takes the addresses of all entry points must link against the library"""
-    import re
     import subprocess
-    hdr = os.path.join(ROOT, "include", "lcrc.h")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
-                   check=True)
-    names = sorted(set(re.findall(r"\b(lcrc_[a-z_0-9]+)\s*\(", open(hdr).read())) - {"lcrc_ctx"})
+    for h in HEADERS:
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(ROOT, "include", h)], check=True)
+    names = _declared_functions()
     src = tmp_path / "link.c"
-    src.write_text('#include "lcrc.h"\n#include <stdio.h>\nint main(void) {\n  const void *p[] = {%s};\n'
+    src.write_text('#include "lcrc_experimental.h"\n#include <stdio.h>\nint main(void) {\n  const void *p[] = {%s};\n'
                    '  printf("%%d %%d\\n", (int)(sizeof p / sizeof p[0]), lcrc_abi_version());\n  return 0;\n}\n'
                    % ", ".join("(const void *)%s" % n for n in names))
     exe = tmp_path / "link"
@@ -159,20 +165,22 @@ def test_header_is_plain_c(tmp_path):
     assert int(out[0]) == len(names) >= 30 and int(out[1]) >= 1
 
 
-def test_device_ln_argument_checks_need_no_gpu():
-    """lcrc_device_ln validates its arguments before it touches a device: an unknown form, a negative count or missing arrays
-    are LCRC_E_ARG, an empty array is nothing to do; with values to compute it needs the GPU and says so (no CPU fallback)"""
-    x = np.array([1.0, 2.0, 0.0, -1.0], np.float32)
-    with pytest.raises(capi.LcrcError) as e:
-        capi.device_ln(x, 7)
-    assert e.value.code == capi.LCRC_E_ARG
-    assert capi.device_ln(np.zeros(0, np.float32), 1).size == 0
-    L = capi.load()
-    import ctypes as C
-    L.lcrc_device_ln.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]
-    assert L.lcrc_device_ln(0, 1, None, None, 4) == capi.LCRC_E_ARG and L.lcrc_device_ln(0, 1, None, None, -1) == capi.LCRC_E_ARG
-    import torch
-    if not torch.cuda.is_available():
-        with pytest.raises(capi.LcrcError) as e:
-            capi.device_ln(x, 1)
-        assert e.value.code == capi.LCRC_E_DEVICE
+def test_core_header_is_the_traps_seam_and_small():
+    """lcrc.h alone is what INTEGRATION.md's two adoption routes call (and the reference-side binding compiles against it
+    alone): at most 250 lines, none of the tuning / test hooks, none of the list pipeline's helpers"""
+    core = _declared_functions(("lcrc.h",))
+    txt = open(os.path.join(ROOT, "include", "lcrc.h")).read()
+    assert len(txt.splitlines()) <= 250
+    for must in ("lcrc_create", "lcrc_create_system", "lcrc_destroy", "lcrc_reset", "lcrc_push", "lcrc_delay", "lcrc_num_outputs",
+                 "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_last_error", "lcrc_set_arithmetic"):
+        assert must in core, must
+    for moved in ("lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_debug_fail_alloc", "lcrc_debug_fail_launch",
+                  "lcrc_posteriors_probe", "lcrc_set_wait_mode", "lcrc_set_mean_order", "lcrc_set_decoder_overlap",
+                  "lcrc_set_launch_order", "lcrc_wave_stage_run", "lcrc_reserve"):
+        assert moved not in core, moved
+    hooks = _declared_functions(("lcrc_experimental.h",))
+    assert set(hooks) >= {"lcrc_set_tile_frames", "lcrc_set_hidden_split", "lcrc_debug_fail_alloc", "lcrc_posteriors_probe",
+                          "lcrc_set_mean_order"}
+    # the binding of INTEGRATION.md includes lcrc.h and nothing else of this repository's headers
+    binding = open(os.path.join(ROOT, "tests", "integration", "traps_lcrc.cpp")).read()
+    assert '#include "lcrc.h"' in binding and "lcrc_pipeline.h" not in binding and "lcrc_experimental.h" not in binding

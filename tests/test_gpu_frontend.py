@@ -428,3 +428,57 @@ def test_decoder_overlap_is_inert_while_posteriors_are_read_back(capi):
     assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32)) and ctx.last_labels() == ref.last_labels()
     ref.close()
     ctx.close()
+
+
+def test_overlapped_decoder_is_settled_before_calls_of_other_entry_points(capi):
+    """A decoder left running by an overlapped staged call is ordered only against LATER overlapped calls.  Mixing entry
+    points is allowed (lcrc.h): a synchronous lcrc_posteriors_batch, a staged call with a caller's posterior buffer, or a
+    staged call after lcrc_set_posterior_readback(1), right behind an overlapped call on the same context, first waits
+    for that decoder -- the overlapped call's labels (fetched AFTER the other call) are the ones a synchronous context
+    gives, the other call's own labels and posteriors too, and the context goes on overlapping afterwards.  Long
+    utterances (59 900 samples = 747 frames, many per call) keep the decoder busy for milliseconds behind the call."""
+    raw = open(os.path.join(GOLD, "test.raw"), "rb").read()
+    big = [raw[:119800]] * 24                                   # 24 x 747 frames: a decoder launch of a few milliseconds
+    small = [raw[2000:42000], raw[50000:70000]]
+    mel = read_htk(os.path.join(GOLD, CZ, "test.mel")) - 11.0
+    off = np.array([0, 300, 747], np.int32)
+
+    def make():
+        c = _ctx(capi, CZ)
+        c.configure_output(("log",))
+        c.configure_decoder(45, 3, 40, -4.6875)
+        c.set_posterior_readback(False)
+        return c
+
+    ref = make()
+    ref.wave_decode_staged(big)
+    want_big = ref.last_labels()
+    ref.wave_decode_staged(small)
+    want_small = ref.last_labels()
+    ref.set_posterior_readback(True)
+    want_post = ref.posteriors_batch(mel, off)
+    want_batch = ref.last_labels()
+    want_wave_post, _ = ref.wave_to_posteriors_staged(small)
+    ref.set_posterior_readback(False)
+    assert sum(len(u) for u in want_big) > 1000 and len(want_batch[1]) > 10
+
+    ctx = make()
+    ctx.set_decoder_overlap(True)
+    for _ in range(3):
+        # (1) overlapped call, then the synchronous batch entry (decodes on the launch stream into the same label buffers)
+        ctx.wave_decode_staged(big)
+        got_post = ctx.posteriors_batch(mel, off)
+        assert ctx.last_labels() == want_batch
+        assert np.array_equal(got_post.view(np.uint32), want_post.view(np.uint32))
+        # (2) overlapped call, then read-back switched on: the staged call takes the synchronous road
+        ctx.wave_decode_staged(big)
+        ctx.set_posterior_readback(True)
+        p, _ = ctx.wave_to_posteriors_staged(small)
+        assert np.array_equal(p.view(np.uint32), want_wave_post.view(np.uint32)) and ctx.last_labels() == want_small
+        ctx.set_posterior_readback(False)
+        # (3) and overlapping again: two overlapped calls, both sets' labels
+        ctx.wave_decode_staged(big)
+        ctx.wave_decode_staged(small)
+        assert ctx.prev_labels() == want_big and ctx.last_labels() == want_small
+    ref.close()
+    ctx.close()
