@@ -435,9 +435,17 @@ def run_cli(exe, args, env, timeout=600):
     if pr.returncode != 0 or not stats:
         return {"error": "rc=%d %s" % (pr.returncode, pr.stderr.strip()[-300:])}, pr
     kv = dict(tok.split("=", 1) for tok in stats[-1].replace("(", "").replace(")", "").split() if "=" in tok)
-    return {"value": float(kv["frames_per_s"]), "unit": "frames/s", "list_wall_s": float(kv["wall_s"]),
+    # Since round 6 the contexts come up BESIDE the list: the CLI's wall_s runs from the list's first line to its last and
+    # contains first_ctx_s, the time until the first context could take a launch (HIP start-up, model load, upload: 0.2-0.3 s
+    # of runtime floor on these boxes).  `value` stays what it was in earlier rounds -- the rate of the list loop while
+    # contexts work on it: frames / (wall_s - first_ctx_s) --, `setup_s` what lies in front of the first launch, and
+    # `process_frames_per_s` (exec to exit) is the figure a caller of the CLI sees.
+    first_ctx = float(kv.get("first_ctx_s", 0))
+    loop_s = max(1e-6, float(kv["wall_s"]) - first_ctx)
+    return {"value": round(float(kv["frames"]) / loop_s, 1), "unit": "frames/s", "list_wall_s": round(loop_s, 3),
+            "list_from_first_line_s": float(kv["wall_s"]), "first_ctx_s": first_ctx, "contexts": int(kv.get("contexts", 0)),
             "process_wall_s": round(wall, 3), "xrt": float(kv["xRT"]), "gpu_kernel_ms": float(kv["gpu_kernel_ms"]),
-            "setup_s": float(kv["setup_s"]), "create_s": float(kv.get("create_s", 0)),
+            "setup_s": round(float(kv["setup_s"]) + first_ctx, 3), "create_s": float(kv.get("create_s", 0)),
             "first_launch_s": float(kv.get("first_launch_s", 0)), "main_s": float(kv.get("main_s", 0)),
             "host_cpu_s": float(kv.get("host_cpu_s", 0)), "host_threads": int(kv.get("host_threads", 0)),
             "cpu_s_by_stage": {k: float(kv[k]) for k in ("stage1", "read", "gather", "decode_write", "viterbi") if k in kv},
@@ -606,6 +614,31 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         except Exception:
             pass
         out["weak_list"] = weak
+        if n_gpus == 1:
+            # configs[3] itself (the 1x list) as `-g 8` takes it, eight logical GPUs on this box's one device: what the run
+            # picks by itself (F+D,auto; 2 contexts per GPU planned).  A process-level criterion: set-up + list no longer than
+            # `-g 1` needs on the same device (round 5: 0.60 + 0.30 against 0.30 + 0.28 s -- 24 contexts built in front of a
+            # 0.28 s list; now the contexts come up beside the list, share ONE copy of the model per device, and those the
+            # list would not live to see are left out).  Better of two runs, as the modes above.
+            try:
+                e8 = dict(env, PHNREC_DEVICE_MAP=",".join([str(dmap[0])] * 8))
+                best = None
+                for _ in range(2):
+                    r, _pr = run_cli(exe, ["-c", mdir, "-l", lst, "-m", os.path.join(td, "g8.mlf"), "-g", "8"], e8)
+                    if "error" in r or best is None or r["process_wall_s"] < best["process_wall_s"]:
+                        best = r
+                    if "error" in r:
+                        break
+                if "error" not in best:
+                    best["mlf_equals_g1"] = open(os.path.join(td, "g8.mlf")).read() == open(mlfs["gpu_frontend_F"]).read()
+                    g1 = out.get("gpu_frontend_decoder_F_D", {})
+                    if "process_wall_s" in g1:
+                        best["g1_F_D_process_wall_s"] = g1["process_wall_s"]
+                        best["g1_F_D_setup_plus_list_s"] = round(g1["setup_s"] + g1["list_wall_s"], 3)
+                    best["setup_plus_list_s"] = round(best["setup_s"] + best["list_wall_s"], 3)
+                out["as_g8_on_1x_list"] = best
+            except Exception as e:
+                out["as_g8_on_1x_list"] = {"error": repr(e)}
         # the headline's system (CZ) through the same list and modes (round 3's cli_e2e leg timed a 0.06-0.1 s loop of
         # 2000 files: inside the start-up ramp this list exists to amortise)
         cz_dir = os.path.join(ROOT, "tests", "golden", "models", "PHN_CZ_SPDAT_LCRC_N1500")
@@ -756,8 +789,11 @@ def four_systems_leg(n_gpus, dmap, n_files=2500):
                     kv = dict(tok.split("=", 1) for tok in ln.replace("(", "").replace(")", "").split() if "=" in tok)
                     nf = int(kv["files"])
                     name = systems[3] if nf == n_files else systems[n_files - 1 - nf]
-                    per[name] = {"files": nf, "frames": int(kv["frames"]), "frames_per_s": float(kv["frames_per_s"]),
-                                 "list_wall_s": float(kv["wall_s"]), "main_s": float(kv["main_s"]), "xrt": float(kv["xRT"]),
+                    # (the list loop while contexts work on it, as in run_cli: wall_s minus the time until the first context was up)
+                    loop_s = max(1e-6, float(kv["wall_s"]) - float(kv.get("first_ctx_s", 0)))
+                    per[name] = {"files": nf, "frames": int(kv["frames"]), "frames_per_s": round(int(kv["frames"]) / loop_s, 1),
+                                 "list_wall_s": round(loop_s, 3), "first_ctx_s": float(kv.get("first_ctx_s", 0)),
+                                 "main_s": float(kv["main_s"]), "xrt": float(kv["xRT"]), "contexts": int(kv.get("contexts", 0)),
                                  "mode": kv.get("mode"), "host_cpu_s": float(kv["host_cpu_s"])}
                     tot += int(kv["frames"])
                 r = {"per_system": per, "frames": tot, "process_wall_s": round(wall, 3),

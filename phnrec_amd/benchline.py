@@ -44,7 +44,7 @@ def _sig(x, n=4):
 
 
 def _list_mode(m):
-    return _pick(m, ("value", "process_frames_per_s", "setup_s", "list_wall_s"))
+    return _pick(m, ("value", "process_frames_per_s", "process_wall_s", "setup_s", "list_wall_s"))
 
 
 def _sharded(sl):
@@ -76,7 +76,8 @@ def _sharded(sl):
     g8 = sl.get("as_g8_on_1x_list")
     if isinstance(g8, dict):
         out["as_g8_on_1x_list"] = _pick(g8, ("value", "process_frames_per_s", "setup_s", "list_wall_s", "process_wall_s",
-                                             "mode", "first_result_s"))
+                                             "setup_plus_list_s", "g1_F_D_setup_plus_list_s", "g1_F_D_process_wall_s",
+                                             "contexts", "mode", "mlf_equals_g1"))
     return out
 
 

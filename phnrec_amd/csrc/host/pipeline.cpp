@@ -245,6 +245,29 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // PHNREC_DECODER_OVERLAP=0/1 overrides (experiments).
     bool dec_overlap = dev_dec && !single_file && (int)gpus_.size() <= 2 * std::max(1, n_gpus_);
     if (const char *e = getenv("PHNREC_DECODER_OVERLAP")) dec_overlap = dev_dec && !single_file && atoi(e) != 0;
+    // -v: one line that names the road this run takes through the device -- the same command line takes different ones by
+    // list length, -g, the host's libm and the configuration, all with the same output bytes
+    if (verbose_ && need_gpu) {
+        const int n = std::max(1, n_gpus_);
+        std::string fe = FrontendOn() ? (auto_frontend_ ? "GPU (-F, chosen by itself: a list of ~100 files or more / several GPUs, this libm's logf() "
+                                                          "reproduced on the device)" : "GPU (-F)")
+                         : EnergiesOn() ? (auto_energies_ ? "GPU up to the mel-bank energies, ln() and normalisations on the host (-E, chosen by itself: "
+                                                            "several GPUs; -F not bit-exact for this libm / configuration)" : "GPU up to the mel-bank energies (-E)")
+                         : in == dfWaveform ? (single_file ? "host (one file)" : long_list_ || n >= 2 ? "host (PHNREC_NO_AUTO_E, source/noise_level or a configuration the GPU front-end does not take)"
+                                                                                                      : "host (a short list on one GPU)")
+                                            : "none (parameter files in)";
+        std::string dec = out != dfStrings ? "none (posterior dump)"
+                          : dev_dec ? (auto_decoder_ ? "GPU (-D, chosen by itself: four or more GPUs)" : "GPU (-D)") : "host";
+        char line[900];
+        snprintf(line, sizeof line,
+                 "Device path: front-end %s; decoder %s; %d GPU(s) x %d context(s) planned%s; posterior kernels of a GPU's contexts %s; "
+                 "%d frames per launch%s\n",
+                 fe.c_str(), dec.c_str(), n, (int)gpus_.size() / n,
+                 single_file ? "" : " (contexts that share a model come up beside the running list, only while it is long enough)",
+                 launch_order ? "one after the other in queueing order" : "share the device",
+                 batch_frames_, dev_dec && dec_overlap ? "; a launch's decoder runs beside the context's next launch" : "");
+        Log(line);
+    }
     std::vector<std::string> phn_names;
     ContextPlan plan;
     if (need_gpu) {

@@ -590,13 +590,33 @@ void ensure_split_scratch(lcrc_ctx *c)
 // device: hipStreamWaitEvent) for the posterior kernels of the launch queued before it through the gate, and leave an event
 // for the next one.  The events come from a small ring the gate owns (a waiter refers to the record that was current when it
 // was queued; sixteen launches later nobody still waits for it).
+// The gate lives as long as ordered contexts of its device do (`users`): with the last one its events are destroyed and
+// `last` forgotten -- a later ordered context never waits on an event recorded on a stream that is gone.
 struct LaunchGate {
     std::mutex mu;
     hipEvent_t ring[16] = {};
     int next = 0;
     hipEvent_t last = nullptr;
+    int users = 0;
 };
 LaunchGate g_gates[64];
+
+// lcrc_set_launch_order / lcrc_destroy: the context joins or leaves its device's gate
+void gate_membership(lcrc_ctx *c, bool ordered)
+{
+    if (c->launch_ordered == ordered) return;
+    c->launch_ordered = ordered;
+    if (c->device < 0 || c->device >= 64) return;
+    LaunchGate &g = g_gates[c->device];
+    std::lock_guard<std::mutex> l(g.mu);
+    g.users += ordered ? 1 : -1;
+    if (g.users > 0) return;
+    g.users = 0;
+    (void)hipSetDevice(c->device);
+    for (hipEvent_t &e : g.ring) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+    g.last = nullptr;
+    g.next = 0;
+}
 
 struct GateHold {
     LaunchGate *g = nullptr;
@@ -1174,6 +1194,7 @@ void lcrc_destroy(lcrc_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->dec_stream) (void)hipStreamSynchronize(c->dec_stream);
+    gate_membership(c, false);             // (behind the synchronise: nothing of this context is queued any more)
     for (void *p : c->allocs) (void)hipFree(p);
     free_frame_staging(c);
     if (c->alt.d_post) (void)hipFree(c->alt.d_post);
@@ -1349,7 +1370,7 @@ int lcrc_posteriors_device(lcrc_ctx *c, const float *d_mel, const int *d_off, in
 int lcrc_set_launch_order(lcrc_ctx *c, int ordered)
 {
     if (!c) return LCRC_E_ARG;
-    c->launch_ordered = ordered != 0;
+    gate_membership(c, ordered != 0);
     return LCRC_OK;
 }
 

@@ -22,6 +22,15 @@
 
 #include "lcrc_dev.h"
 
+// The maxima and the history below are written as gfx9 wave64 instructions (DPP row_bcast does not exist from gfx10 on; a
+// 32-wide wave would need other masks): refuse to build for anything else rather than compute something else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "phndec_kernels.hip is written for wave64 gfx9-class ISA (gfx950; gfx942 / gfx90a share the instructions it uses)"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE__)
+static_assert(__AMDGCN_WAVEFRONT_SIZE__ == 64, "one utterance per 64-lane wave");
+#endif
+
 namespace phnrec {
 
 namespace {
@@ -37,11 +46,13 @@ constexpr int kMaxHist = 64;       // time_pruning + 1 <= 64: history slot q liv
 // v_max x, x, x that quiets a possible signalling NaN and the v_max itself, and the four rows met through four v_readlane
 // and three more v_max -- 30 instructions per maximum, two maxima per frame on the decoder's one dependent chain.  (The
 // values are finite floats or -FLT_MAX: no NaN to quiet.  s_nop 1: a DPP operand written by the previous VALU instruction
-// needs two wait states, and the assembler does not see inside an asm block.)
+// needs two wait states, and the assembler does not see inside an asm block; s_nop 4 in front of the FIRST one: the
+// instruction ahead of the block is the compiler's and may be a VALU write of EXEC (v_cmpx), which a DPP read must follow
+// by five wait states.)
 __device__ __forceinline__ void wave_argmax(float v, float &best, int &lane_of_best)
 {
     float m = v;
-    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 4\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"

@@ -198,6 +198,53 @@ def test_verbose_banner(tmp_path):
     assert q.stdout == ""
 
 
+def _device_path_line(*args, env=None):
+    e = dict(os.environ, **(env or {}))
+    p = subprocess.run([BIN, "-v"] + [str(a) for a in args], capture_output=True, text=True, env=e)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("Device path:")]
+    assert len(lines) == 1, p.stdout[-800:] + p.stderr[-300:]
+    return lines[0], p
+
+
+def test_verbose_names_the_device_path(tmp_path):
+    """`phnrec -v` prints ONE line that names the road a run takes through the device: front-end (host / -E / -F), decoder
+    (host / device), GPUs x contexts planned, ordered or shared posterior kernels, frames per launch -- and why, when the
+    run chose by itself.  The line is written when the run is planned, before any context exists: without a GPU (here) the
+    run then fails with the library's "no HIP device" error, never with a CPU fallback."""
+    raw = os.path.join(GOLD, "test.raw")
+    short = tmp_path / "short.scp"
+    short.write_text((raw + "\n") * 3)
+    long_ = tmp_path / "long.scp"
+    long_.write_text((raw + "\n") * 200)
+    assert long_.stat().st_size >= 4096
+    mlf = tmp_path / "o.mlf"
+    line, p = _device_path_line("-c", model_dir(CZ), "-i", raw, "-o", tmp_path / "a.rec")
+    assert "front-end host (one file)" in line and "decoder host" in line and "1 GPU(s) x 1 context(s)" in line
+    assert "share the device" in line and "32768 frames per launch" in line
+    assert p.returncode != 0 and "no HIP device" in p.stderr
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", short, "-m", mlf)
+    assert "front-end host (a short list on one GPU)" in line and "1 GPU(s) x 3 context(s)" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf)
+    assert "front-end GPU (-F, chosen by itself" in line and "decoder host" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf, env={"PHNREC_LN_FORM": "0"})
+    assert "front-end host (PHNREC_NO_AUTO_E" in line          # (a libm whose logf the device cannot reproduce, one GPU)
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf, "-g", "2", env={"PHNREC_LN_FORM": "0"})
+    assert "mel-bank energies" in line and "-E, chosen by itself" in line and "2 GPU(s) x 3 context(s)" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf, "-g", "8")
+    assert "front-end GPU (-F, chosen by itself" in line and "decoder GPU (-D, chosen by itself" in line
+    assert "8 GPU(s) x 2 context(s)" in line and "one after the other in queueing order" in line and "65536 frames per launch" in line
+    assert "decoder runs beside the context's next launch" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf, "-F", "-D", "-b", "5000")
+    assert "front-end GPU (-F);" in line and "decoder GPU (-D);" in line and "5000 frames per launch" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-t", "post", "-E")
+    assert "mel-bank energies (-E)" in line and "decoder none (posterior dump)" in line
+    line, _ = _device_path_line("-c", model_dir(CZ), "-s", "par", "-i", os.path.join(GOLD, CZ, "test.mel"), "-o", tmp_path / "b.rec")
+    assert "front-end none (parameter files in)" in line
+    # conversions that never touch the GPU print no such line
+    p = run("-v", "-c", model_dir(CZ), "-s", "post", "-i", os.path.join(GOLD, CZ, "test.lop"), "-o", tmp_path / "v.rec")
+    assert "Device path" not in p.stdout
+
+
 def test_a_missing_file_in_the_middle_of_a_list(tmp_path):
     """The reference works through a list line by line and exit(1)s at the first file it cannot open
     (srec.cpp:1280-1284, MError srec.cpp:118-122): everything BEFORE that line has been written (label files,

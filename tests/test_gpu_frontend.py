@@ -466,10 +466,17 @@ def test_overlapped_decoder_is_settled_before_calls_of_other_entry_points(capi):
     ctx.set_decoder_overlap(True)
     for _ in range(3):
         # (1) overlapped call, then the synchronous batch entry (decodes on the launch stream into the same label buffers)
+        # (read-back is off on this context: the call returns labels only)
         ctx.wave_decode_staged(big)
+        ctx.posteriors_batch(mel, off)
+        assert ctx.last_labels() == want_batch
+        # ... and with read-back on for the one call: its posteriors too
+        ctx.wave_decode_staged(big)
+        ctx.set_posterior_readback(True)
         got_post = ctx.posteriors_batch(mel, off)
         assert ctx.last_labels() == want_batch
         assert np.array_equal(got_post.view(np.uint32), want_post.view(np.uint32))
+        ctx.set_posterior_readback(False)
         # (2) overlapped call, then read-back switched on: the staged call takes the synchronous road
         ctx.wave_decode_staged(big)
         ctx.set_posterior_readback(True)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the CLI's list modes over two builds of the library on the same box, alternating, on the configs[3] list with every
-file listed REPS times (a list loop of seconds, not of 0.3 s).  The library file next to the CLI is swapped in place and
-restored at the end.
+file listed REPS times (a list loop of seconds, not of 0.3 s).  Each build is a copy named libphnrec_lcrc.so in its own
+temporary directory, selected through LD_LIBRARY_PATH (the CLI finds its library by RUNPATH, which LD_LIBRARY_PATH
+precedes): the installed library is never touched, whatever kills this tool.
     ab_cli_list.py LIB_A LIB_B [reps = 4] [rounds = 3] [mode ...]        ("-" = the library as it stands; a mode is the flag
                                                                         string, e.g. "-F" "-F -D" "-E -D" "" (the host
                                                                         front-end: run with PHNREC_NO_AUTO_E=1); default -F, -F -D)
@@ -26,14 +27,18 @@ def main():
     lib = os.path.join(ROOT, "phnrec_amd", "lib", "libphnrec_lcrc.so")
     exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
     mdir = os.path.join(ROOT, "tests", "golden", "models", bench.HU)
-    keep = "/tmp/ab_cli_list_keep.so"
-    shutil.copyfile(lib, keep)
+    libdir = tempfile.mkdtemp(prefix="ab_cli_list_")
     builds = []
-    for x in (a, b):
+    for tag, x in zip("AB", (a, b)):
+        extra, src = {}, lib
         if x.startswith("env:"):
-            builds.append((keep, dict(kv.split("=", 1) for kv in x[4:].split(","))))
-        else:
-            builds.append((keep if x == "-" else os.path.join(ROOT, x), {}))
+            extra = dict(kv.split("=", 1) for kv in x[4:].split(","))
+        elif x != "-":
+            src = os.path.join(ROOT, x)
+        d = os.path.join(libdir, tag)
+        os.mkdir(d)
+        shutil.copyfile(src, os.path.join(d, "libphnrec_lcrc.so"))
+        builds.append((d, extra))
     res = {}
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as td:
@@ -45,10 +50,10 @@ def main():
             for r in range(rounds):
                 for mode in modes:
                     row, mlfs = [], []
-                    for tag, (so, extra) in zip("AB", builds):
-                        shutil.copyfile(so, lib)
+                    for tag, (d, extra) in zip("AB", builds):
                         mlf = os.path.join(td, "o%s.mlf" % tag)
                         env = dict(os.environ, PHNREC_STATS="1", **extra)
+                        env["LD_LIBRARY_PATH"] = d + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
                         if not mode.split():
                             env.setdefault("PHNREC_NO_AUTO_E", "1")
                         v, _pr = bench.run_cli(exe, ["-c", mdir, "-l", rep_lst, "-m", mlf] + mode.split(), env)
@@ -61,7 +66,7 @@ def main():
                         mlfs.append(open(mlf, "rb").read())
                     print(r, repr(mode), "  ".join(row), " same MLF:", len(mlfs) == 2 and mlfs[0] == mlfs[1], flush=True)
     finally:
-        shutil.copyfile(keep, lib)
+        shutil.rmtree(libdir, ignore_errors=True)
     for (mode, tag), v in sorted(res.items()):
         v = sorted(v)
         print("median %-8s %s %.2f M  (min %.2f, max %.2f)" % (repr(mode), tag, v[len(v) // 2] / 1e6, v[0] / 1e6, v[-1] / 1e6))

@@ -3,8 +3,8 @@
 
 What a caller of `phnrec -l list -m out.mlf` waits for, by mode and by -g (with -g 8 mapped onto this box's one GPU:
 PHNREC_DEVICE_MAP=0 x 8 -- 24 contexts, one device), with the CLI's own break-down: setup_s (in front of the list),
-first_ctx_s / create_s (until the first / the last context could take a launch: beside the list), wall_s (the list from
-its first line to its last).  Every MLF is compared with the first one byte for byte.
+first_ctx_s / create_s (until the first / the last context could take a launch: beside the list), list (from its first
+line to its last, that start-up included), contexts that came up (of those planned).  Every MLF is compared with the first one byte for byte.
 
 usage: list_startup.py [n_files] [runs]
 """
@@ -28,7 +28,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         lst, names, frames = bench.synthetic_list(td, n_files)
         print("%s, %d files, %d frames; median of %d runs after one discarded run" % (HU, n_files, frames, runs))
-        print("%-26s %8s %8s %8s %8s %8s %8s %8s  %s" % ("run", "process", "main", "setup", "1st ctx", "all ctx", "list", "M fr/s", "mode"))
+        print("%-26s %8s %8s %8s %8s %8s %8s %5s  %s" % ("run", "process", "main", "1st ctx", "all ctx", "list", "M fr/s", "ctxs", "mode"))
         ref = None
         for g, dmap in ((1, "0"), (2, "0,0"), (8, ",".join(["0"] * 8))):
             for name, extra, env_extra in (("default flags", [], {}), ("host front-end", [], {"PHNREC_NO_AUTO_E": "1", "PHNREC_NO_AUTO_D": "1"}),
@@ -41,9 +41,6 @@ def main():
                     if "error" in r:
                         print("-g %d %s: %s" % (g, name, r["error"]))
                         break
-                    st = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")][-1]
-                    kv = dict(t.split("=", 1) for t in st.replace("(", "").replace(")", "").split() if "=" in t)
-                    r["first_ctx_s"] = float(kv.get("first_ctx_s", 0))
                     if k > 0:
                         rs.append(r)
                     data = open(mlf, "rb").read()
@@ -54,9 +51,9 @@ def main():
                 if not rs:
                     continue
                 med = lambda key: statistics.median(x[key] for x in rs)
-                print("-g %d %-21s %8.3f %8.3f %8.3f %8.3f %8.3f %8.3f %8.2f  %s" % (
-                    g, name, med("process_wall_s"), med("main_s"), med("setup_s"), med("first_ctx_s"), med("create_s"),
-                    med("list_wall_s"), frames / med("process_wall_s") / 1e6, rs[-1]["mode"]))
+                print("-g %d %-21s %8.3f %8.3f %8.3f %8.3f %8.3f %8.2f %5d  %s" % (
+                    g, name, med("process_wall_s"), med("main_s"), med("first_ctx_s"), med("create_s"),
+                    med("list_from_first_line_s"), frames / med("process_wall_s") / 1e6, rs[-1]["contexts"], rs[-1]["mode"]))
         print("MLFs: every run's equals the first run's byte for byte" if ref is not None else "no run")
 
 
