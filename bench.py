@@ -733,7 +733,7 @@ def sharded_list_leg(n_gpus, dmap, n_files):
     return out
 
 
-def four_systems_leg(n_gpus, dmap, n_files=2500):
+def four_systems_leg(n_gpus, dmap, n_files=2500, variants=None):
     """BASELINE configs[4]: all four LCRC systems at once, two GPUs each, mixed 8 / 16 kHz lists, end to end.
     tools/run_four_systems.sh starts four `phnrec -g 2` processes (CZ, HU, RU on 8 kHz lin16 files, EN on 16 kHz), each on its
     GPU pair; the pairs come from the ranks' device map -- 8 GPUs: 0,1 2,3 4,5 6,7; fewer: the pairs wrap around; ONE GPU:
@@ -774,11 +774,12 @@ def four_systems_leg(n_gpus, dmap, n_files=2500):
         env = dict(os.environ, PHNREC_GPU_PAIRS=" ".join(pairs), PHNREC_BIN=exe)
         env.pop("PHNREC_DEVICE_MAP", None)
         args = [a for pr in zip(dirs, lists) for a in pr]
-        for key, extra in (("default_flags", []), ("gpu_frontend_decoder_F_D", ["-F", "-D"])):
+        # variants (tools/four_systems_ab.py): (key, extra flags, extra environment)
+        for key, extra, env_extra in (variants or (("default_flags", [], {}), ("gpu_frontend_decoder_F_D", ["-F", "-D"], {}))):
             best = None
             for _ in range(2):               # the better of two runs (the first warms the page cache)
                 t0 = time.perf_counter()
-                pr = subprocess.run(["bash", script] + args + extra, env=env, capture_output=True, text=True, timeout=900)
+                pr = subprocess.run(["bash", script] + args + extra, env=dict(env, **env_extra), capture_output=True, text=True, timeout=900)
                 wall = time.perf_counter() - t0
                 stats = [ln for ln in pr.stderr.splitlines() if ln.startswith("phnrec: files=")]
                 if pr.returncode != 0 or len(stats) != 4:
