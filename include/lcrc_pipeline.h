@@ -19,8 +19,9 @@ extern "C" {
 /* Optional: starts the HIP runtime and GPU `device_id`'s context (~0.2 s in a fresh process, by far the largest part of
  * a first lcrc_create) and returns when they are up.  Thread-safe; meant to be called from a helper thread at program
  * start so that the caller's own initialisation -- configuration, the model files and their re-packing inside
- * lcrc_create, the first file's front-end -- overlaps with it (the CLI does).  It also brings the posterior kernels' code
- * object onto the device (20-40 ms that a context's creation or first launch pays otherwise; beside the caller's
+ * lcrc_create, the first file's front-end -- overlaps with it (the CLI does, one thread per device it will use).  It also
+ * brings the library's code objects -- posterior kernels, then front-end and decoder -- onto the device (15-40 ms each that a
+ * context's creation or the first launch of each kind pays otherwise; beside the caller's
  * lcrc_create -- stream, weight upload -- it costs nothing: a one-file `phnrec` run 0.15-0.24 s instead of 0.21-0.29 on
  * the same boxes).  No reference counterpart: the reference has no device to bring up. */
 int lcrc_device_warmup(int device_id);

@@ -29,6 +29,7 @@ struct FrontendParams {
 hipError_t frontend_ln_launch(float *x, size_t n, int form, hipStream_t stream);
 
 hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream);
+hipError_t frontend_preload_code();
 // host (pinned, mapped) -> device by a kernel instead of a copy command; both 16-byte aligned, `bytes` rounded up to 16
 hipError_t pull_bytes_launch(const void *mapped_src, void *dst, size_t bytes, hipStream_t stream);
 // Sentence mean normalisation.  means: device scratch [n_utts][nbanks].  block_off [n_utts + 1] (first

@@ -600,6 +600,14 @@ hipError_t frontend_launch(const FrontendParams &p, hipStream_t stream)
     return hipGetLastError();
 }
 
+// This file's code object onto the current device (the runtime loads a code object with the first launch of one of its
+// kernels: 15-20 ms that a list's first waveform launch paid; lcrc_device_warmup pays them on its helper thread instead)
+hipError_t frontend_preload_code()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&melbank_kernel<256>));
+}
+
 int meannorm_blocks(int rows) { return (rows + kMeanBlock - 1) / kMeanBlock; }
 
 hipError_t meannorm_launch(float *mel, const int *frame_off, const int *block_off, int n_blocks, float *partial,

@@ -183,6 +183,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     // enforces; anything else keeps the host front-end).  One file, and short lists on one GPU, keep the host front-end.
     // PHNREC_NO_AUTO_E=1 keeps it whatever the list and -g say.  The choice lives in auto_frontend_ / auto_energies_ /
     // auto_decoder_: what the caller set (SetGpuFrontend, SetGpuEnergies, SetGpuDecoder) is never overwritten.
+    // THE FIRST CALL DECIDES: contexts are configured for a front-end when they are created and live as long as this
+    // SpeechRec, so the choice is made once, while no context has been planned, and holds for every later call on the object
+    // (a single file first, then a long list: the list keeps the host front-end; the CLI makes one call per process).
+    // ModeString() and the default frames per launch report that first choice.
     if (gpus_.empty()) {
         const bool eligible = need_gpu && !single_file && in == dfWaveform && !gpu_frontend_ && !gpu_energies_ &&
                               wave_.noise_level == 0.0f && GpuFrontendTakesConfig() && !getenv("PHNREC_NO_AUTO_E");

@@ -1057,8 +1057,11 @@ int lcrc_device_warmup(int device_id)
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
     HIP_TRY(nullptr, hipSetDevice(device_id));
     HIP_TRY(nullptr, hipFree(nullptr));                 // brings the device's primary context up
-    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights)
+    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights); then the
+    // front-end's and the decoder's (15-20 ms each that the first waveform / decoder launch of the process paid otherwise)
     (void)lcrc_preload_code();
+    (void)frontend_preload_code();
+    (void)phndec_preload_code();
     return LCRC_OK;
 }
 

@@ -184,6 +184,7 @@ struct PhnDecParams {
     int *count;             // [n_utts]
 };
 hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream);
+hipError_t phndec_preload_code();
 
 // launcher (lcrc_kernels.hip)
 hipError_t lcrc_launch(const LcrcParams &p, hipStream_t stream, const char **variant_name);

@@ -265,6 +265,13 @@ __global__ __launch_bounds__(64 * kDecWaves, 8) void phndec_kernel(const PhnDecP
     if (lane == 0) p.count[u] = nlab + ntail;
 }
 
+// this file's code object onto the current device ahead of the first decoder launch (lcrc_device_warmup)
+hipError_t phndec_preload_code()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phndec_kernel<3>));
+}
+
 hipError_t phndec_launch(const PhnDecParams &p, hipStream_t stream)
 {
     if (p.n_utts <= 0) return hipSuccess;

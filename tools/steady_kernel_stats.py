@@ -25,8 +25,12 @@ def main():
     if len(sys.argv) > 4:
         import json
         import re
-        line = [ln for ln in open(sys.argv[4]).read().splitlines() if ln.startswith("{")][-1]
-        nums = [int(v) for v in re.findall(r"\d+", json.loads(line)["roofline"]["launches_timed"])]
+        text = open(sys.argv[4]).read()
+        try:                                        # the full record (bench.py --detail-out: one indented JSON document) ...
+            rec = json.loads(text)
+        except ValueError:                          # ... or a file whose last line is a record (earlier rounds' stdout)
+            rec = json.loads([ln for ln in text.splitlines() if ln.startswith("{")][-1])
+        nums = [int(v) for v in re.findall(r"\d+", rec["roofline"]["launches_timed"])]
         assert nums[0] == n, (nums, n)
         first = sum(nums[1:])                       # launches before the timed region
     files = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))
