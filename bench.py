@@ -425,9 +425,17 @@ def synthetic_list(td, n_files, seed=1236, rate=8000):
     return lst, names, frames
 
 
+# A process's GPU state is torn down by the kernel AFTER it has exited, and a process that starts meanwhile waits for that
+# inside hipInit: 150-250 ms instead of 50 ms when HIP processes follow each other without a pause, 50 ms from a quarter
+# of a second on (profiles/r06_ab_runs.txt 5, tools/exit_probe.py).  Every timed CLI process of this file therefore starts
+# SETTLE_S after the previous one has exited -- what a caller who runs ONE command sees -- and the pause is in no figure.
+SETTLE_S = 0.3
+
+
 def run_cli(exe, args, env, timeout=600):
     """one CLI run: wall clock of the process and the figures of its PHNREC_STATS line"""
     import subprocess
+    time.sleep(SETTLE_S)
     t0 = time.perf_counter()
     pr = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=timeout)
     wall = time.perf_counter() - t0
@@ -465,8 +473,8 @@ def single_file_leg(mdir, gpu):
         return None
     env = dict(os.environ, PHNREC_STATS="1", PHNREC_DEVICE_MAP=str(gpu))
     out = {"file": "tests/golden/test.raw (7.5 s, 747 frames)",
-           "what": "process wall clock, median / min of 5 runs after one discarded run; break-down from PHNREC_STATS and "
-                   "LCRC_TRACE_STARTUP of the median run"}
+           "what": "process wall clock, median / min of 5 runs after one discarded run, each started %.1f s after the previous "
+                   "process had exited; break-down from PHNREC_STATS and LCRC_TRACE_STARTUP of the median run" % SETTLE_S}
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         for key, extra in (("str", ["-o", os.path.join(td, "x.rec")]), ("post", ["-t", "post", "-o", os.path.join(td, "x.lop")])):
             runs = []
@@ -778,6 +786,7 @@ def four_systems_leg(n_gpus, dmap, n_files=2500, variants=None):
         for key, extra, env_extra in (variants or (("default_flags", [], {}), ("gpu_frontend_decoder_F_D", ["-F", "-D"], {}))):
             best = None
             for _ in range(2):               # the better of two runs (the first warms the page cache)
+                time.sleep(SETTLE_S)
                 t0 = time.perf_counter()
                 pr = subprocess.run(["bash", script] + args + extra, env=dict(env, **env_extra), capture_output=True, text=True, timeout=900)
                 wall = time.perf_counter() - t0

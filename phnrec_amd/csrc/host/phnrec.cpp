@@ -82,6 +82,27 @@ static double MaxRssMb()
     return getrusage(RUSAGE_SELF, &ru) == 0 ? ru.ru_maxrss / 1024.0 : 0.0;
 }
 
+// the resident set as it stands, by kind (/proc/self/status: RssAnon, RssFile, RssShmem), for PHNREC_STATS
+static std::string RssKinds()
+{
+    std::string out;
+    if (FILE *f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            long kb = 0;
+            char key[64];
+            if (sscanf(line, "%63[^:]: %ld kB", key, &kb) == 2 &&
+                (!strcmp(key, "RssAnon") || !strcmp(key, "RssFile") || !strcmp(key, "RssShmem") || !strcmp(key, "VmLck") || !strcmp(key, "VmPin"))) {
+                char b[96];
+                snprintf(b, sizeof b, " %s_mb=%.1f", key, kb / 1024.0);
+                out += b;
+            }
+        }
+        fclose(f);
+    }
+    return out;
+}
+
 static void Die(const std::string &msg)
 {
     fprintf(stderr, "ERROR: %s", msg.c_str());
@@ -226,13 +247,13 @@ int main(int argc, char **argv)
         // (code-object load, cold clock); main_s: since main() was entered
         fprintf(stderr, "phnrec: files=%lld frames=%lld wall_s=%.3f frames_per_s=%.1f xRT=%.6f gpu_kernel_ms=%.3f "
                         "(front_end_s=%.3f setup_s=%.3f first_ctx_s=%.3f create_s=%.3f first_launch_s=%.3f config_s=%.3f main_s=%.3f) "
-                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d contexts=%d mode=%s max_rss_mb=%.1f\n",
+                        "host_cpu_s=%.3f (stage1=%.3f read=%.3f gather=%.3f decode_write=%.3f viterbi=%.3f) host_threads=%d contexts=%d mode=%s max_rss_mb=%.1f%s\n",
                 s.files, s.frames, s.seconds, s.seconds > 0 ? s.frames / s.seconds : 0.0,
                 s.frames > 0 ? s.seconds / (s.frames * 0.01) : 0.0, s.gpu_kernel_ms, s.stage1_seconds, s.init_seconds,
                 s.first_context_seconds, s.create_seconds, s.first_launch_seconds, config_s,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
                 s.cpu_stage1 + s.cpu_read + s.cpu_gather + s.cpu_stage3, s.cpu_stage1, s.cpu_read, s.cpu_gather, s.cpu_stage3, s.cpu_viterbi,
-                s.host_threads, s.contexts, SR.ModeString().c_str(), MaxRssMb());
+                s.host_threads, s.contexts, SR.ModeString().c_str(), MaxRssMb(), RssKinds().c_str());
     }
     // Every output file is closed by now.  Leave without tearing the HIP runtime down piece by piece (contexts, streams,
     // pinned buffers, code objects: tens of milliseconds that a one-file run would notice); the driver reclaims it all.

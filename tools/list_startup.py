@@ -6,7 +6,10 @@ PHNREC_DEVICE_MAP=0 x 8 -- 24 contexts, one device), with the CLI's own break-do
 first_ctx_s / create_s (until the first / the last context could take a launch: beside the list), list (from its first
 line to its last, that start-up included), contexts that came up (of those planned).  Every MLF is compared with the first one byte for byte.
 
-usage: list_startup.py [n_files] [runs]
+Every process starts bench.SETTLE_S (0.3 s) after the previous one has exited (pass 0 as the third argument for runs back to back:
+each then waits in hipInit for the kernel to finish tearing down its predecessor's GPU state, 0.1-0.2 s).
+
+usage: list_startup.py [n_files] [runs] [pause_s]
 """
 import os
 import statistics
@@ -23,11 +26,13 @@ HU = "PHN_HU_SPDAT_LCRC_N1500"
 def main():
     n_files = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    if len(sys.argv) > 3:
+        bench.SETTLE_S = float(sys.argv[3])
     exe = os.path.join(ROOT, "phnrec_amd", "bin", "phnrec")
     mdir = os.path.join(ROOT, "tests", "golden", "models", HU)
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         lst, names, frames = bench.synthetic_list(td, n_files)
-        print("%s, %d files, %d frames; median of %d runs after one discarded run" % (HU, n_files, frames, runs))
+        print("%s, %d files, %d frames; median of %d runs after one discarded run, %.2f s between processes" % (HU, n_files, frames, runs, bench.SETTLE_S))
         print("%-26s %8s %8s %8s %8s %8s %8s %5s  %s" % ("run", "process", "main", "1st ctx", "all ctx", "list", "M fr/s", "ctxs", "mode"))
         ref = None
         for g, dmap in ((1, "0"), (2, "0,0"), (8, ",".join(["0"] * 8))):
