@@ -34,7 +34,8 @@ def passes(src):
             continue
         per = collections.defaultdict(dict)        # dispatch id -> {counter: value}
         t = {}
-        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        # (one process per pass: if an earlier call's files were merged into the same directory, the newest process counts)
+        for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 if "lcrc_fused_kernel" not in r["Kernel_Name"] or int(r["Grid_Size"]) != HEADLINE_GRID:
                     continue

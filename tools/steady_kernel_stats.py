@@ -33,7 +33,7 @@ def main():
         nums = [int(v) for v in re.findall(r"\d+", rec["roofline"]["launches_timed"])]
         assert nums[0] == n, (nums, n)
         first = sum(nums[1:])                       # launches before the timed region
-    files = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))
+    files = sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)      # the newest process
     if not files:
         raise SystemExit("no *kernel_trace.csv under " + trace_dir)
     rows = list(csv.DictReader(open(files[0])))
