@@ -494,7 +494,13 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         // are being staged from its first line on, and the contexts that are up take launches.
         {
             std::string cerr;
-            const int up_rc = BringUpContext(g, plan, cerr, [&](const char *what) { trace(g, what); }, worth_another_context);
+            // (the worker moves next to its GPU as soon as the context exists -- the runtime is up then, asking for the device's
+            //  bus id costs nothing -- and BEFORE the context's staging buffers are reserved: they are this thread's first-touched
+            //  pages, so they land on the GPU's NUMA node)
+            const int up_rc = BringUpContext(g, plan, cerr, [&](const char *what) {
+                trace(g, what);
+                if (!single_file && strcmp(what, "ctx: created") == 0) PinToGpuNode(device);
+            }, worth_another_context);
             if (up_rc < 0) return;                  // left out: the contexts that are up finish the list sooner without it
             if (up_rc == 0) {
                 std::lock_guard<std::mutex> l(mu);

@@ -9,6 +9,11 @@
 // device: lcrc_api_decoder.cpp; what the three share: lcrc_ctx.h.)
 #include "lcrc_ctx.h"
 
+#include <sys/mman.h>
+
+#include <cstdint>
+#include <unordered_map>
+
 namespace lcrc_impl {
 
 thread_local std::string g_create_err = "";
@@ -272,11 +277,58 @@ hipError_t dev_alloc(void **p, size_t bytes)
 // every hipHostGetDevicePointer here).  Without the flag the registration belongs to the device that was current at
 // allocation time only -- invisible on a one-GPU box.
 // device_reads: a buffer that kernels read in place (mapped into the device, coherent: never cached on the device side)
+// Large buffers (the posterior, feature and byte buffers of a list's launches: 5-60 MB each) are the process's own
+// 2 MiB-aligned anonymous memory with MADV_HUGEPAGE, touched, then registered with the runtime (hipHostRegister, mapped
+// and portable): pinning and mapping 2 MiB pages instead of 4 KiB ones takes a third of hipHostMalloc's time -- 3 x 40 MiB:
+// 10.7 against 32 ms; 6 x 40 MiB: 23 against 67 ms -- and the kernel tears such a process down 30-40 ms sooner after exit
+// (tools/ubench/pin_probe, profiles/r06_ab_runs.txt 6).  Where transparent huge pages are off the advice is a no-op and
+// the cost is hipHostMalloc's.  Small buffers, and any failure on the way, take hipHostMalloc.  pinned_free() knows which.
+namespace {
+struct PinnedRegion { void *map_base; size_t map_bytes; };
+std::mutex g_pinned_mu;
+std::unordered_map<void *, PinnedRegion> g_pinned;
+constexpr size_t kHugePage = 2u << 20, kHugeMin = 4u << 20;
+}  // namespace
+
 hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads)
 {
     *p = nullptr;
     if (inject_alloc_failure()) return hipErrorOutOfMemory;
+#ifndef LCRC_PINNED_PLAIN
+    if (bytes >= kHugeMin) {
+        const size_t len = (bytes + kHugePage - 1) & ~(kHugePage - 1), map_bytes = len + kHugePage;
+        void *base = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base != MAP_FAILED) {
+            void *h = (void *)(((uintptr_t)base + kHugePage - 1) & ~(uintptr_t)(kHugePage - 1));
+            (void)madvise(h, len, MADV_HUGEPAGE);
+            for (size_t o = 0; o < len; o += 4096) ((volatile char *)h)[o] = 0;      // (the pages exist before they are pinned)
+            if (hipHostRegister(h, len, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
+                std::lock_guard<std::mutex> l(g_pinned_mu);
+                g_pinned[h] = PinnedRegion{base, map_bytes};
+                *p = h;
+                return hipSuccess;
+            }
+            (void)hipGetLastError();
+            (void)munmap(base, map_bytes);
+        }
+    }
+#endif
     return hipHostMalloc(p, bytes, device_reads ? kPinnedMapped : kPinned);
+}
+
+hipError_t pinned_free(void *p)
+{
+    if (!p) return hipSuccess;
+    PinnedRegion r{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> l(g_pinned_mu);
+        auto it = g_pinned.find(p);
+        if (it != g_pinned.end()) { r = it->second; g_pinned.erase(it); }
+    }
+    if (!r.map_base) return hipHostFree(p);
+    const hipError_t e = hipHostUnregister(p);
+    (void)munmap(r.map_base, r.map_bytes);
+    return e;
 }
 
 void free_frame_staging(lcrc_ctx *c)
@@ -284,8 +336,8 @@ void free_frame_staging(lcrc_ctx *c)
     if (c->dec_stream) (void)hipStreamSynchronize(c->dec_stream);      // (a decoder of the last call may still read d_post)
     if (c->d_mel) (void)hipFree(c->d_mel);
     if (c->d_post) (void)hipFree(c->d_post);
-    if (c->h_mel) (void)hipHostFree(c->h_mel);
-    if (c->h_post) (void)hipHostFree(c->h_post);
+    if (c->h_mel) (void)pinned_free(c->h_mel);
+    if (c->h_post) (void)pinned_free(c->h_post);
     c->d_mel = c->d_post = c->h_mel = c->h_post = nullptr;
     c->cap_rows = c->cap_host_post = c->d_post_cap = 0;
 }
@@ -293,7 +345,7 @@ void free_frame_staging(lcrc_ctx *c)
 void free_offset_staging(lcrc_ctx *c)
 {
     if (c->d_off) (void)hipFree(c->d_off);
-    if (c->h_off) (void)hipHostFree(c->h_off);
+    if (c->h_off) (void)pinned_free(c->h_off);
     c->d_off = c->h_off = nullptr;
     c->cap_utts = 0;
 }
@@ -420,7 +472,7 @@ int ensure_staging(lcrc_ctx *c, size_t rows, size_t utts)
 int ensure_host_post(lcrc_ctx *c)
 {
     if (c->h_post && c->cap_host_post >= c->cap_rows) return LCRC_OK;
-    if (c->h_post) (void)hipHostFree(c->h_post);
+    if (c->h_post) (void)pinned_free(c->h_post);
     c->h_post = nullptr; c->cap_host_post = 0;
     const size_t O = c->nets[2].n_out;
     if (pinned_alloc((void **)&c->h_post, c->cap_rows * O * sizeof(float), true) != hipSuccess) {      // (mapped: direct output)
@@ -1201,8 +1253,8 @@ void lcrc_destroy(lcrc_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     free_frame_staging(c);
     if (c->alt.d_post) (void)hipFree(c->alt.d_post);
-    if (c->alt.h_labels) (void)hipHostFree(c->alt.h_labels);
-    if (c->alt.h_count) (void)hipHostFree(c->alt.h_count);
+    if (c->alt.h_labels) (void)pinned_free(c->alt.h_labels);
+    if (c->alt.h_count) (void)pinned_free(c->alt.h_count);
     if (c->d_dec_off) (void)hipFree(c->d_dec_off);
     if (c->alt.d_dec_off) (void)hipFree(c->alt.d_dec_off);
     if (c->ev_post) (void)hipEventDestroy(c->ev_post);
@@ -1211,8 +1263,8 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->dec_stream) (void)hipStreamDestroy(c->dec_stream);
     free_offset_staging(c);
     for (float *p : c->d_dbg) if (p) (void)hipFree(p);
-    if (c->h_labels) (void)hipHostFree(c->h_labels);
-    if (c->h_count) (void)hipHostFree(c->h_count);
+    if (c->h_labels) (void)pinned_free(c->h_labels);
+    if (c->h_count) (void)pinned_free(c->h_count);
     if (c->d_feat) (void)hipFree(c->d_feat);
     if (c->d_minp) (void)hipFree(c->d_minp);
     if (c->d_hamming) (void)hipFree(c->d_hamming);
@@ -1220,15 +1272,15 @@ void lcrc_destroy(lcrc_ctx *c)
     if (c->d_twiddle) (void)hipFree(c->d_twiddle);
     if (c->d_runs) (void)hipFree(c->d_runs);
     if (c->d_bytes) (void)hipFree(c->d_bytes);
-    if (c->h_bytes) (void)hipHostFree(c->h_bytes);
+    if (c->h_bytes) (void)pinned_free(c->h_bytes);
     if (c->d_soff) (void)hipFree(c->d_soff);
-    if (c->h_soff) (void)hipHostFree(c->h_soff);
+    if (c->h_soff) (void)pinned_free(c->h_soff);
     if (c->d_foff) (void)hipFree(c->d_foff);
-    if (c->h_foff) (void)hipHostFree(c->h_foff);
+    if (c->h_foff) (void)pinned_free(c->h_foff);
     if (c->d_means) (void)hipFree(c->d_means);
     if (c->d_mean_part) (void)hipFree(c->d_mean_part);
-    if (c->h_ring) (void)hipHostFree(c->h_ring);
-    if (c->h_pushout) (void)hipHostFree(c->h_pushout);
+    if (c->h_ring) (void)pinned_free(c->h_ring);
+    if (c->h_pushout) (void)pinned_free(c->h_pushout);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -1415,11 +1467,11 @@ static int ensure_ring(lcrc_ctx *c, size_t n)
             const size_t cap = std::max<size_t>(4096, 2 * (H + n) + 256);
             float *h = nullptr, *d = nullptr;
             HIP_TRY(c, hipHostMalloc((void **)&h, cap * nb * sizeof(float), kPinnedMapped));
-            if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed"); }
+            if (hipHostGetDevicePointer((void **)&d, h, 0) != hipSuccess) { (void)pinned_free(h); return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed"); }
             if (c->h_ring) {
                 const size_t keep = std::min(c->ring_rows, H);
                 memcpy(h, c->h_ring + (c->ring_rows - keep) * nb, keep * nb * sizeof(float));
-                (void)hipHostFree(c->h_ring);
+                (void)pinned_free(c->h_ring);
                 c->ring_rows = keep;
             }
             c->h_ring = h; c->d_ring = d; c->ring_cap = cap;
@@ -1431,7 +1483,7 @@ static int ensure_ring(lcrc_ctx *c, size_t n)
     }
     if (n > c->pushout_cap) {
         const size_t cap = n + n / 4 + 64;
-        if (c->h_pushout) (void)hipHostFree(c->h_pushout);
+        if (c->h_pushout) (void)pinned_free(c->h_pushout);
         c->h_pushout = c->d_pushout = nullptr; c->pushout_cap = 0;
         HIP_TRY(c, hipHostMalloc((void **)&c->h_pushout, cap * O * sizeof(float), kPinnedMapped));
         if (hipHostGetDevicePointer((void **)&c->d_pushout, c->h_pushout, 0) != hipSuccess) return fail(c, LCRC_E_DEVICE, "hipHostGetDevicePointer failed");

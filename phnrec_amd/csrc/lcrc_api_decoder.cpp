@@ -14,7 +14,7 @@ int ensure_labels(lcrc_ctx *c, size_t n_rows, size_t n_utts)
 {
     if (n_rows > c->cap_label_rows) {
         const size_t cap = n_rows + n_rows / 4 + 64;
-        if (c->h_labels) (void)hipHostFree(c->h_labels);
+        if (c->h_labels) (void)pinned_free(c->h_labels);
         c->d_labels = c->h_labels = nullptr;
         c->cap_label_rows = 0;
         HIP_TRY(c, pinned_alloc((void **)&c->h_labels, cap * sizeof(lcrc_label), true));
@@ -23,7 +23,7 @@ int ensure_labels(lcrc_ctx *c, size_t n_rows, size_t n_utts)
     }
     if (n_utts > c->cap_label_utts) {
         const size_t cap = n_utts + n_utts / 4 + 64;
-        if (c->h_count) (void)hipHostFree(c->h_count);
+        if (c->h_count) (void)pinned_free(c->h_count);
         c->d_count = c->h_count = nullptr;
         c->cap_label_utts = 0;
         HIP_TRY(c, pinned_alloc((void **)&c->h_count, cap * sizeof(int), true));

@@ -115,11 +115,11 @@ struct SlowTrace {
 static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
 {
     if ((size_t)total_bytes + 16 > c->cap_bytes) {
-        if (c->d_bytes) { (void)hipFree(c->d_bytes); (void)hipHostFree(c->h_bytes); }
+        if (c->d_bytes) { (void)hipFree(c->d_bytes); (void)pinned_free(c->h_bytes); }
         c->d_bytes = c->h_bytes = nullptr; c->cap_bytes = 0;
         const size_t cap = (size_t)total_bytes + total_bytes / 4 + 4096;
         HIP_TRY(c, hipMalloc((void **)&c->d_bytes, cap));
-        HIP_TRY(c, hipHostMalloc((void **)&c->h_bytes, cap, kPinnedMapped));      // (mapped: lcrc_wave_stage_energies pulls it by a kernel)
+        HIP_TRY(c, pinned_alloc((void **)&c->h_bytes, cap, true));      // (mapped: lcrc_wave_stage_energies pulls it by a kernel)
         c->cap_bytes = cap;
     }
     return LCRC_OK;
@@ -129,7 +129,7 @@ static int ensure_wave_bytes(lcrc_ctx *c, long long total_bytes)
 static int ensure_fe_utts(lcrc_ctx *c, size_t n_utts)
 {
     if (2 * n_utts + 2 <= c->cap_fe_utts) return LCRC_OK;
-    if (c->d_soff) { (void)hipFree(c->d_soff); (void)hipHostFree(c->h_soff); (void)hipFree(c->d_foff); (void)hipHostFree(c->h_foff); (void)hipFree(c->d_means); }
+    if (c->d_soff) { (void)hipFree(c->d_soff); (void)pinned_free(c->h_soff); (void)hipFree(c->d_foff); (void)pinned_free(c->h_foff); (void)hipFree(c->d_means); }
     c->d_soff = c->h_soff = nullptr; c->d_foff = c->h_foff = nullptr; c->d_means = nullptr; c->cap_fe_utts = 0;
     const size_t cap = 2 * n_utts + n_utts / 2 + 64;
     HIP_TRY(c, hipMalloc((void **)&c->d_soff, cap * sizeof(long long)));

@@ -196,6 +196,7 @@ constexpr int kCopyPieces = 4;           // <= lcrc_ctx::ev_piece
 // ---- lcrc_api.cpp ----
 hipError_t dev_alloc(void **p, size_t bytes);
 hipError_t pinned_alloc(void **p, size_t bytes, bool device_reads = false);
+hipError_t pinned_free(void *p);         // for anything pinned_alloc or hipHostMalloc handed out
 hipError_t wait_stream(lcrc_ctx *c);
 hipError_t wait_event(lcrc_ctx *c, hipEvent_t ev);
 hipError_t copy_back(lcrc_ctx *c, float *dst, float *pinned, const float *dev, size_t nbytes);

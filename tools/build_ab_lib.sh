@@ -8,7 +8,7 @@ TMP="$(mktemp -d /tmp/ablib.XXXXXX)"
 if [ "$REF" = "WORKTREE" ]; then
     mkdir -p "$TMP/phnrec_amd" "$TMP/include"
     cp -r "$ROOT/phnrec_amd/csrc" "$TMP/phnrec_amd/csrc"
-    cp "$ROOT/include/lcrc.h" "$TMP/include/"
+    cp "$ROOT"/include/*.h "$TMP/include/"
 else
     git -C "$ROOT" archive "$REF" phnrec_amd/csrc include | tar -x -C "$TMP"
 fi
