@@ -221,7 +221,8 @@ def test_verbose_names_the_device_path(tmp_path):
     line, p = _device_path_line("-c", model_dir(CZ), "-i", raw, "-o", tmp_path / "a.rec")
     assert "front-end host (one file)" in line and "decoder host" in line and "1 GPU(s) x 1 context(s)" in line
     assert "share the device" in line and "32768 frames per launch" in line
-    assert p.returncode != 0 and "no HIP device" in p.stderr
+    if p.returncode != 0:                    # (here: no GPU.  On a GPU box the run simply succeeds)
+        assert "no HIP device" in p.stderr
     line, _ = _device_path_line("-c", model_dir(CZ), "-l", short, "-m", mlf)
     assert "front-end host (a short list on one GPU)" in line and "1 GPU(s) x 3 context(s)" in line
     line, _ = _device_path_line("-c", model_dir(CZ), "-l", long_, "-m", mlf)
