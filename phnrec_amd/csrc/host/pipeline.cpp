@@ -471,9 +471,15 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     const bool all_contexts = getenv("PHNREC_ALL_CONTEXTS") != nullptr;
     // (the first context of every physical device is always created)
     const int n_first_contexts = (int)std::set<int>(gpu_devices_.begin(), gpu_devices_.end()).size();
-    auto worth_another_context = [&]() -> bool {
+    // ... and a PHYSICAL device gets three at most, however many logical GPUs are mapped onto it (PHNREC_DEVICE_MAP=0,0,...):
+    // a fourth context on a device adds nothing (profiles/r05_ab_runs.txt 3: 2 / 3 / 4 contexts), it only comes up beside
+    // the others' launches
+    std::map<int, int> on_device;
+    for (int d : gpu_devices_) on_device[d] = 1;
+    auto worth_another_context = [&](int device) -> bool {
         std::lock_guard<std::mutex> l(mu);
         if (!fatal.empty()) return false;
+        if (!all_contexts && on_device[device] >= 3) return false;
         long long left = -1;                             // frames no launch has taken yet; -1: unknown
         if (eof) {
             left = 0;
@@ -484,7 +490,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             }
         }
         const bool yes = all_contexts || left < 0 || left > 1500000LL * (n_first_contexts + contexts_committed.load());
-        if (yes) contexts_committed++;
+        if (yes) { contexts_committed++; on_device[device]++; }
         return yes;
     };
     auto worker = [&](int g) {
@@ -500,7 +506,7 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
             const int up_rc = BringUpContext(g, plan, cerr, [&](const char *what) {
                 trace(g, what);
                 if (!single_file && strcmp(what, "ctx: created") == 0) PinToGpuNode(device);
-            }, worth_another_context);
+            }, [&, device] { return worth_another_context(device); });
             if (up_rc < 0) return;                  // left out: the contexts that are up finish the list sooner without it
             if (up_rc == 0) {
                 std::lock_guard<std::mutex> l(mu);

@@ -630,6 +630,18 @@ def test_configs3_list_at_scale(tmp_path):
     assert "files=10000 frames=%d" % frames in p1.stderr and "files=10000 frames=%d" % frames in p2.stderr
     a, b = mlf1.read_bytes(), mlf2.read_bytes()
     assert a == b, "-g 2 must write the bytes -g 1 writes"
+    # `-g 8` as eight logical GPUs on this one device, what it picks by itself (-F -D): contexts come up beside the running
+    # list, and only those the list lives to see and the device can use -- three per PHYSICAL device at most; with
+    # PHNREC_ALL_CONTEXTS=1 every planned one (16 here: one process, 16 worker threads, one launch queue).  Same bytes.
+    e8 = {"PHNREC_STATS": "1", "PHNREC_DEVICE_MAP": ",".join(["0"] * 8)}
+    for extra, lo, hi in (({}, 1, 3), ({"PHNREC_ALL_CONTEXTS": "1"}, 16, 24)):
+        mlf8 = tmp_path / "g8.mlf"
+        p8 = run("-c", model_dir(HU), "-l", lst, "-m", mlf8, "-g", 8, env=dict(e8, AUTO="1", **extra))
+        st = [l for l in p8.stderr.splitlines() if l.startswith("phnrec: files=")][-1]
+        assert "mode=F+D,auto" in st and "files=10000 frames=%d" % frames in st
+        n_ctx = int(st.split("contexts=")[1].split()[0])
+        assert lo <= n_ctx <= hi, st
+        assert mlf8.read_bytes() == a, "-g 8 %s must write the bytes -g 1 writes" % extra
     lines = a.decode().splitlines()
     heads = [l for l in lines if l.startswith('"')]
     assert lines[0] == "#!MLF!#" and len(heads) == 10000 and lines.count(".") == 10000
