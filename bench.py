@@ -605,18 +605,22 @@ def sharded_list_leg(n_gpus, dmap, n_files):
         if n_gpus == 1:
             # What `phnrec -g 8 -l ... -m ...`, called as the reference is called (no flags), selects by itself -- the GPU
             # front-end and, from four GPUs on, -D; sleeping waits -- with all eight logical GPUs mapped onto this
-            # box's one device: the per-GPU rate is that of ONE GPU behind sixteen contexts, the host CPU seconds are
-            # those the auto-selected path costs per frame.
-            try:
-                e8 = dict(env, PHNREC_DEVICE_MAP=",".join([str(dmap[0])] * 8))
-                r = weak_run([], 8, e8)
-                if "ceiling_over_8_gpus" in r:       # (eight logical GPUs, ONE device: value is one GPU's rate)
-                    r["ceiling_over_8_gpus"] = round(r["host_ceiling_frames_per_s"] / (8.0 * r["value"]), 3)
-                r["what"] = ("PHNREC_DEVICE_MAP=%s phnrec -g 8 without -F / -E / -D: the mode the CLI picks by itself ('mode'), "
-                             "eight logical GPUs on one device" % e8["PHNREC_DEVICE_MAP"])
-                weak["as_g8_default"] = r
-            except Exception as e:
-                weak["as_g8_default"] = {"error": repr(e)}
+            # box's one device: the per-GPU rate is that of ONE GPU, the host CPU seconds are those the auto-selected path
+            # costs per frame.  as_g8_default: as the CLI runs it (a physical device gets three contexts at most, however
+            # many logical GPUs are mapped onto it); as_g8_all_contexts: PHNREC_ALL_CONTEXTS=1, every planned context -- 24:
+            # one process, 24 worker threads, one launch queue -- the rehearsal of the eight-GPU arrangement's host side that
+            # rounds 4 and 5 recorded under the first name.
+            for key8, extra_env in (("as_g8_default", {}), ("as_g8_all_contexts", {"PHNREC_ALL_CONTEXTS": "1"})):
+                try:
+                    e8 = dict(env, PHNREC_DEVICE_MAP=",".join([str(dmap[0])] * 8), **extra_env)
+                    r = weak_run([], 8, e8)
+                    if "ceiling_over_8_gpus" in r:       # (eight logical GPUs, ONE device: value is one GPU's rate)
+                        r["ceiling_over_8_gpus"] = round(r["host_ceiling_frames_per_s"] / (8.0 * r["value"]), 3)
+                    r["what"] = ("PHNREC_DEVICE_MAP=%s %sphnrec -g 8 without -F / -E / -D: the mode the CLI picks by itself ('mode'), "
+                                 "eight logical GPUs on one device" % (e8["PHNREC_DEVICE_MAP"], "PHNREC_ALL_CONTEXTS=1 " if extra_env else ""))
+                    weak[key8] = r
+                except Exception as e:
+                    weak[key8] = {"error": repr(e)}
         try:
             weak["F_D_over_F"] = round(weak["gpu_frontend_decoder_F_D"]["value"] / weak["gpu_frontend_F"]["value"], 4)
         except Exception:

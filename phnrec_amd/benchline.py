@@ -18,9 +18,9 @@ _DROP_ORDER = ("push_bunch512", "host_path", "wave_path_en", "dropin_reference_c
                "host_path_zero_copy", "wave_path", "split_f16", "single_file", "systems", "four_systems", "sharded_list")
 
 _MODES = ("host_frontend", "gpu_energies_E", "gpu_energies_decoder_E_D", "gpu_frontend_F", "gpu_frontend_decoder_F_D",
-          "as_g8_default")
+          "as_g8_default", "as_g8_all_contexts")
 _MODE_SHORT = {"host_frontend": "host", "gpu_energies_E": "E", "gpu_energies_decoder_E_D": "E_D", "gpu_frontend_F": "F",
-               "gpu_frontend_decoder_F_D": "F_D", "as_g8_default": "g8_default"}
+               "gpu_frontend_decoder_F_D": "F_D", "as_g8_default": "g8_default", "as_g8_all_contexts": "g8_all_ctx"}
 
 
 def _pick(d, keys):
@@ -66,8 +66,8 @@ def _sharded(sl):
         for k in _MODES:
             if k in wl:
                 w[_MODE_SHORT[k]] = _pick(wl[k], ("value", "ceiling_over_8_gpus"))
-                if k == "as_g8_default":
-                    w[_MODE_SHORT[k]].update(_pick(wl[k], ("process_frames_per_s", "setup_s", "mode")))
+                if k.startswith("as_g8"):
+                    w[_MODE_SHORT[k]].update(_pick(wl[k], ("process_frames_per_s", "contexts", "mode")))
         out["weak_list"] = w
     cz = sl.get("cz_same_list")
     if isinstance(cz, dict):

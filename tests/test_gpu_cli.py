@@ -737,6 +737,7 @@ def test_bench_line_carries_every_leg(tmp_path):
     assert wl["files"] == 8 * 120 and all(wl[k]["value"] > 50000 and wl[k]["ceiling_over_8_gpus"] > 0 for k in (
         "host_frontend", "gpu_energies_E", "gpu_energies_decoder_E_D", "gpu_frontend_F", "gpu_frontend_decoder_F_D"))
     assert wl["as_g8_default"]["mode"] == "F+D,auto" and wl["as_g8_default"]["value"] > 50000
+    assert wl["as_g8_default"]["contexts"] <= 3 < wl["as_g8_all_contexts"]["contexts"] and wl["as_g8_all_contexts"]["value"] > 50000
     # configs[4]: the four systems at once (here: all on this box's one GPU), MLFs those of each system run alone
     fs = d["four_systems"]
     assert fs["oversubscribed"] is True and set(fs["default_flags"]["per_system"]) == set(fs["systems"])
