@@ -675,7 +675,9 @@ struct GateHold {
     hipStream_t s;
     GateHold(lcrc_ctx *c, hipStream_t stream) : s(stream)
     {
-        if (!c->launch_ordered || c->device < 0 || c->device >= 64) return;
+        // (only launches on the context's OWN stream: an asynchronous lcrc_posteriors_device launch on a caller's stream stays
+        //  out -- the gate would otherwise keep an event of a stream whose life it knows nothing about)
+        if (!c->launch_ordered || c->device < 0 || c->device >= 64 || stream != c->stream) return;
         g = &g_gates[c->device];
         g->mu.lock();
     }
