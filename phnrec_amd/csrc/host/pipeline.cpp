@@ -482,6 +482,10 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
         if (!all_contexts && on_device[device] >= 3) return false;
         long long left = -1;                             // frames no launch has taken yet; -1: unknown
         if (eof) {
+            // (a launch holds at least one job: fewer jobs left than contexts already there -- the one file of a one-line list,
+            //  whatever its length -- and a further context could never get one)
+            const long long jobs_left = (long long)win.size() - (next_launch - base);
+            if (!all_contexts && jobs_left <= (long long)(n_first_contexts + contexts_committed.load())) return false;
             left = 0;
             for (long long q = next_launch; q - base < (long long)win.size(); q++) {
                 const Item *it = win[(size_t)(q - base)].get();
