@@ -338,11 +338,15 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     std::vector<std::string> trace_rows;
     auto trace = [&](int ctx, const char *what, long long a = 0, long long b = 0) {
         if (!trace_on) return;
-        char line[200];
-        snprintf(line, sizeof line, "%9.3f ms  (%lld us, thread %ld)  ctx %d  %-18s %lld %lld\n",
+        char line[240];
+        long rss_pages = 0;                              // the process's resident set as the step ends (/proc/self/statm)
+        if (strncmp(what, "ctx:", 4) == 0 || strncmp(what, "worker", 6) == 0)
+            if (FILE *f = fopen("/proc/self/statm", "r")) { long sz = 0; if (fscanf(f, "%ld %ld", &sz, &rss_pages) != 2) rss_pages = 0; fclose(f); }
+        snprintf(line, sizeof line, "%9.3f ms  (%lld us, thread %ld)  ctx %d  %-18s %lld %lld%s\n",
                  std::chrono::duration<double, std::milli>(clock::now() - t1).count(),
                  (long long)std::chrono::duration<double, std::micro>(clock::now().time_since_epoch()).count() % 100000000LL,
-                 (long)(size_t)pthread_self() % 1000, ctx, what, a, b);
+                 (long)(size_t)pthread_self() % 1000, ctx, what, a, b,
+                 rss_pages ? ("  rss " + std::to_string(rss_pages * 4 / 1024) + " MB").c_str() : "");
         std::lock_guard<std::mutex> l(trace_mu);
         trace_rows.emplace_back(line);
     };
