@@ -42,10 +42,14 @@ int lcrc_frontend_configure(lcrc_ctx *c, const lcrc_frontend *cfg)
     HIP_TRY(c, hipMalloc((void **)&c->d_coeffs, mf.coeffs.size() * sizeof(float)));
     HIP_TRY(c, hipMalloc((void **)&c->d_twiddle, tw.size() * sizeof(double)));
     HIP_TRY(c, hipMalloc((void **)&c->d_runs, runs.size() * sizeof(int)));
-    HIP_TRY(c, hipMemcpy(c->d_hamming, ham.data(), ham.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_coeffs, mf.coeffs.data(), mf.coeffs.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_twiddle, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_runs, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
+    // On the context's OWN stream, then one wait: a plain hipMemcpy runs on the device's null stream, whose queue the runtime
+    // creates with its first use -- 8 ms and ~190 MB of resident memory (a queue's wave save area on this 256-CU device) that a
+    // process which never touches the null stream never pays (PHNREC_TRACE_PIPELINE: "ctx: front-end set" 8.3 -> 0.3 ms).
+    HIP_TRY(c, hipMemcpyAsync(c->d_hamming, ham.data(), ham.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_coeffs, mf.coeffs.data(), mf.coeffs.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_twiddle, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_runs, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));       // (the sources are this function's locals)
     c->fe = *cfg;
     c->fe.nbanks_full = nbf;
     c->fe_fft = fft;
