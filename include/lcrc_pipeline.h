@@ -20,11 +20,17 @@ extern "C" {
  * a first lcrc_create) and returns when they are up.  Thread-safe; meant to be called from a helper thread at program
  * start so that the caller's own initialisation -- configuration, the model files and their re-packing inside
  * lcrc_create, the first file's front-end -- overlaps with it (the CLI does, one thread per device it will use).  It also
- * brings the library's code objects -- posterior kernels, then front-end and decoder -- onto the device (15-40 ms each that a
- * context's creation or the first launch of each kind pays otherwise; beside the caller's
+ * brings the posterior kernels' code object onto the device (20-40 ms that a
+ * context's creation or first launch pays otherwise; beside the caller's
  * lcrc_create -- stream, weight upload -- it costs nothing: a one-file `phnrec` run 0.15-0.24 s instead of 0.21-0.29 on
  * the same boxes).  No reference counterpart: the reference has no device to bring up. */
 int lcrc_device_warmup(int device_id);
+/* The same for the other code objects of the library: the GPU front-end's and the device decoder's kernels (15-20 ms each that
+ * the first waveform / decoder launch of the process pays otherwise: a list's first launch 0.02-0.05 -> 0.003 s).  For the
+ * helper thread that ran lcrc_device_warmup, when the run will use them -- a one-file run that does not is 10 ms sooner done
+ * without (the loads compete with its one context's creation). */
+enum { LCRC_PRELOAD_FRONTEND = 1, LCRC_PRELOAD_DECODER = 2 };
+int lcrc_device_preload(int device_id, int what);
 /* PCI address of GPU `device_id` ("0000:c1:00.0") into buf: lets a host that drives several GPUs place the threads of
  * each near it (the CLI pins a GPU's worker threads to the CPUs of /sys/bus/pci/devices/<id>/numa_node).  No reference
  * counterpart. */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libphnrec_lcrc.so")
 
 # every symbol include/lcrc.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "lcrc_create", "lcrc_clone", "lcrc_device_warmup", "lcrc_device_pci_bus_id", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
+    "lcrc_create", "lcrc_clone", "lcrc_device_warmup", "lcrc_device_preload", "lcrc_device_pci_bus_id", "lcrc_create_system", "lcrc_model_outputs", "lcrc_destroy", "lcrc_last_error", "lcrc_abi_version", "lcrc_model_info",
     "lcrc_num_outputs", "lcrc_num_banks", "lcrc_trap_shift", "lcrc_device", "lcrc_net_dims",
     "lcrc_posteriors", "lcrc_posteriors_batch", "lcrc_posteriors_device", "lcrc_posteriors_probe", "lcrc_posteriors_rows",
     "lcrc_stage_buffers", "lcrc_stage_run",
@@ -108,6 +108,7 @@ def load():
     L.lcrc_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lcrc_clone.argtypes = [C.POINTER(vp), vp]
     L.lcrc_device_warmup.argtypes = [C.c_int]
+    L.lcrc_device_preload.argtypes = [C.c_int, C.c_int]
     L.lcrc_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.lcrc_model_outputs.argtypes = [C.c_char_p, C.c_char_p]
     L.lcrc_create_system.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

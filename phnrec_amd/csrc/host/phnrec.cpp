@@ -209,7 +209,11 @@ int main(int argc, char **argv)
     // a conversion through the posterior estimator will need the GPU: bring the HIP runtime up NOW, on a helper thread,
     // while the configuration, the model files and the weights' re-packing are dealt with on this one
     SR.SetGpus(gpus);
-    if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors) SR.WarmUpGpuAsync();
+    // (a list takes the GPU front-end by itself, over four or more GPUs the device decoder too; one file keeps the host's unless
+    //  the flags say otherwise: the warm-up threads load those kernels' code objects only for runs that will launch them)
+    if ((input_file || file_list) && (int)iformat <= (int)dfParams && (int)oformat >= (int)dfPosteriors)
+        SR.WarmUpGpuAsync(iformat == dfWaveform && (gpu_fe || gpu_en || file_list != nullptr),
+                          oformat == dfStrings && (gpu_dec || (file_list != nullptr && gpus >= 4)));
     if (batch > 0) SR.SetBatchFrames(batch);
     if (threads > 0) SR.SetHostThreads(threads);
     if (gpu_fe && gpu_en) Die("-F and -E are two forms of the GPU front-end: give one\n");

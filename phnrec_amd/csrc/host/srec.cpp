@@ -375,7 +375,7 @@ bool SpeechRec::DeviceMap(std::vector<int> &devices)
     return true;
 }
 
-void SpeechRec::WarmUpGpuAsync()
+void SpeechRec::WarmUpGpuAsync(bool frontend, bool decoder)
 {
     if (!warmup_.empty()) return;
     std::vector<int> devices;
@@ -384,7 +384,12 @@ void SpeechRec::WarmUpGpuAsync()
     devices.erase(std::unique(devices.begin(), devices.end()), devices.end());
     // one thread per distinct device: seven more HIP start-ups of 80-100 ms each would otherwise begin only when the
     // list's workers create their contexts (failures surface in lcrc_create)
-    for (int dev : devices) warmup_.emplace_back([dev] { (void)lcrc_device_warmup(dev); });
+    const int what = (frontend ? LCRC_PRELOAD_FRONTEND : 0) | (decoder ? LCRC_PRELOAD_DECODER : 0);
+    for (int dev : devices)
+        warmup_.emplace_back([dev, what] {
+            (void)lcrc_device_warmup(dev);
+            if (what) (void)lcrc_device_preload(dev, what);
+        });
 }
 
 SpeechRec::~SpeechRec()

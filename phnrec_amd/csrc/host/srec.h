@@ -111,7 +111,9 @@ public:
     // Starts the HIP runtime and the primary context of EVERY distinct device the run will use (SetGpus first: -g N,
     // PHNREC_DEVICE_MAP) on helper threads, one per device (lcrc_device_warmup): ~0.1-0.2 s each that then overlap with
     // Init(), the model files, their re-packing and each other.  Call it as early as the conversion is known to need the GPU.
-    void WarmUpGpuAsync();
+    // frontend / decoder: the run will (or may) use the GPU front-end / the device decoder -- a list, or the flags given --:
+    // their code objects are brought onto the devices too (lcrc_device_preload)
+    void WarmUpGpuAsync(bool frontend = false, bool decoder = false);
     void JoinWarmUp() { for (auto &t : warmup_) if (t.joinable()) t.join(); }
     ~SpeechRec();
     // srec.cpp:1201-1244: "src[ \t]+tgt" or "src" (target derived)

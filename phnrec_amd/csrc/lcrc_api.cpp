@@ -1111,11 +1111,21 @@ int lcrc_device_warmup(int device_id)
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
     HIP_TRY(nullptr, hipSetDevice(device_id));
     HIP_TRY(nullptr, hipFree(nullptr));                 // brings the device's primary context up
-    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights); then the
-    // front-end's and the decoder's (15-20 ms each that the first waveform / decoder launch of the process paid otherwise)
+    // the posterior kernels' code object, while the caller's own thread creates its context (stream, weights)
     (void)lcrc_preload_code();
-    (void)frontend_preload_code();
-    (void)phndec_preload_code();
+    return LCRC_OK;
+}
+
+int lcrc_device_preload(int device_id, int what)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LCRC_E_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, LCRC_E_DEVICE, "device_id out of range");
+    HIP_TRY(nullptr, hipSetDevice(device_id));
+    if (what & LCRC_PRELOAD_FRONTEND) (void)frontend_preload_code();
+    if (what & LCRC_PRELOAD_DECODER) (void)phndec_preload_code();
+    (void)hipGetLastError();
     return LCRC_OK;
 }
 
