@@ -823,7 +823,10 @@ def four_systems_leg(n_gpus, dmap, n_files=2500, variants=None):
             for d, l, x in zip(dirs, lists, systems):
                 solo = os.path.join(td, x + ".solo.mlf")
                 e1 = dict(os.environ, PHNREC_DEVICE_MAP=str(dmap[0]))
-                subprocess.run([exe, "-c", d, "-l", l, "-m", solo, "-F", "-D"], env=e1, check=True, capture_output=True, timeout=600)
+                time.sleep(SETTLE_S)
+                sp = subprocess.run([exe, "-c", d, "-l", l, "-m", solo, "-F", "-D"], env=e1, capture_output=True, text=True, timeout=600)
+                if sp.returncode != 0:
+                    raise RuntimeError("single-system run of %s: rc=%d %s" % (x, sp.returncode, sp.stderr.strip()[-300:]))
                 same[x] = open(solo).read() == open(l[:-4] + ".mlf").read()
             out["mlf_equals_single_system_run"] = same
         except Exception as e:

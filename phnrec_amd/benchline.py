@@ -92,6 +92,8 @@ def _four(fs):
     eq = fs.get("mlf_equals_single_system_run")
     if isinstance(eq, dict):
         out["mlf_equal"] = all(eq.values())
+    if "mlf_check_error" in fs:
+        out["mlf_check_error"] = str(fs["mlf_check_error"])[:160]
     return out
 
 

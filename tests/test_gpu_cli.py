@@ -690,7 +690,8 @@ def test_bench_line_carries_every_leg(tmp_path):
     for leg in ("sharded_list", "four_systems", "systems", "small_launches", "single_file", "split_f16", "push_bunch5"):
         assert leg in c, leg
     assert c["sharded_list"]["F"]["value"] > 50000 and c["sharded_list"]["F"]["process_frames_per_s"] > 0
-    assert c["sharded_list"]["mlf_all_modes_equal"] is True and c["four_systems"]["mlf_equal"] is True
+    assert c["sharded_list"]["mlf_all_modes_equal"] is True, c["sharded_list"]
+    assert c["four_systems"].get("mlf_equal") is True, (c["four_systems"], p.stderr[-1500:])
     assert "bench detail [roofline]" in p.stderr and "bench detail [sharded_list]" in p.stderr
     d = json.loads(detail.read_text())                    # the full record
     assert d["value"] == c["value"] and d["ms_per_step"] == c["ms_per_step"] and d["roofline"]["frac"] == c["roofline"]["frac"]
