@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised run of the CLI's list pipeline (GPU): random lists -- files of 0 bytes, less than a frame, exactly a frame, up to
 20 s, optionally one unreadable name --, random batch sizes (-b), logical GPU counts (-g N on the one device), host threads
-(-j), modes (host front-end, -E, -E -D, -F, -F -D), contexts per GPU, launch order and decoder overlap on / off, over the four
+(-j), modes (host front-end, -E, -E -D, -F, -F -D), contexts per GPU (created beside the list: those the list lives to see, or
+all of them), launch order and decoder overlap on / off, over the four
 shipped systems (8 kHz lin16 and A-law, 16 kHz lin16): every
 configuration must write the MLF the plain host-front-end run writes, byte for byte (every mode's features and labels are
 the host's), or fail the same way, and none may hang (each run has a time limit).     usage: fuzz_cli.py [seed [lists]]"""
@@ -66,7 +67,7 @@ def fuzz(seed=0, n_lists=12, log=print):
                         os.remove(out)
                     env = {"PHNREC_DEVICE_MAP": ",".join(["0"] * g)}
                     for name, choices in (("PHNREC_CTX_PER_GPU", ["", "1", "2", "3", "4"]), ("PHNREC_LAUNCH_ORDER", ["", "0", "1"]),
-                                          ("PHNREC_DECODER_OVERLAP", ["", "0", "1"])):
+                                          ("PHNREC_DECODER_OVERLAP", ["", "0", "1"]), ("PHNREC_ALL_CONTEXTS", ["", "", "1"])):
                         v = str(rng.choice(choices))
                         if v:
                             env[name] = v
