@@ -906,6 +906,35 @@ def emit(full, detail_out):
     _RECORD_OUT.flush()
 
 
+def cli_process_legs(args, dmap, mdir):
+    """The legs that time whole CLI PROCESSES (single file, the reference's CLI over the library, configs[3]'s list by mode,
+    configs[4]).  A plain one-GPU run calls this BEFORE its own process touches the GPU: a process that starts while another
+    one holds the device takes 20-50 ms longer over hipInit and its first stream (profiles/r06_ab_runs.txt 5), and what these
+    legs report is what ONE command costs on a GPU nobody else holds."""
+    out = {}
+    if not args.no_extras:
+        for key, leg in (("single_file", lambda: single_file_leg(mdir, dmap[0])),
+                         ("dropin_reference_cli", lambda: reference_cli_leg(mdir, dmap[0]))):
+            try:
+                val = leg()
+            except Exception as e:      # side legs are reported when they can be measured, never fatal
+                val = {"error": repr(e)}
+            if val is not None:
+                out[key] = val
+    if args.list_files > 0:
+        # the thing north_star asks to scale: the sharded file list through the CLI, -g N over the ranks' GPUs
+        try:
+            out["sharded_list"] = sharded_list_leg(len(dmap), dmap, args.list_files)
+        except Exception as e:
+            out["sharded_list"] = {"error": repr(e)}
+        # BASELINE configs[4]: the four systems at once on the ranks' GPUs (one GPU: all on it, labelled)
+        try:
+            out["four_systems"] = four_systems_leg(len(dmap), dmap, max(4, args.list_files // 4))
+        except Exception as e:
+            out["four_systems"] = {"error": repr(e)}
+    return out
+
+
 def stub_main(args, ranks):
     """Launcher self-test: everything of the N-rank harness except the GPU (see --stub)."""
     from phnrec_amd import distrun
@@ -988,6 +1017,11 @@ def main():
     oversubscribed = len(set(dmap)) < len(dmap)
     if args.stub:
         return stub_main(args, ranks)
+    # A plain one-GPU run (the driver's N = 1 form): the CLI's processes are timed first, before this process holds the GPU
+    # (the shipped weights must be there; with synthetic ones, and in N-rank runs, they are timed behind the headline as before)
+    pre, real_mdir = {}, os.path.join(ROOT, "tests", "golden", "models", SYSTEM)
+    if ranks.world == 1 and not ranks.launched and not args.kernel_only and os.path.isdir(real_mdir):
+        pre = cli_process_legs(args, dmap, real_mdir)
     import torch
     from phnrec_amd import capi, modelgen
 
@@ -1152,8 +1186,10 @@ def main():
                                      what="configs[1] input per SURVEY 8(d) cfg2 (EN, 16 kHz lin16, 5 sines + noise, seed 1234, "
                                           "4096 frames, posterior-only): lcrc_wave_to_posteriors(), host bytes in, host posteriors out "
                                           "(reused buffers), synchronous") if os.path.isdir(en_dir) else None),
-                                 ("single_file", lambda: single_file_leg(mdir, gpu)),
-                                 ("dropin_reference_cli", lambda: reference_cli_leg(mdir, gpu))):
+                                 ("single_file", lambda: pre["single_file"] if "single_file" in pre else
+                                  None if pre else single_file_leg(mdir, gpu)),
+                                 ("dropin_reference_cli", lambda: pre["dropin_reference_cli"] if "dropin_reference_cli" in pre else
+                                  None if pre else reference_cli_leg(mdir, gpu))):
                     try:
                         val = leg()
                     except Exception as e:      # side legs are reported when they can be measured, never fatal
@@ -1172,18 +1208,14 @@ def main():
                                                    "peak) of %d-frame launches of the other shipped systems, each behind its own "
                                                    "time-based pre-heat, median of %d windows with min / max; CZ at this size is "
                                                    "`roofline`" % (BATCH, WINDOWS))
-            if args.list_files > 0:
-                # the thing north_star asks to scale: the sharded file list through the CLI, -g N over the ranks' GPUs
-                # (the other ranks idle at the barrier below; their contexts hold no work)
-                try:
-                    line["sharded_list"] = sharded_list_leg(ranks.world, dmap, args.list_files)
-                except Exception as e:
-                    line["sharded_list"] = {"error": repr(e)}
-                # BASELINE configs[4]: the four systems at once on the ranks' GPUs (one GPU: all on it, labelled)
-                try:
-                    line["four_systems"] = four_systems_leg(ranks.world, dmap, max(4, args.list_files // 4))
-                except Exception as e:
-                    line["four_systems"] = {"error": repr(e)}
+            line["config"]["cli_processes_timed"] = ("before this process touched the GPU" if pre else
+                                                     "behind the headline, this process holding the GPU")
+            if args.list_files > 0 and pre:
+                line["sharded_list"], line["four_systems"] = pre["sharded_list"], pre["four_systems"]
+            elif args.list_files > 0:
+                # (N ranks: the other ranks idle at the barrier below; their contexts hold no work)
+                legs = cli_process_legs(argparse.Namespace(no_extras=True, list_files=args.list_files), dmap, mdir)
+                line["sharded_list"], line["four_systems"] = legs["sharded_list"], legs["four_systems"]
             split_post = None
             gpu_post = d_post.cpu().numpy() if ranks.world == 1 else None
             if ranks.world == 1 and not args.no_extras:

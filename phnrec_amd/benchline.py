@@ -131,7 +131,7 @@ def compact(full):
     """the stdout form of a full bench record"""
     out = {k: full[k] for k in CONTRACT if k in full}
     if isinstance(out.get("config"), dict):
-        out["config"] = _pick(out["config"], ("workload", "weights", "kernel"))
+        out["config"] = _pick(out["config"], ("workload", "weights", "kernel", "cli_processes_timed"))
         out["config"]["arithmetic"] = "f32 MFMA 16x16x4, f32 accumulate"
         out["config"]["sharding"] = "replica per GPU, no collective"
     for k in ("preheat_launches", "ms_per_step_before_closing_barrier", "frames_per_s_per_gpu", "xrt", "stub",
