@@ -18,10 +18,10 @@ int main(int argc, char **argv)
     const int n = argc > 3 ? atoi(argv[3]) : 3;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
-    hipSetDevice(0);
-    hipFree(nullptr);
+    (void)hipSetDevice(0);
+    (void)hipFree(nullptr);
     hipStream_t s;
-    hipStreamCreate(&s);
+    (void)hipStreamCreate(&s);
     const auto t1 = clk::now();
     for (int k = 0; k < n && mode > 0; k++) {
         void *h = nullptr;
@@ -36,9 +36,9 @@ int main(int argc, char **argv)
             if (hipHostRegister(h, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { printf("hipHostRegister failed\n"); return 1; }
         }
         float *d = nullptr;
-        hipHostGetDevicePointer((void **)&d, h, 0);
+        (void)hipHostGetDevicePointer((void **)&d, h, 0);
         touch<<<(unsigned)((bytes / 4 + 255) / 256), 256, 0, s>>>(d, bytes / 4);      // the device really maps and walks it
-        hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s);
     }
     const auto t2 = clk::now();
     printf("mode %d  %d x %zu MiB: runtime up %.1f ms, buffers %.1f ms, main %.1f ms\n", mode, n, bytes >> 20,
