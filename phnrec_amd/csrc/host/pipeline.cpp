@@ -914,6 +914,11 @@ bool SpeechRec::RunPipeline(DataFormat in, DataFormat out, const std::function<i
     stats_.host_threads = std::max(1, pool_->Size());
     for (double k : kms) stats_.gpu_kernel_ms += k;
     stats_.contexts = contexts_up.load();
+    if (verbose_ && need_gpu && !single_file) {
+        char line[160];
+        snprintf(line, sizeof line, "Device path: %d of %d planned contexts came up and took launches\n", contexts_up.load(), n_ctx);
+        Log(line);
+    }
     stats_.files += files_done;
     stats_.frames += frames_done;
     stats_.seconds += std::chrono::duration<double>(clock::now() - t1).count();

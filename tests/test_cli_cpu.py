@@ -201,7 +201,7 @@ def test_verbose_banner(tmp_path):
 def _device_path_line(*args, env=None):
     e = dict(os.environ, **(env or {}))
     p = subprocess.run([BIN, "-v"] + [str(a) for a in args], capture_output=True, text=True, env=e)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("Device path:")]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("Device path: front-end")]      # (a list run adds "... contexts came up")
     assert len(lines) == 1, p.stdout[-800:] + p.stderr[-300:]
     return lines[0], p
 

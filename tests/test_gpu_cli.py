@@ -822,6 +822,22 @@ def test_bench_one_rank_over_rccl(tmp_path):
     assert "device_ids" not in p.stderr or "using GPU" not in p.stderr, "the barrier names its device"
 
 
+def test_verbose_says_which_contexts_came_up(tmp_path):
+    """`phnrec -v` on a list: the planned road (front-end, decoder, GPUs x contexts, ordered or shared) before the list, and
+    how many of the planned contexts came up behind it -- a short list over two logical GPUs on one device plans six and
+    gets by with fewer"""
+    lst = _make_list(tmp_path, "hu", 40, seed=3)
+    p = run("-v", "-c", model_dir(HU), "-l", lst, "-m", tmp_path / "o.mlf", "-g", 2, env={"PHNREC_DEVICE_MAP": "0,0", "AUTO": "1"})
+    lines = [l for l in p.stdout.splitlines() if l.startswith("Device path:")]
+    assert len(lines) == 2, p.stdout[-600:]
+    assert "front-end GPU (-F, chosen by itself" in lines[0] and "2 GPU(s) x 3 context(s) planned" in lines[0]
+    n = int(lines[1].split("Device path: ")[1].split(" of ")[0])
+    assert 1 <= n <= 3 and "of 6 planned contexts came up" in lines[1]
+    p = run("-v", "-c", model_dir(HU), "-l", lst, "-m", tmp_path / "o2.mlf", "-g", 2,
+            env={"PHNREC_DEVICE_MAP": "0,0", "AUTO": "1", "PHNREC_ALL_CONTEXTS": "1"})
+    assert "Device path: 6 of 6 planned contexts came up" in p.stdout
+
+
 def test_more_gpus_than_the_box_has_fails_loudly(tmp_path):
     lst = _make_list(tmp_path, "cz", 3, seed=1)
     e = dict(os.environ)
